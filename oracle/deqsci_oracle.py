@@ -1,0 +1,269 @@
+"""CPU oracle for the DEQ-SCI hot path.  TEST INFRASTRUCTURE - NOT PRODUCT CODE.
+
+A CPU restatement (torch-CPU / numpy, fp32) of the reference algorithm for the path
+BASELINE.json names: SCI operators, GAP projection, denoiser call, sigma schedule,
+Anderson / Picard fixed-point drivers, DEQFixedPoint forward, PSNR and the evaluation
+harness.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may
+import this module, and only as the checker / the reported CPU baseline; nothing under
+deqsci_amd/ imports it and the product path has no CPU fallback.
+
+Parity pin: every function below is checked in tests/test_oracle_golden.py against
+golden vectors produced by importing the reference itself in the build container
+(tests/golden/make_golden.py): ops, toy Anderson/Picard traces, FFDNet/SimpleCNN single
+forwards, a teacher-forced 12-call loop trace, and the reference's real test_solver_sci
+runs at and_maxiters 10/30/100/180.  Third-party arithmetic below the reference
+(ATen/oneDNN conv2d, bmm, LAPACK gesv) is pinned only through those goldens
+(torch 2.10 CPU on the build host) - the reference itself holds no tests.
+
+Reference citations are file:line into IndigoPurple/DEQSCI.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WEIGHTS_DIR = os.path.join(_ROOT, "deqsci_amd", "weights")
+DATA_DIR = os.path.join(_ROOT, "data", "test_gray")
+
+SIGMA0 = 60 / 255        # solvers/equilibrium_solvers_yaping.py:394,410
+SIGMA_DECAY = 0.971      # solvers/equilibrium_solvers_yaping.py:413
+
+
+# ----------------------------------------------------------------------------- operators
+def sci_forward(x, Phi):
+    """y[n,h,w] = sum_b x[n,h,w,b] * Phi[n,h,w,b]            (utils/cg_utils.py:85-90)"""
+    return torch.sum(x * Phi, dim=3)
+
+
+def sci_adjoint(y, Phi):
+    """x[n,h,w,b] = y[n,h,w] * Phi[n,h,w,b]                   (utils/cg_utils.py:124-129)"""
+    return y.unsqueeze(3) * Phi
+
+
+def initial_point(y, Phi, Phi_sum=None, gt=None):
+    """x0 = Phi^T y; Phi_sum and gt are ignored              (utils/cg_utils.py:228-229)"""
+    return sci_adjoint(y, Phi)
+
+
+def phi_sum(Phi):
+    """sum over frames with zeros replaced by one (training/sci_equilibrium_training.py:162-163)"""
+    s = torch.sum(Phi, dim=3)
+    s[s == 0] = 1
+    return s
+
+
+def gap_update(z, y, Phi, Phi_sum):
+    """z + Phi^T((y - Phi z) / Phi_sum)     (solvers/equilibrium_solvers_yaping.py:399-400)"""
+    fb = sci_forward(z, Phi)
+    return z + sci_adjoint((y - fb) / Phi_sum, Phi)
+
+
+# ----------------------------------------------------------------------------- denoisers
+def load_weights(name):
+    """name in {'cnn','ffdnet_gray','rsn_cnn'} -> {key: tensor}; 'module.' and
+    'nonlinear_op.' prefixes dropped (video_sci_proxgrad.py:217-223)."""
+    arc = np.load(os.path.join(WEIGHTS_DIR, name + ".npz"))
+    out = {}
+    for k in arc.files:
+        if k.startswith("__"):
+            continue
+        kk = k
+        for pre in ("module.", "nonlinear_op."):
+            if kk.startswith(pre):
+                kk = kk[len(pre):]
+        out[kk] = torch.from_numpy(arc[k])
+    return out
+
+
+def ffdnet_forward(W, x, sigma):
+    """FFDNet gray: predicted NOISE for x (N,1,H,W), sigma (N,).
+    networks/ffdnet/models.py:46-64,98-108; functions.py:16-53 (2x2 unshuffle, channel
+    2i+j, sigma map first) and :62-81 (inverse shuffle)."""
+    N, _, H, Wd = x.shape
+    down = F.pixel_unshuffle(x, 2)
+    nmap = sigma.reshape(N, 1, 1, 1).expand(N, 1, H // 2, Wd // 2)
+    h = torch.cat([nmap, down], dim=1)
+    p = "intermediate_dncnn.itermediate_dncnn."
+    h = F.relu(F.conv2d(h, W[p + "0.weight"], padding=1))
+    for i in range(13):
+        c, b = 2 + 3 * i, 3 + 3 * i
+        h = F.conv2d(h, W[p + f"{c}.weight"], padding=1)
+        h = F.batch_norm(h, W[p + f"{b}.running_mean"], W[p + f"{b}.running_var"],
+                         W[p + f"{b}.weight"], W[p + f"{b}.bias"], training=False, eps=1e-5)
+        h = F.relu(h)
+    h = F.conv2d(h, W[p + "41.weight"], padding=1)
+    return F.pixel_shuffle(h, 2)
+
+
+def simplecnn_forward(W, x):
+    """DE-GAP-CNN: 4 x conv3x3 (1-64-64-64-1), ReLU between, no bias/BN; predicted NOISE.
+    networks/provable/model/SimpleCNN_models.py:43-61 with num_of_layers=4, lip=0, no_bn."""
+    h = F.relu(F.conv2d(x, W["dncnn.0.weight"], padding=1))
+    h = F.relu(F.conv2d(h, W["dncnn.2.weight"], padding=1))
+    h = F.relu(F.conv2d(h, W["dncnn.4.weight"], padding=1))
+    return F.conv2d(h, W["dncnn.6.weight"], padding=1)
+
+
+def sigma_schedule(n):
+    """sigma after call c = fp32(60/255) * 0.971 (c times, fp32 multiply each time).
+    solvers/equilibrium_solvers_yaping.py:410,413."""
+    s = torch.tensor([SIGMA0], dtype=torch.float32)
+    out = []
+    for _ in range(n):
+        out.append(s.clone())
+        s = s * SIGMA_DECAY
+    return torch.cat(out)
+
+
+class ProxGradSCI:
+    """The single-iterate map f(z; y, Phi, Phi_sum) = z1 - denoiser(z1) with its state.
+    solvers/equilibrium_solvers_yaping.py:382-436 (EquilibriumProxGradSCI)."""
+
+    def __init__(self, kind, weights=None):
+        assert kind in ("ffdnet", "SimpleCNN")
+        self.kind = kind
+        self.W = weights if weights is not None else load_weights(
+            "ffdnet_gray" if kind == "ffdnet" else "cnn")
+        self.y_mean = 0
+        self.noise_sigma = torch.tensor([SIGMA0], dtype=torch.float32).expand(8)
+        self.calls = 0
+
+    @torch.no_grad()
+    def __call__(self, z, y, Phi, Phi_sum):
+        bsz, H, Wd, B = z.shape
+        z1 = gap_update(z, y, Phi, Phi_sum)
+        planar = z1.permute(0, 3, 1, 2).contiguous().view(bsz * B, 1, H, Wd)
+        if self.kind == "ffdnet":
+            ym = y.mean()
+            if bool(torch.as_tensor(self.y_mean != ym)):          # :409
+                self.noise_sigma = torch.tensor([SIGMA0], dtype=torch.float32).expand(bsz * B)
+                self.y_mean = ym
+            else:
+                self.noise_sigma = self.noise_sigma * SIGMA_DECAY
+            noise = ffdnet_forward(self.W, planar, self.noise_sigma)
+        else:
+            noise = simplecnn_forward(self.W, planar)
+        self.calls += 1
+        return z1 - noise.view(bsz, B, H, Wd).permute(0, 2, 3, 1)
+
+
+# ----------------------------------------------------------------------------- fixed-point drivers
+def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
+    """Anderson acceleration exactly as solvers/new_equilibrium_utils_yaping.py:153-189:
+    slot k % m, Gram over the first n=min(k,m) slots, bordered (n+1) system, returns the
+    last INPUT to f and the last relative residual (global over the batch)."""
+    bsz = x0.shape[0]
+    N = x0[0].numel()
+    X = torch.zeros(bsz, m, N, dtype=x0.dtype)
+    Fh = torch.zeros(bsz, m, N, dtype=x0.dtype)
+    X[:, 0] = x0.reshape(bsz, -1)
+    Fh[:, 0] = f(x0).reshape(bsz, -1)
+    X[:, 1] = Fh[:, 0]
+    Fh[:, 1] = f(Fh[:, 0].reshape(x0.shape)).reshape(bsz, -1)
+    Hm = torch.zeros(bsz, m + 1, m + 1, dtype=x0.dtype)
+    Hm[:, 0, 1:] = 1
+    Hm[:, 1:, 0] = 1
+    rhs = torch.zeros(bsz, m + 1, 1, dtype=x0.dtype)
+    rhs[:, 0] = 1
+    last, res = 0, None
+    for k in range(2, max_iter):
+        last = k
+        n = min(k, m)
+        G = Fh[:, :n] - X[:, :n]
+        Hm[:, 1:n + 1, 1:n + 1] = torch.bmm(G, G.transpose(1, 2)) + lam * torch.eye(n, dtype=x0.dtype)[None]
+        alpha = torch.linalg.solve(Hm[:, :n + 1, :n + 1], rhs[:, :n + 1])[:, 1:n + 1, 0]
+        X[:, k % m] = beta * (alpha[:, None] @ Fh[:, :n])[:, 0] + (1 - beta) * (alpha[:, None] @ X[:, :n])[:, 0]
+        Fh[:, k % m] = f(X[:, k % m].reshape(x0.shape)).reshape(bsz, -1)
+        res = (Fh[:, k % m] - X[:, k % m]).norm().item() / (1e-5 + Fh[:, k % m].norm().item())
+        if res < tol:
+            break
+    return X[:, last % m].view_as(x0), res
+
+
+def forward_iteration(f, x0, max_iter=50, tol=1e-5):
+    """Picard iteration, solvers/new_equilibrium_utils_yaping.py:213-222: returns the last
+    OUTPUT of f and the list of residuals."""
+    f0 = f(x0)
+    res = []
+    for _ in range(max_iter):
+        x = f0
+        f0 = f(x)
+        res.append((f0 - x).norm().item() / (1e-7 + f0.norm().item()))
+        if res[-1] < tol:
+            break
+    return f0, res
+
+
+def deq_forward(fmap, iterator, y, Phi, Phi_sum, x0, **kw):
+    """DEQFixedPoint.forward in inference (solvers/new_equilibrium_utils_yaping.py:249-281):
+    z*,res = iterator(f, x0); z = f(z*); one more f(z) whose output is discarded but which
+    advances the sigma state (:271-272).  Returns (z, res)."""
+    zs, res = iterator(lambda z: fmap(z, y, Phi, Phi_sum), x0, **kw)
+    z = fmap(zs, y, Phi, Phi_sum)
+    fmap(z, y, Phi, Phi_sum)
+    return z, res
+
+
+# ----------------------------------------------------------------------------- harness
+def psnr(rec, gt):
+    """10 log10(1 / mean((clip(rec,0,1)-gt)^2)): skimage PSNR for float input, data_range 1
+    (training/sci_equilibrium_training.py:182-183)."""
+    a = np.asarray(gt, dtype=np.float32)
+    b = np.clip(np.asarray(rec, dtype=np.float32), 0, 1)
+    return 10.0 * math.log10(1.0 / np.mean((a - b) ** 2, dtype=np.float64))
+
+
+def load_clip(path):
+    """v5 .mat -> gt=float32(orig)/255, mask=float32(mask), meas=float32(meas)/255
+    (utils/sci_dataloader.py:241-258)."""
+    import scipy.io as sio
+    f = sio.loadmat(path)
+    return {"gt": np.float32(f["orig"]) / 255, "mask": np.float32(f["mask"]),
+            "meas": np.float32(f["meas"]) / 255, "file": os.path.basename(path)}
+
+
+def list_clips(directory=DATA_DIR):
+    """sorted(os.listdir) order, hidden files skipped (utils/sci_dataloader.py:69-74)."""
+    return [f for f in sorted(os.listdir(directory))
+            if os.path.isfile(os.path.join(directory, f)) and not f.startswith(".")]
+
+
+def run_harness(kind, and_maxiters, iterator="anderson", directory=DATA_DIR, clips=None,
+                max_meas=None, fmap=None, crop=None):
+    """test_solver_sci restated (training/sci_equilibrium_training.py:152-205): per clip
+    Phi_sum, drop*/runner* keep measurement 0 only, per measurement x0 = Phi^T y, DEQ forward,
+    PSNR; clip mean then grand mean.  Returns dict with per-measurement records."""
+    fmap = fmap or ProxGradSCI(kind)
+    out, clip_means = [], []
+    for name in (clips or list_clips(directory)):
+        d = load_clip(os.path.join(directory, name))
+        sl = (slice(None), slice(None)) if crop is None else (slice(crop[0], crop[1]), slice(crop[2], crop[3]))
+        gt_all = torch.from_numpy(np.ascontiguousarray(d["gt"][sl]))[None]
+        meas = torch.from_numpy(np.ascontiguousarray(d["meas"][sl]))[None]
+        Phi = torch.from_numpy(np.ascontiguousarray(d["mask"][sl]))[None]
+        Ps = phi_sum(Phi)
+        if "drop" in name or "runner" in name:
+            meas = meas[..., :1]
+        M = meas.shape[3] if max_meas is None else min(max_meas, meas.shape[3])
+        ps = []
+        for fi in range(M):
+            y = meas[..., fi]
+            gt = gt_all[..., fi * 8:(fi + 1) * 8]
+            x0 = initial_point(y, Phi, Ps, gt_all)
+            c0 = fmap.calls
+            if iterator == "anderson":
+                rec, res = deq_forward(fmap, andersonexp, y, Phi, Ps, x0, m=5, beta=1.0, lam=1e-2,
+                                       max_iter=and_maxiters, tol=1e-5)
+            else:
+                rec, res = deq_forward(fmap, forward_iteration, y, Phi, Ps, x0,
+                                       max_iter=and_maxiters, tol=1e-5)
+                res = res[-1]
+            p = psnr(rec.numpy(), gt.numpy())
+            ps.append(p)
+            out.append({"id": f"{name}:{fi}", "psnr": p, "res": res, "f_calls": fmap.calls - c0,
+                        "rec": rec})
+        clip_means.append(sum(ps) / M)
+    return {"measurements": out, "clip_psnr": clip_means, "avg_psnr": sum(clip_means) / len(clip_means)}

@@ -1,0 +1,143 @@
+"""Pins the CPU oracle (oracle/deqsci_oracle.py) against golden vectors produced by the
+reference's own code (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+from oracle import deqsci_oracle as orc
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_ops_golden_bit_exact():
+    g = np.load(os.path.join(GOLDEN, "ops.npz"))
+    for c in ("c0_", "c1_", "c2_"):
+        Phi, x, z, y = T(g[c + "Phi"]), T(g[c + "x"]), T(g[c + "z"]), T(g[c + "y"])
+        assert torch.equal(orc.sci_forward(x, Phi), y)
+        assert torch.equal(orc.sci_forward(z, Phi), T(g[c + "Az"]))
+        assert torch.equal(orc.sci_adjoint(y, Phi), T(g[c + "Aty"]))
+        assert torch.equal(orc.initial_point(y, Phi), T(g[c + "x0"]))
+        Ps = orc.phi_sum(Phi)
+        assert torch.equal(Ps, T(g[c + "Phi_sum"]))
+        assert (Ps[:, 0, :3] == 1).all()
+        assert torch.equal(orc.gap_update(z, y, Phi, Ps), T(g[c + "z1"]))
+    assert torch.equal(orc.gap_update(T(g["grey_z"]), T(g["grey_y"]), T(g["grey_Phi"]), T(g["grey_Phi_sum"])),
+                       T(g["grey_z1"]))
+
+
+def _toy(a, c):
+    return lambda z: a * z + 0.3 * torch.sin(z) + c
+
+
+@pytest.mark.parametrize("bsz", [1, 3])
+def test_anderson_toy_golden(bsz):
+    g = np.load(os.path.join(GOLDEN, "anderson_toy.npz"))
+    a, c, x0 = T(g[f"b{bsz}_a"]), T(g[f"b{bsz}_c"]), T(g[f"b{bsz}_x0"])
+    for it in (3, 7, 12, 40):
+        fed = []
+
+        def f(z):
+            fed.append(z.clone())
+            return _toy(a, c)(z)
+        z, res = orc.andersonexp(f, x0, m=5, lam=1e-2, max_iter=it, tol=1e-5, beta=1.0)
+        assert torch.equal(z, T(g[f"b{bsz}_it{it}_z"])), it
+        assert res == float(g[f"b{bsz}_it{it}_res"])
+        assert torch.equal(torch.stack(fed), T(g[f"b{bsz}_it{it}_fed"]))
+    n = [0]
+
+    def f2(z):
+        n[0] += 1
+        return _toy(a, c)(z)
+    z, res = orc.andersonexp(f2, x0, m=5, lam=1e-2, max_iter=40, tol=1e-3, beta=1.0)
+    assert n[0] == int(g[f"b{bsz}_early_ncalls"]) and n[0] < 40
+    assert torch.equal(z, T(g[f"b{bsz}_early_z"])) and res == float(g[f"b{bsz}_early_res"])
+    z, res = orc.andersonexp(_toy(a, c), x0, m=3, lam=1e-3, max_iter=9, tol=1e-5, beta=0.7)
+    assert torch.equal(z, T(g[f"b{bsz}_m3beta_z"])) and res == float(g[f"b{bsz}_m3beta_res"])
+    z, res = orc.forward_iteration(_toy(a, c), x0, max_iter=15, tol=1e-5)
+    assert torch.equal(z, T(g[f"b{bsz}_picard_z"]))
+    assert np.array_equal(np.array(res), g[f"b{bsz}_picard_res"])
+    z, res = orc.forward_iteration(_toy(a, c), x0, max_iter=60, tol=1e-3)
+    assert torch.equal(z, T(g[f"b{bsz}_picard_early_z"])) and len(res) == len(g[f"b{bsz}_picard_early_res"]) < 60
+
+
+def test_denoisers_golden():
+    g = np.load(os.path.join(GOLDEN, "nets.npz"))
+    x = T(g["x"])
+    Wf, Wc = orc.load_weights("ffdnet_gray"), orc.load_weights("cnn")
+    sched = orc.sigma_schedule(51)
+    with torch.no_grad():
+        for k in (0, 1, 50):
+            assert sched[k].item() == g[f"ffdnet_sigma_k{k}"][0]
+            out = orc.ffdnet_forward(Wf, x, T(g[f"ffdnet_sigma_k{k}"]))
+            assert rel_l2(out, g[f"ffdnet_noise_k{k}"]) < 1e-6
+        assert rel_l2(orc.simplecnn_forward(Wc, x), g["cnn_noise"]) < 1e-6
+
+
+def test_sigma_sequence_golden():
+    g = np.load(os.path.join(GOLDEN, "sigma.npz"))["sigma"]
+    s = orc.sigma_schedule(len(g)).numpy()
+    assert np.array_equal(s, g)
+    assert abs(s[181] * 255 - 0.29163) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+def test_teacher_forced_trace_golden(kind):
+    """Every f-call of the reference's 12-call run (64x64 crop, and_maxiters=10): feed the
+    reference's input, compare the oracle's output; then the free-running loop end to end."""
+    g = np.load(os.path.join(GOLDEN, f"trace_{kind}.npz"))
+    Phi, y, Ps = T(g["Phi"]), T(g["y"]), T(g["Phi_sum"])
+    assert torch.equal(orc.phi_sum(Phi), Ps)
+    assert torch.equal(orc.initial_point(y, Phi), T(g["x0"]))
+    f = orc.ProxGradSCI(kind)
+    assert g["fed"].shape[0] == 12
+    for i in range(12):
+        out = f(T(g["fed"][i]), y, Phi, Ps)
+        assert rel_l2(out, g["ret"][i]) < 2e-6, i
+        if kind == "ffdnet":
+            assert np.array_equal(f.noise_sigma.numpy(), g["sigma"][i])
+    f = orc.ProxGradSCI(kind)
+    rec, res = orc.deq_forward(f, orc.andersonexp, y, Phi, Ps, T(g["x0"]), m=5, beta=1.0, lam=1e-2,
+                               max_iter=10, tol=1e-5)
+    assert f.calls == 12
+    assert rel_l2(rec, g["rec"]) < 1e-5
+    assert abs(res - float(g["res"])) < 1e-4 * float(g["res"]) + 1e-9
+
+
+def _e2e(tag):
+    with open(os.path.join(GOLDEN, f"e2e_{tag}.json")) as fh:
+        return json.load(fh)
+
+
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+def test_harness_10_iters_traffic_m0(kind):
+    """Full 256x256x8, and_maxiters=10, against the reference's own test_solver_sci run
+    (BASELINE config 1: FFDNet traffic m0 expects 12 f-calls, PSNR 19.068 dB)."""
+    meta = _e2e(f"{kind}_anderson_10")
+    want = [m for m in meta["measurements"] if m["id"] == "traffic_cacti.mat:0"][0]
+    r = orc.run_harness(kind, 10, clips=["traffic_cacti.mat"], max_meas=1)["measurements"][0]
+    assert r["f_calls"] == want["f_calls"] == 12
+    assert abs(r["psnr"] - want["psnr"]) < 1e-3
+    assert abs(r["res"] - want["res"]) < 1e-3 * want["res"]
+    if kind == "ffdnet":
+        assert abs(want["psnr"] - 19.068) < 1e-3
+        rec = np.load(os.path.join(GOLDEN, "e2e_ffdnet_anderson_10_rec.npz"))["traffic_m0"]
+        assert rel_l2(r["rec"].numpy(), rec) < 1e-5
+
+
+def test_harness_golden_metadata_consistency():
+    """Slicing rules / f-call counts / PNG payload count recorded from the reference harness."""
+    for tag, iters in (("SimpleCNN_anderson_10", 10), ("ffdnet_anderson_10", 10)):
+        meta = _e2e(tag)
+        ids = [m["id"] for m in meta["measurements"]]
+        assert ids == ["drop8_cacti.mat:0", "runner8_cacti.mat:0"] + [f"traffic_cacti.mat:{i}" for i in range(6)]
+        assert all(m["f_calls"] == iters + 2 for m in meta["measurements"])
+        assert meta["n_png_payloads"] == 64
+        ps = [m["psnr"] for m in meta["measurements"]]
+        avg = (ps[0] + ps[1] + sum(ps[2:]) / 6) / 3
+        assert abs(avg - meta["avg_psnr"]) < 1e-9
