@@ -1,0 +1,22 @@
+# Builds the C-ABI HIP library (gfx950 only) and the plain-C oracle helper.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -Wall -Wno-unused-function
+LIB        := deqsci_amd/lib/libdeqsci_hip.so
+SRCS       := deqsci_amd/csrc/sci_ops.hip deqsci_amd/csrc/anderson.hip
+HDRS       := include/deqsci_hip.h deqsci_amd/csrc/common.hpp
+ORACLE_LIB := oracle/libdeqsci_oracle.so
+
+all: $(LIB) $(ORACLE_LIB)
+
+$(LIB): $(SRCS) $(HDRS)
+	@mkdir -p deqsci_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(SRCS)
+
+$(ORACLE_LIB): oracle/deqsci_oracle.c include/deqsci_hip.h
+	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -Iinclude -o $@ oracle/deqsci_oracle.c -lm
+
+clean:
+	rm -f $(LIB) $(ORACLE_LIB)
+
+.PHONY: all clean

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py - headline metric of BASELINE.json on MI355X: reconstructed frames/s at 256x256x8,
+180 DEQ (Anderson) iterations, FFDNet denoiser, plus the HBM roofline of the fused
+Phi/Phi^T + GAP-update kernel and the reference algorithm timed on the host CPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full reconstruction pass (x0 = Phi^T y, max_iter+1 f-calls, final all-gather) over
+one synthetic batch of `--batch-per-gpu` measurements per GPU (SURVEY 8(d) C3 recipe: Bernoulli(0.5)
+masks, x ~ U[0,1), y = Phi x, seed 1234+rank), inputs resident in HBM when the timed region starts.
+Weak scaling: the per-GPU batch is fixed (BASELINE config 3: 64 measurements over 8 GPUs = 8 per GPU,
+which is also the 8 shipped measurements of config 2 at N=1).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def mix_gap_bytes(bsz, H, W, B, n):
+    """Algorithmic bytes of one launch of the fused K7+K3 kernel: per pixel read
+    n history rows + Phi (4B each per frame) + y + Phi_sum, write X_k and z1."""
+    return bsz * H * W * (4 * B * (n + 3) + 8)
+
+
+def gap_bytes(bsz, H, W, B):
+    """K3 = 12B+8 bytes per pixel."""
+    return bsz * H * W * (12 * B + 8)
+
+
+def make_batch(bsz, H, W, B, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    Phi = (torch.rand(bsz, H, W, B, device=device, generator=g) < 0.5).float()
+    x = torch.rand(bsz, H, W, B, device=device, generator=g)
+    y = (x * Phi).sum(3)
+    return y, Phi, x
+
+
+def cpu_baseline(iters_sample, full_calls, H, W, B, kind):
+    """The CPU oracle (restatement of the reference algorithm, torch-CPU fp32) on ONE synthetic
+    measurement for `iters_sample` Anderson iterations; per-f-call cost scaled to the full run."""
+    from oracle import deqsci_oracle as orc
+    g = torch.Generator().manual_seed(1234)
+    Phi = (torch.rand(1, H, W, B, generator=g) < 0.5).float()
+    x = torch.rand(1, H, W, B, generator=g)
+    y = orc.sci_forward(x, Phi)
+    Ps = orc.phi_sum(Phi)
+    f = orc.ProxGradSCI(kind)
+    f(orc.initial_point(y, Phi), y, Phi, Ps)           # warm-up call (oneDNN primitive creation)
+    f.calls = 0
+    t0 = time.perf_counter()
+    orc.deq_forward(f, orc.andersonexp, y, Phi, Ps, orc.initial_point(y, Phi), m=5, beta=1.0, lam=1e-2,
+                    max_iter=iters_sample, tol=1e-5)
+    dt = time.perf_counter() - t0
+    per_call = dt / f.calls
+    fps = B / (per_call * full_calls)
+    return {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 synthetic {H}x{W}x{B} measurement, {kind}, and_maxiters={iters_sample} ({f.calls} f-calls, "
+                      f"{dt:.1f} s) scaled per f-call to the reference's {full_calls} calls"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=180)
+    ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
+    ap.add_argument("--size", default="256x256x8")
+    ap.add_argument("--cpu-iters", type=int, default=14)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import deqsci_amd
+    from deqsci_amd import _hip, checkpoint
+    from deqsci_amd.cli import build_denoiser
+    from deqsci_amd.engine import DEQSCIEngine
+
+    H, W, B = (int(v) for v in args.size.split("x"))
+    bsz = args.batch_per_gpu
+    net = build_denoiser(args.denoiser).eval()
+    net.load_state_dict({k.replace("nonlinear_op.", ""): v for k, v in
+                         checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
+    net = net.to(dev)
+    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5)
+    y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
+    gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
+
+    # per-launch HIP-event timing of the fused Phi/Phi^T+GAP-update kernel, on the stream it runs on
+    ev_pairs = []
+    timing_on = [False]
+    if not args.no_kernel_timing:
+        orig = _hip.anderson_mix_gap
+
+        def timed_mix_gap(ws, beta, n, *a):
+            if not timing_on[0] or n != eng.m:
+                return orig(ws, beta, n, *a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(ws, beta, n, *a)
+            e1.record()
+            ev_pairs.append((e0, e1))
+        import deqsci_amd.engine as engine_mod
+        engine_mod._hip.anderson_mix_gap = timed_mix_gap
+
+    def step():
+        rec = eng.reconstruct(y, Phi)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, rec)          # the path's one collective (RCCL over xGMI)
+        return rec
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timing_on[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing_on[0] = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = world * bsz * B * args.steps
+    value = frames / elapsed
+    out = {
+        "metric": "reconstructed frames/sec at 256x256x8, 180 DEQ iters",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"synthetic batch of {bsz} measurements per GPU, {H}x{W}x{B}, Bernoulli(0.5) masks "
+                               f"(BASELINE config 3 per-GPU shard = config 2's 8 measurements at N=1); "
+                               f"{args.denoiser} denoiser ({'net_gray.pth weights, substitute for the missing ffdnet.ckpt' if args.denoiser == 'ffdnet' else 'cnn.ckpt'}), "
+                               f"Anderson m=5 lam=1e-2 beta=1, and_maxiters={args.iters}, tol=1e-5",
+                   "global_batch": world * bsz, "frames_per_measurement": B, "f_calls_per_step": eng.last_info["f_calls"],
+                   "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU"},
+        "final_res": eng.last_info["res"],
+    }
+    if rank == 0:
+        if ev_pairs:
+            ms = [a.elapsed_time(b) for a, b in ev_pairs]
+            avg_s = 1e-3 * sum(ms) / len(ms)
+            nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_mix_gap_traffic.json")
+            if os.path.exists(tfile):
+                with open(tfile) as fh:
+                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": f"mix_gap_bhw_kernel<{B}> (K7+K3: Anderson mix + Phi/Phi^T GAP update)",
+                               "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_iters, args.iters + 2, H, W, B, args.denoiser)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

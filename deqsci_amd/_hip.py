@@ -1,0 +1,262 @@
+"""ctypes binding of the C-ABI HIP library (include/deqsci_hip.h -> lib/libdeqsci_hip.so).
+
+PyTorch is used for device memory and streams only: every function takes torch CUDA(HIP)
+tensors, passes raw device pointers + the current HIP stream to the library and returns
+torch tensors.  There is NO CPU fallback: a missing library or a non-GPU tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+LAYOUT_HWB = 0   # (bsz,H,W,B)  reference API layout
+LAYOUT_BHW = 1   # (bsz,B,H,W)  planar / denoiser layout
+MAX_M = 8
+PART_STRIDE = MAX_M + 1
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdeqsci_hip.so")
+_lib = None
+
+_i64, _int, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes; the single source of truth for tests/test_cabi_exports.py too
+SIGNATURES = {
+    "deqsci_sci_forward_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],
+    "deqsci_sci_adjoint_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],
+    "deqsci_phi_sum_f32": [_ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_gap_update_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _int, _ptr],
+    "deqsci_transpose_f32": [_ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_residual_out_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_residual_store_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
+    "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
+    "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                    _i64, _i64, _i64, _i64, _int, _int, _ptr],
+}
+OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
+                 "deqsci_partials_bytes", "deqsci_gram_bytes")
+
+
+class DeqsciHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libdeqsci_hip.so (after torch, so it binds to the HIP runtime torch already loaded)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise DeqsciHipError(
+            f"{_LIB_PATH} is missing: build it with `make` (or __graft_entry__.build()). "
+            "deqsci_amd has no CPU / eager fallback for its HIP kernels.")
+    lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.deqsci_version.restype = ctypes.c_char_p
+    lib.deqsci_error_string.restype = ctypes.c_char_p
+    lib.deqsci_error_string.argtypes = [_int]
+    lib.deqsci_anderson_chunks.restype = _i64
+    lib.deqsci_anderson_chunks.argtypes = [_i64, _i64]
+    lib.deqsci_partials_bytes.restype = ctypes.c_size_t
+    lib.deqsci_partials_bytes.argtypes = [_i64, _i64]
+    lib.deqsci_gram_bytes.restype = ctypes.c_size_t
+    lib.deqsci_gram_bytes.argtypes = [_i64]
+    _lib = lib
+    return lib
+
+
+def _check(code, what):
+    if code != 0:
+        msg = load().deqsci_error_string(code).decode()
+        raise DeqsciHipError(f"{what} failed with code {code}: {msg}")
+
+
+def _p(t, name="tensor", allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise DeqsciHipError(f"{name} is None")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise DeqsciHipError(f"{name} must be a torch tensor on a HIP device (got "
+                             f"{getattr(t, 'device', type(t))}); deqsci_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise DeqsciHipError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise DeqsciHipError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _NullCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NULL = _NullCtx()
+
+
+def _dev(t):
+    """Device guard only when the tensor is not on the current device (the common case is free)."""
+    if not t.is_cuda or t.device.index == torch.cuda.current_device():
+        return _NULL
+    return torch.cuda.device(t.device)
+
+
+def f32c(t):
+    """fp32 contiguous view/copy (the reference's tensors are fp32 throughout)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _dims(layout, shape):
+    if layout == LAYOUT_HWB:
+        bsz, H, W, B = shape
+    else:
+        bsz, B, H, W = shape
+    return bsz, H, W, B
+
+
+def _shape(layout, bsz, H, W, B):
+    return (bsz, H, W, B) if layout == LAYOUT_HWB else (bsz, B, H, W)
+
+
+def _phi_shared(phi, bsz):
+    if phi.dim() == 3:
+        return 1
+    if phi.shape[0] == 1 and bsz > 1:
+        return 1
+    if phi.shape[0] != bsz:
+        raise DeqsciHipError(f"Phi batch {phi.shape[0]} does not match batch {bsz}")
+    return 0
+
+
+# ----------------------------------------------------------------------------- operators
+def sci_forward(x, phi, layout=LAYOUT_HWB, out=None):
+    bsz, H, W, B = _dims(layout, x.shape)
+    if tuple(phi.shape[-3:]) != tuple(x.shape[-3:]):
+        raise DeqsciHipError(f"x {tuple(x.shape)} and Phi {tuple(phi.shape)} do not match")
+    y = out if out is not None else torch.empty((bsz, H, W), device=x.device, dtype=torch.float32)
+    with _dev(x):
+        _check(load().deqsci_sci_forward_f32(_p(x, "x"), _p(phi, "Phi"), _p(y, "y"), bsz, H, W, B, layout,
+                                             _phi_shared(phi, bsz), _stream()), "sci_forward")
+    return y
+
+
+def sci_adjoint(y, phi, layout=LAYOUT_HWB, out=None):
+    bsz = y.shape[0]
+    _, H, W, B = _dims(layout, (1,) + tuple(phi.shape[-3:]))
+    if tuple(y.shape) != (bsz, H, W):
+        raise DeqsciHipError(f"y {tuple(y.shape)} and Phi {tuple(phi.shape)} do not match")
+    x = out if out is not None else torch.empty(_shape(layout, bsz, H, W, B), device=y.device, dtype=torch.float32)
+    with _dev(y):
+        _check(load().deqsci_sci_adjoint_f32(_p(y, "y"), _p(phi, "Phi"), _p(x, "x"), bsz, H, W, B, layout,
+                                             _phi_shared(phi, bsz), _stream()), "sci_adjoint")
+    return x
+
+
+def phi_sum(phi, layout=LAYOUT_HWB):
+    p4 = phi if phi.dim() == 4 else phi.unsqueeze(0)
+    nb, H, W, B = _dims(layout, p4.shape)
+    out = torch.empty((nb, H, W), device=phi.device, dtype=torch.float32)
+    with _dev(phi):
+        _check(load().deqsci_phi_sum_f32(_p(p4, "Phi"), _p(out), nb, H, W, B, layout, _stream()), "phi_sum")
+    return out if phi.dim() == 4 else out[0]
+
+
+def gap_update(z, phi, y, phisum, layout_in=LAYOUT_HWB, layout_out=None, out=None):
+    layout_out = layout_in if layout_out is None else layout_out
+    bsz, H, W, B = _dims(layout_in, z.shape)
+    if tuple(phi.shape[-3:]) != tuple(z.shape[-3:]) or tuple(y.shape) != (bsz, H, W):
+        raise DeqsciHipError(f"gap_update shapes z {tuple(z.shape)} Phi {tuple(phi.shape)} y {tuple(y.shape)}")
+    shared = _phi_shared(phi, bsz)
+    if phisum.numel() != (1 if shared else bsz) * H * W:
+        raise DeqsciHipError(f"Phi_sum {tuple(phisum.shape)} does not match Phi {tuple(phi.shape)} (shared={shared})")
+    z1 = out if out is not None else torch.empty(_shape(layout_out, bsz, H, W, B), device=z.device, dtype=torch.float32)
+    with _dev(z):
+        _check(load().deqsci_gap_update_f32(_p(z, "z"), _p(phi, "Phi"), _p(y, "y"), _p(phisum, "Phi_sum"), _p(z1, "z1"),
+                                            bsz, H, W, B, layout_in, layout_out, _phi_shared(phi, bsz), _stream()),
+               "gap_update")
+    return z1
+
+
+def transpose(t, to_layout, out=None):
+    """(bsz,H,W,B) -> (bsz,B,H,W) when to_layout == LAYOUT_BHW, and back."""
+    from_layout = LAYOUT_HWB if to_layout == LAYOUT_BHW else LAYOUT_BHW
+    bsz, H, W, B = _dims(from_layout, t.shape)
+    o = out if out is not None else torch.empty(_shape(to_layout, bsz, H, W, B), device=t.device, dtype=torch.float32)
+    with _dev(t):
+        _check(load().deqsci_transpose_f32(_p(t, "in"), _p(o, "out"), bsz, H, W, B, to_layout, _stream()), "transpose")
+    return o
+
+
+def residual_out(z1, noise, layout_out=LAYOUT_HWB, out=None):
+    """out = z1 - noise; z1, noise planar (bsz,B,H,W); out in layout_out."""
+    bsz, B, H, W = z1.shape
+    o = out if out is not None else torch.empty(_shape(layout_out, bsz, H, W, B), device=z1.device, dtype=torch.float32)
+    with _dev(z1):
+        code = load().deqsci_residual_out_f32(_p(z1, "z1"), _p(noise, "noise"), _p(o, "out"), bsz, H, W, B, layout_out, _stream())
+    if code == -4 and layout_out == LAYOUT_HWB:       # odd B / H*W: planar subtract, then the generic LDS transpose
+        tmp = residual_out(z1, noise, LAYOUT_BHW)
+        return transpose(tmp, LAYOUT_HWB, out=o)
+    _check(code, "residual_out")
+    return o
+
+
+# ----------------------------------------------------------------------------- Anderson workspace + steps
+class AndersonWorkspace:
+    """Caller-owned buffers for K4-K7 (the library never allocates)."""
+
+    def __init__(self, bsz, N, m, device, res_rows=1):
+        if m > MAX_M:
+            raise DeqsciHipError(f"Anderson history m={m} exceeds DEQSCI_MAX_M={MAX_M}")
+        lib = load()
+        self.bsz, self.N, self.m = bsz, N, m
+        self.F = torch.zeros((bsz, m, N), device=device, dtype=torch.float32)
+        self.G = torch.zeros((bsz, m, N), device=device, dtype=torch.float32)
+        self.nchunks = lib.deqsci_anderson_chunks(bsz, N)
+        self.partials = torch.empty(lib.deqsci_partials_bytes(bsz, N) // 4, device=device, dtype=torch.float32)
+        self.gram = torch.zeros(lib.deqsci_gram_bytes(bsz) // 8, device=device, dtype=torch.float64)
+        self.alpha = torch.zeros((bsz, MAX_M), device=device, dtype=torch.float32)
+        self.res = torch.zeros((res_rows, 1 + bsz), device=device, dtype=torch.float32)
+
+
+def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
+    with _dev(z1):
+        _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
+                                                _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
+                                                n_filled, _stream()), "residual_store")
+
+
+def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0):
+    with _dev(ws.F):
+        _check(load().deqsci_anderson_solve_f32(_p(ws.partials), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
+                                                ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()),
+               "anderson_solve")
+
+
+def anderson_mix(ws, x_out, beta, n):
+    with _dev(ws.F):
+        _check(load().deqsci_anderson_mix_f32(_p(ws.F), _p(ws.G), _p(ws.alpha), _p(x_out, "x_out"), float(beta), n,
+                                              ws.bsz, ws.N, ws.m, _stream()), "anderson_mix")
+
+
+def anderson_mix_gap(ws, beta, n, phi, y, phisum, x_out, z1, layout):
+    bsz, H, W, B = _dims(layout, z1.shape)
+    with _dev(ws.F):
+        _check(load().deqsci_anderson_mix_gap_f32(_p(ws.F), _p(ws.G), _p(ws.alpha), float(beta), n, ws.m, _p(phi, "Phi"),
+                                                  _p(y, "y"), _p(phisum, "Phi_sum"), _p(x_out, "x_out"), _p(z1, "z1"),
+                                                  bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream()), "anderson_mix_gap")

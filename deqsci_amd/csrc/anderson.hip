@@ -1,0 +1,392 @@
+// Anderson-acceleration bookkeeping for the DEQ fixed-point loop on MI355X (gfx950).
+// Reference: andersonexp, solvers/new_equilibrium_utils_yaping.py:153-189 (and the Picard
+// iterator :213-222, which only needs the two norms).
+//
+// The reference rebuilds G = F - X (n x N), the full n x n Gram matrix (torch.bmm), solves the
+// bordered system (torch.solve) and mixes (two 1 x n bmm's) with ~12 ATen launches and two
+// .item() host syncs per iteration.  Here the history is kept as F and G = F - X (X_i = F_i - G_i
+// is never stored), only the Gram row of the slot that changed is recomputed, and an iteration is
+// three launches with no host sync:
+//   K4    residual_store  F_k = z1 - noise, G_k = F_k - X_k written into slot k%m while the block
+//                         accumulates <G_k,G_j> and |F_k|^2 (wave64 shuffle tree -> LDS -> one
+//                         partial row per block; deterministic, no atomics)
+//   K5+K6 anderson_solve  fp64 finish of the partial sums, Gram row/column refresh, (n+1)x(n+1)
+//                         LU with partial pivoting (one wavefront per sample), residual norms
+//   K7    anderson_mix    X_{k+1} = sum_i alpha_i F_i [- (1-beta) sum_i alpha_i G_i], optionally fused
+//                         with the GAP projection of the result (mix_gap) so X_{k+1} is not re-read.
+// All streaming parts are HBM-bound (per iteration and sample ~ 4N(2m+3) bytes); the solve is a
+// few hundred flops.
+#include "common.hpp"
+
+namespace deqsci {
+
+// ------------------------------------------------------------------------------------------------
+// K4
+// ------------------------------------------------------------------------------------------------
+template <int NF>   // number of filled history slots INCLUDING the one being written
+__global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restrict__ z1, const float* __restrict__ noise,
+                                                            const float* x_cur, float* __restrict__ F_hist,
+                                                            float* __restrict__ G_hist, float* x_next,
+                                                            float* __restrict__ partials, int64_t N, int m, int slot,
+                                                            int64_t chunk, int vec) {
+    const int64_t s = blockIdx.y;
+    const int64_t beg = (int64_t)blockIdx.x * chunk;
+    const int64_t end = (beg + chunk < N) ? beg + chunk : N;
+    const float* zs = z1 + s * N;
+    const float* ns = noise ? noise + s * N : nullptr;
+    const float* xs = x_cur + s * N;
+    float* Fs = F_hist + (s * m + slot) * N;
+    float* Gs = G_hist + (s * m + slot) * N;
+    const float* Gall = G_hist + (s * m) * N;
+    float* xn = x_next ? x_next + s * N : nullptr;
+
+    float acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[j] = 0.0f;
+    float accf = 0.0f;
+
+    if (vec) {
+        for (int64_t i = beg + 4 * threadIdx.x; i < end; i += 4 * TB) {
+            float4 f = ld4(zs + i);
+            if (ns) f = f - ld4(ns + i);
+            const float4 g = f - ld4(xs + i);
+            float4 o[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) o[j] = (j == slot) ? g : ld4(Gall + j * N + i);
+            st4(Fs + i, f);
+            st4(Gs + i, g);
+            if (xn) st4(xn + i, f);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = dot4_fma(g, (j == slot) ? g : o[j], acc[j]);
+            accf = dot4_fma(f, f, accf);
+        }
+    } else {
+        for (int64_t i = beg + threadIdx.x; i < end; i += TB) {
+            float f = zs[i];
+            if (ns) f -= ns[i];
+            const float g = f - xs[i];
+            Fs[i] = f;
+            Gs[i] = g;
+            if (xn) xn[i] = f;
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = fmaf(g, (j == slot) ? g : Gall[j * N + i], acc[j]);
+            accf = fmaf(f, f, accf);
+        }
+    }
+
+    __shared__ float red[TB / WAVE][PART_STRIDE];
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const float v = wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = v;
+    }
+    {
+        const float v = wave_sum(accf);
+        if (lane == 0) red[wave][MAXM] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < PART_STRIDE) {
+        const int j = threadIdx.x;
+        float v = 0.0f;
+        if (j < NF || j == MAXM) v = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+        partials[(s * gridDim.x + blockIdx.x) * PART_STRIDE + j] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 + K6
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TB) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
+                                                            float* __restrict__ alpha, float* __restrict__ res, int bsz,
+                                                            int nchunks, int slot, int n_filled, int n, float lam, float eps) {
+    constexpr int NW = TB / WAVE;
+    __shared__ double A[NW][MAXM + 1][MAXM + 2];
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    for (int s = wave; s < bsz; s += NW) {
+        double* gs = gram + (int64_t)s * GRAM_STRIDE;
+        const float* ps = partials + (int64_t)s * nchunks * PART_STRIDE;
+        for (int j = 0; j <= n_filled; ++j) {
+            const int col = j < n_filled ? j : MAXM;
+            double a = 0.0;
+            for (int c = lane; c < nchunks; c += WAVE) a += (double)ps[(int64_t)c * PART_STRIDE + col];
+            a = wave_sum(a);
+            if (lane == 0) {
+                if (j < n_filled) { gs[slot * MAXM + j] = a; gs[j * MAXM + slot] = a; }
+                else gs[MAXM * MAXM] = a;                       // |F_k|^2
+            }
+        }
+        if (lane == 0) {
+            gs[MAXM * MAXM + 1] = gs[slot * MAXM + slot];        // |G_k|^2
+            if (n > 0) {
+                // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180)
+                const int nn = n + 1;
+                double (*M)[MAXM + 2] = A[wave];
+                for (int i = 0; i < nn; ++i)
+                    for (int j = 0; j < nn; ++j) {
+                        double v;
+                        if (i == 0 && j == 0) v = 0.0;
+                        else if (i == 0 || j == 0) v = 1.0;
+                        else v = gs[(i - 1) * MAXM + (j - 1)] + (i == j ? (double)lam : 0.0);
+                        M[i][j] = v;
+                    }
+                for (int i = 0; i < nn; ++i) M[i][nn] = (i == 0) ? 1.0 : 0.0;
+                for (int k = 0; k < nn; ++k) {                    // LU, partial pivoting (as LAPACK gesv)
+                    int piv = k;
+                    double best = fabs(M[k][k]);
+                    for (int i = k + 1; i < nn; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; piv = i; } }
+                    if (piv != k) for (int j = 0; j <= nn; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+                    const double inv = 1.0 / M[k][k];
+                    for (int i = k + 1; i < nn; ++i) {
+                        const double f = M[i][k] * inv;
+                        for (int j = k; j <= nn; ++j) M[i][j] -= f * M[k][j];
+                    }
+                }
+                for (int i = nn - 1; i >= 0; --i) {
+                    double v = M[i][nn];
+                    for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
+                    M[i][nn] = v / M[i][i];
+                }
+                for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sg = 0.0, sf = 0.0;
+        for (int s = 0; s < bsz; ++s) {
+            const double ff = gram[(int64_t)s * GRAM_STRIDE + MAXM * MAXM];
+            const double gg = gram[(int64_t)s * GRAM_STRIDE + MAXM * MAXM + 1];
+            res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
+            sg += gg;
+            sf += ff;
+        }
+        res[0] = (float)(sqrt(sg) / ((double)eps + sqrt(sf)));   // whole-batch norms, :184
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 (flat) and K7+K3 (HWB / BHW)
+// ------------------------------------------------------------------------------------------------
+struct Coef { float a[MAXM]; };
+
+__device__ __forceinline__ Coef load_coef(const float* alpha, int64_t s, int n) {
+    Coef c;
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) c.a[i] = i < n ? alpha[s * MAXM + i] : 0.0f;
+    return c;
+}
+
+// x = beta * sum a_i F_i + (1-beta) * sum a_i (F_i - G_i) = sum a_i F_i - (1-beta) sum a_i G_i
+__device__ __forceinline__ float4 mix4(const float* Fs, const float* Gs, int64_t N, int64_t off, const Coef& c, int n, float omb) {
+    float4 x = f4(0.0f);
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) if (i < n) x = fma4(c.a[i], ld4(Fs + i * N + off), x);
+    if (omb != 0.0f) {
+        float4 g = f4(0.0f);
+#pragma unroll
+        for (int i = 0; i < MAXM; ++i) if (i < n) g = fma4(c.a[i], ld4(Gs + i * N + off), g);
+        x = fma4(-omb, g, x);
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(TB) void mix_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
+                                                 const float* __restrict__ alpha, float* __restrict__ x_out, float omb, int n,
+                                                 int64_t N, int m, int vec) {
+    const int64_t s = blockIdx.y;
+    const Coef c = load_coef(alpha, s, n);
+    const float* Fs = F_hist + s * m * N;
+    const float* Gs = G_hist + s * m * N;
+    float* xs = x_out + s * N;
+    if (vec) {
+        const int64_t i = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
+        if (i < N) st4(xs + i, mix4(Fs, Gs, N, i, c, n, omb));
+    } else {
+        const int64_t i0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
+        const int64_t i1 = i0 + 4 < N ? i0 + 4 : N;
+        for (int64_t i = i0; i < i1; ++i) {
+            float x = 0.0f, g = 0.0f;
+            for (int k = 0; k < n; ++k) { x = fmaf(c.a[k], Fs[k * N + i], x); g = fmaf(c.a[k], Gs[k * N + i], g); }
+            xs[i] = omb != 0.0f ? fmaf(-omb, g, x) : x;
+        }
+    }
+}
+
+constexpr int UNR = 2;
+
+template <int LP>
+__global__ __launch_bounds__(TB) void mix_gap_hwb_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
+                                                         const float* __restrict__ alpha, float omb, int n, int m,
+                                                         const float* __restrict__ phi, const float* __restrict__ y,
+                                                         const float* __restrict__ phisum, float* __restrict__ x_out,
+                                                         float* __restrict__ z1, int64_t P, int phi_shared) {
+    const int64_t s = blockIdx.y;
+    const int64_t Q = P * LP, N = Q * 4;
+    const Coef c = load_coef(alpha, s, n);
+    const float* Fs = F_hist + s * m * N;
+    const float* Gs = G_hist + s * m * N;
+    const float* ps = phi + (phi_shared ? 0 : s * N);
+    const float* ys = y + s * P;
+    const float* ss = phisum + (phi_shared ? 0 : s * P);
+    const int64_t base = (int64_t)blockIdx.x * (TB * UNR) + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < UNR; ++j) {
+        const int64_t q = base + j * TB;
+        const int64_t qc = q < Q ? q : Q - 1;
+        const float4 x = mix4(Fs, Gs, N, qc * 4, c, n, omb);
+        const float4 pv = ld4(ps + qc * 4);
+        const float fb = group_sum<LP>(dot4_seq(x, pv));
+        const float r = (ys[qc / LP] - fb) / ss[qc / LP];
+        if (q < Q) {
+            st4(x_out + s * N + q * 4, x);
+            st4(z1 + s * N + q * 4, x + r * pv);
+        }
+    }
+}
+
+template <int BT>
+__global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
+                                                         const float* __restrict__ alpha, float omb, int n, int m,
+                                                         const float* __restrict__ phi, const float* __restrict__ y,
+                                                         const float* __restrict__ phisum, float* __restrict__ x_out,
+                                                         float* __restrict__ z1, int64_t P, int phi_shared) {
+    const int64_t s = blockIdx.y;
+    const int64_t p = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
+    if (p >= P) return;
+    const int64_t N = (int64_t)BT * P;
+    const Coef c = load_coef(alpha, s, n);
+    const float* Fs = F_hist + s * m * N;
+    const float* Gs = G_hist + s * m * N;
+    const float* ps = phi + (phi_shared ? 0 : s * N) + p;
+    float4 xv[BT], pv[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        xv[b] = mix4(Fs, Gs, N, b * P + p, c, n, omb);
+        pv[b] = ld4(ps + b * P);
+    }
+    const float4 yv = ld4(y + s * P + p);
+    const float4 sv = ld4(phisum + (phi_shared ? 0 : s * P) + p);
+    float4 fb = xv[0] * pv[0];
+#pragma unroll
+    for (int b = 1; b < BT; ++b) fb = fb + xv[b] * pv[b];
+    const float4 r = (yv - fb) / sv;
+    float* xo = x_out + s * N + p;
+    float* zo = z1 + s * N + p;
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        st4(xo + b * P, xv[b]);
+        st4(zo + b * P, xv[b] + r * pv[b]);
+    }
+}
+
+static inline int64_t chunk_elems(int64_t bsz, int64_t N) {
+    // ~2048 blocks over the whole batch, each block a whole number of 1024-element sweeps (>= 2)
+    int64_t per_sample = 2048 / (bsz > 0 ? bsz : 1);
+    if (per_sample < 1) per_sample = 1;
+    int64_t chunk = ceil_div(ceil_div(N, per_sample), 1024) * 1024;
+    if (chunk < 2048) chunk = 2048;
+    return chunk;
+}
+
+}  // namespace deqsci
+
+using namespace deqsci;
+
+extern "C" {
+
+int64_t deqsci_anderson_chunks(int64_t bsz, int64_t N) {
+    if (bsz <= 0 || N <= 0) return 0;
+    return ceil_div(N, chunk_elems(bsz, N));
+}
+
+size_t deqsci_partials_bytes(int64_t bsz, int64_t N) {
+    return (size_t)(bsz * deqsci_anderson_chunks(bsz, N)) * PART_STRIDE * sizeof(float);
+}
+
+size_t deqsci_gram_bytes(int64_t bsz) { return (size_t)bsz * GRAM_STRIDE * sizeof(double); }
+
+int deqsci_residual_store_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
+                              float* x_next, float* partials, int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                              deqsci_stream_t stream) {
+    if (!z1 || !x_cur || !F_hist || !G_hist || !partials) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || slot >= n_filled) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(z1) || (noise && !aligned16(noise)) || !aligned16(x_cur) || !aligned16(F_hist) || !aligned16(G_hist) ||
+        (x_next && !aligned16(x_next)))
+        return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t chunk = chunk_elems(bsz, N);
+    const dim3 grid(ceil_div(N, chunk), bsz);
+    const int vec = (N % 4 == 0) ? 1 : 0;
+#define RS_CASE(NF) case NF: hipLaunchKernelGGL(residual_store_kernel<NF>, grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec); break;
+    switch (n_filled) {
+        RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
+        default: return DEQSCI_ERR_UNSUPPORTED;
+    }
+#undef RS_CASE
+    return launch_status();
+}
+
+int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                              int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    if (!partials || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+    hipLaunchKernelGGL(anderson_solve_kernel, dim3(1), dim3(TB), 0, st, partials, static_cast<double*>(gram), alpha, res,
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps);
+    return launch_status();
+}
+
+int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha, float* x_out, float beta, int n,
+                            int64_t bsz, int64_t N, int m, deqsci_stream_t stream) {
+    if (!F_hist || !G_hist || !alpha || !x_out) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || n < 1 || n > m) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(F_hist) || !aligned16(G_hist) || !aligned16(x_out)) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mix_kernel, dim3(ceil_div(ceil_div(N, 4), TB), bsz), dim3(TB), 0, st, F_hist, G_hist, alpha, x_out,
+                       1.0f - beta, n, N, m, (N % 4 == 0) ? 1 : 0);
+    return launch_status();
+}
+
+int deqsci_anderson_mix_gap_f32(const float* F_hist, const float* G_hist, const float* alpha, float beta, int n, int m,
+                                const float* phi, const float* y, const float* phisum, float* x_out, float* z1,
+                                int64_t bsz, int64_t H, int64_t W, int64_t B, int layout, int phi_shared,
+                                deqsci_stream_t stream) {
+    if (!F_hist || !G_hist || !alpha || !phi || !y || !phisum || !x_out || !z1) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || H <= 0 || W <= 0 || B <= 0 || m <= 0 || n < 1 || n > m) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535 || (layout != DEQSCI_LAYOUT_HWB && layout != DEQSCI_LAYOUT_BHW)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(F_hist) || !aligned16(G_hist) || !aligned16(phi) || !aligned16(y) || !aligned16(phisum) || !aligned16(x_out) ||
+        !aligned16(z1))
+        return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t P = H * W, N = P * B;
+    const float omb = 1.0f - beta;
+    if (layout == DEQSCI_LAYOUT_HWB && (B == 4 || B == 8 || B == 16 || B == 32)) {
+        const int LPv = (int)(B / 4);
+        const dim3 grid(ceil_div(P * LPv, TB * UNR), bsz);
+        switch (LPv) {
+            case 1: hipLaunchKernelGGL(mix_gap_hwb_kernel<1>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared); break;
+            case 2: hipLaunchKernelGGL(mix_gap_hwb_kernel<2>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared); break;
+            case 4: hipLaunchKernelGGL(mix_gap_hwb_kernel<4>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared); break;
+            default: hipLaunchKernelGGL(mix_gap_hwb_kernel<8>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared); break;
+        }
+        return launch_status();
+    }
+    if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0 && (B == 4 || B == 8 || B == 16)) {
+        const dim3 grid(ceil_div(P / 4, TB), bsz);
+        if (B == 4) hipLaunchKernelGGL(mix_gap_bhw_kernel<4>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);
+        else if (B == 8) hipLaunchKernelGGL(mix_gap_bhw_kernel<8>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);
+        else hipLaunchKernelGGL(mix_gap_bhw_kernel<16>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);
+        return launch_status();
+    }
+    // any other shape: the two unfused kernels back to back (x_out is the only intermediate)
+    int e = deqsci_anderson_mix_f32(F_hist, G_hist, alpha, x_out, beta, n, bsz, N, m, stream);
+    if (e) return e;
+    return deqsci_gap_update_f32(x_out, phi, y, phisum, z1, bsz, H, W, B, layout, layout, phi_shared, stream);
+}
+
+}  // extern "C"

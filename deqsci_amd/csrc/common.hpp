@@ -1,0 +1,66 @@
+// Shared device/host helpers for libdeqsci_hip (gfx950 only: wave64, no portability shims).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "deqsci_hip.h"
+
+namespace deqsci {
+
+constexpr int TB = 256;     // threads per block: 4 wavefronts, one per SIMD
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 operator/(float4 a, float4 b) { return make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+__device__ __forceinline__ float4 operator*(float a, float4 b) { return make_float4(a * b.x, a * b.y, a * b.z, a * b.w); }
+__device__ __forceinline__ float4 fma4(float a, float4 b, float4 c) {
+    return make_float4(fmaf(a, b.x, c.x), fmaf(a, b.y, c.y), fmaf(a, b.z, c.z), fmaf(a, b.w, c.w));
+}
+// ((a.x*b.x + a.y*b.y) + a.z*b.z) + a.w*b.w, products and sums rounded separately (no FMA) so the
+// frame sum of K1/K3 matches a left-to-right fp32 sum of the reference's materialised x*Phi.
+__device__ __forceinline__ float dot4_seq(float4 a, float4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+__device__ __forceinline__ float dot4_fma(float4 a, float4 b, float acc) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, fmaf(a.x, b.x, acc))));
+}
+
+// Sum over the LP adjacent lanes that hold the B = 4*LP frames of one pixel (HWB layout).
+// xor-butterfly: every lane of the group ends with the bit-identical total.
+template <int LP>
+__device__ __forceinline__ float group_sum(float v) {
+    if (LP >= 2) v += __shfl_xor(v, 1, WAVE);
+    if (LP >= 4) v += __shfl_xor(v, 2, WAVE);
+    if (LP >= 8) v += __shfl_xor(v, 4, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : static_cast<int>(e);
+}
+
+// history depth / partial layout shared by K4 and K5+K6
+constexpr int MAXM = DEQSCI_MAX_M;
+constexpr int PART_STRIDE = DEQSCI_PART_STRIDE;      // <G_k,G_j> j<MAXM, then |F_k|^2
+constexpr int GRAM_STRIDE = 80;                      // doubles per sample: 64 Gram + ff + gg, padded to 640 B
+
+}  // namespace deqsci

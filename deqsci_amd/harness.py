@@ -1,0 +1,105 @@
+"""Evaluation harness with the reference's behaviour.
+
+    load_test_data / SCITestDataset   utils/sci_dataloader.py:241-274 (v5 .mat, sorted file order)
+    test_solver_sci                   training/sci_equilibrium_training.py:152-205
+    psnr                              skimage.metrics.peak_signal_noise_ratio for float input, range 1
+    tensor_to_np                      ibid. :19-21 (PNG payload: clip(0,1)*255)
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import operators
+
+
+def load_test_data(matfile):
+    import scipy.io as sio
+    try:
+        f = sio.loadmat(matfile)
+    except NotImplementedError as e:                      # MATLAB v7.3 (HDF5): needs h5py, absent here
+        raise NotImplementedError(f"{matfile}: MATLAB v7.3 files need h5py (SURVEY section 8(f-2))") from e
+    return {'gt': np.float32(f['orig']) / 255, 'mask': np.float32(f['mask']), 'meas': np.float32(f['meas']) / 255}
+
+
+def directory_filelist(target_directory):
+    return [f for f in sorted(os.listdir(target_directory))
+            if os.path.isfile(os.path.join(target_directory, f)) and not f.startswith('.')]
+
+
+class SCITestDataset(torch.utils.data.Dataset):
+    def __init__(self, dir):
+        self.dir = dir
+        self.filelist = directory_filelist(dir)
+
+    def __len__(self):
+        return len(self.filelist)
+
+    def __getitem__(self, item):
+        data = load_test_data(os.path.join(self.dir, self.filelist[item]))
+        data['file'] = self.filelist[item]
+        return data
+
+
+def psnr(rec, gt):
+    a = np.asarray(gt, dtype=np.float32)
+    b = np.asarray(rec, dtype=np.float32)
+    return 10.0 * math.log10(1.0 / np.mean((a - b) ** 2, dtype=np.float64))
+
+
+def tensor_to_np(tensor):
+    return tensor.clip(0, 1).cpu().detach().unsqueeze(2).numpy() * 255.
+
+
+def write_png(path, img):
+    """cv2.imwrite(path, float image) casts with saturate_cast<uchar>(round-half-even); PIL is what is
+    installed here, so the rounding is restated (np.rint = half-to-even, then clip)."""
+    from PIL import Image
+    a = np.clip(np.rint(np.asarray(img, dtype=np.float64)), 0, 255).astype(np.uint8)
+    Image.fromarray(a[..., 0] if a.ndim == 3 else a).save(path)
+
+
+def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, verbose=True, save_image=True,
+                    device="cuda", records=None):
+    """Per clip: Phi_sum; drop*/runner* keep measurement 0; per measurement x0 = At(y,Phi), DEQ forward,
+    PSNR; clip mean; grand mean.  Returns (avg_psnr, {png_path: HxWx1 float image})."""
+    all_images = {}
+    psnr_sum_for_avg, num_for_avg = 0, 0
+    for sample_batch in test_dataloader:
+        gt_batch = sample_batch['gt'].to(device)
+        y_batch = sample_batch['meas'].to(device)
+        Phi = sample_batch['mask'].to(device)
+        Phi_sum = operators.phi_sum(Phi)
+        file_name = sample_batch['file']
+        if ('drop' in file_name[0]) or ('runner' in file_name[0]):
+            y_batch = y_batch[:, :, :, 0].unsqueeze(3)
+        psnr_sum = 0
+        bsz, h, w, f = y_batch.shape
+        for fi in range(f):
+            gt = gt_batch[:, :, :, fi * 8:(fi + 1) * 8]
+            y = y_batch[:, :, :, fi].contiguous()
+            with torch.no_grad():
+                initial_point = operators.initial_point(y, Phi, Phi_sum, gt_batch)
+            reconstruction = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=initial_point, train_flag=False)
+            rec_np = reconstruction.clip(0, 1).cpu().detach().numpy()
+            PSNR = psnr(rec_np, gt.cpu().numpy())
+            if records is not None:
+                records.append({"id": f"{file_name[0]}:{fi}", "psnr": PSNR, "res": deep_eq_module.forward_res,
+                                "rec": reconstruction.detach().cpu()})
+            for frame_id in range(8):
+                all_images[(save_img_path or "") + '%s_reconstruction_%d.png' % (file_name[0], fi * 8 + frame_id)] = \
+                    tensor_to_np(reconstruction[0, :, :, frame_id])
+            psnr_sum += PSNR
+        current_psnr = psnr_sum / f
+        psnr_sum_for_avg += current_psnr
+        num_for_avg += 1
+        if verbose:
+            print(file_name, '  PSNR: %.2f dB' % current_psnr)
+    avg_psnr = psnr_sum_for_avg / num_for_avg
+    if verbose:
+        print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg_psnr)
+    if save_image:
+        for k in all_images:
+            write_png(k, all_images[k])
+    return avg_psnr, all_images

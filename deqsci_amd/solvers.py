@@ -1,0 +1,184 @@
+"""Drop-in solver surface of the reference, backed by the HIP kernels.
+
+    EquilibriumProxGradSCI(A, At, nonlinear_operator, eta, minval, maxval).forward(z, y, Phi, Phi_sum)
+                                   solvers/equilibrium_solvers_yaping.py:382-436
+    andersonexp(f, x0, m, lam, max_iter, tol, beta) -> (z, res)
+                                   solvers/new_equilibrium_utils_yaping.py:153-189
+    forward_iteration(f, x0, max_iter, tol) -> (z, [res])            ibid. :213-222
+    DEQFixedPoint(f, solver, **kwargs).forward(y, Phi, Phi_sum, initial_point, train_flag)
+                                   ibid. :241-281 (inference part)
+
+Same names, argument meaning and error behaviour, tensors in the reference's (bsz,H,W,B) layout.
+`andersonexp` / `forward_iteration` accept ANY callable f (kernels K4-K7 on flat (bsz,N) views, one
+residual read-back per iteration exactly like the reference's `.item()`); when DEQFixedPoint is
+given this module's EquilibriumProxGradSCI together with one of these two iterators it routes the
+whole loop to deqsci_amd.engine.DEQSCIEngine (planar state, fused kernels, no per-iteration sync).
+"""
+import torch
+import torch.nn as nn
+
+from . import _hip
+from ._hip import LAYOUT_BHW, LAYOUT_HWB
+from .engine import SIGMA0, SIGMA_DECAY, DEQSCIEngine
+from .operators import A_torch_, At_torch_
+
+
+class EquilibriumProxGradSCI(nn.Module):
+    def __init__(self, A, At, nonlinear_operator, eta, minval=-1, maxval=1):
+        super().__init__()
+        self.A = A
+        self.At = At
+        self.nonlinear_op = nonlinear_operator
+        self.minval = minval
+        self.maxval = maxval
+        self.y = 0
+        self.noise_sigma = None
+        self._y_key = None
+
+    def _sigma(self, y, n):
+        """sigma bookkeeping of :408-413: restart at 60/255 when y.mean() changes, else *0.971.
+        The mean is only recomputed (one host sync) when a different y tensor is passed."""
+        key = (y.data_ptr(), y._version, tuple(y.shape))
+        changed = True
+        if key == self._y_key:
+            changed = False
+        else:
+            ym = y.mean()
+            changed = bool(torch.as_tensor(self.y != ym))
+            self.y = ym
+            self._y_key = key
+        if changed or self.noise_sigma is None:
+            self.noise_sigma = torch.full((1,), SIGMA0, dtype=torch.float32, device=y.device).expand(n)
+        else:
+            self.noise_sigma = self.noise_sigma * SIGMA_DECAY
+        return self.noise_sigma
+
+    def forward(self, z, y, Phi, Phi_sum):
+        bsz, w, h, c = z.shape
+        op = self.nonlinear_op
+        tag = getattr(op, "tag", None)
+        if self.A is A_torch_ and self.At is At_torch_:
+            # K3 fused with the permute(0,3,1,2).contiguous() of :415/:419
+            z1 = _hip.gap_update(_hip.f32c(z), _hip.f32c(Phi), _hip.f32c(y), _hip.f32c(Phi_sum), LAYOUT_HWB, LAYOUT_BHW)
+        else:
+            fb = self.A(z, Phi)
+            z1 = _hip.transpose(_hip.f32c(z + self.At((y - fb) / Phi_sum, Phi)), LAYOUT_BHW)
+        if tag == 'conv2d':
+            out = op(z1.view(bsz * c, 1, w, h))
+            return _hip.transpose(_hip.f32c(out.reshape(bsz, c, w, h)), LAYOUT_HWB)
+        if tag == 'conv3d':
+            out = op(z1.view(bsz, 1, c, w, h))
+            return _hip.transpose(_hip.f32c(out.reshape(bsz, c, w, h)), LAYOUT_HWB)
+        if tag == 'ffdnet':
+            noise = op(z1.view(bsz * c, 1, w, h), self._sigma(y, bsz * c))
+        elif tag == 'denoiser':
+            noise = op(z1.view(bsz * c, 1, w, h))
+        elif tag == '3d_denoiser':
+            noise = op(z1.view(bsz, 1, c, w, h))
+        else:
+            print('unknown nonlinear_op tag!')
+            raise UnboundLocalError("local variable 'z_tplus1' referenced before assignment")
+        return _hip.residual_out(z1, _hip.f32c(noise.reshape(bsz, c, w, h)), LAYOUT_HWB)
+
+
+def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
+    """Anderson acceleration for fixed point iteration (generic f)."""
+    bsz = x0.shape[0]
+    shape = x0.shape
+    xa = _hip.f32c(x0).reshape(bsz, -1)
+    N = xa.shape[1]
+    if m < 2:
+        raise IndexError("index 1 is out of bounds for dimension 1 with size %d" % m)
+    ws = _hip.AndersonWorkspace(bsz, N, m, x0.device)
+    xb = torch.empty_like(xa)
+    flat = lambda t: _hip.f32c(t).reshape(bsz, N)
+    _hip.residual_store(ws, flat(f(xa.view(shape))), None, xa, 0, 1, xb)       # X1 = F0
+    _hip.anderson_solve(ws, 0, 1, 0, lam, 1e-5)
+    _hip.residual_store(ws, flat(f(xb.view(shape))), None, xb, 1, 2, None)
+    _hip.anderson_solve(ws, 1, 2, 2, lam, 1e-5)
+    bufs = [xa.clone(), xb]
+    cur = bufs[0]                                                              # X[:, 0] = x0 if the loop is skipped
+    res = None
+    for k in range(2, max_iter):
+        n = min(k, m)
+        cur = bufs[k % 2]
+        _hip.anderson_mix(ws, cur, beta, n)
+        nf = min(k + 1, m)
+        _hip.residual_store(ws, flat(f(cur.view(shape))), None, cur, k % m, nf, None)
+        _hip.anderson_solve(ws, k % m, nf, nf, lam, 1e-5)
+        res = ws.res[0, 0].item()
+        if res < tol:
+            break
+    if res is None:
+        raise UnboundLocalError("local variable 'res' referenced before assignment")
+    return cur.view(shape), res
+
+
+def forward_iteration(f, x0, max_iter=50, tol=1e-5):
+    bsz = x0.shape[0]
+    shape = x0.shape
+    f0 = f(x0)
+    N = f0[0].numel()
+    ws = _hip.AndersonWorkspace(bsz, N, 1, x0.device)
+    res = []
+    for k in range(max_iter):
+        x = f0
+        f0 = f(x)
+        _hip.residual_store(ws, _hip.f32c(f0).reshape(bsz, N), None, _hip.f32c(x).reshape(bsz, N), 0, 1, None)
+        _hip.anderson_solve(ws, 0, 1, 0, 0.0, 1e-7)
+        res.append(ws.res[0, 0].item())
+        if res[-1] < tol:
+            break
+    return f0, res
+
+
+class DEQFixedPoint(nn.Module):
+    def __init__(self, f, solver, **kwargs):
+        super().__init__()
+        self.f = f
+        self.solver = solver
+        self.kwargs = kwargs
+        self.forward_res = None
+        self.use_engine = True
+        self._engine = None
+
+    def _engine_for(self):
+        f = self.f.module if isinstance(self.f, nn.DataParallel) else self.f
+        if not (self.use_engine and isinstance(f, EquilibriumProxGradSCI) and f.A is A_torch_ and f.At is At_torch_):
+            return None
+        if getattr(f.nonlinear_op, "tag", None) not in ("conv2d", "conv3d", "ffdnet", "denoiser", "3d_denoiser"):
+            return None
+        kw = dict(self.kwargs)
+        if self.solver is andersonexp:
+            cfg = dict(iterator="anderson", m=kw.pop("m", 5), lam=kw.pop("lam", 1e-4), max_iter=kw.pop("max_iter", 50),
+                       tol=kw.pop("tol", 1e-5), beta=kw.pop("beta", 1.0))
+        elif self.solver is forward_iteration:
+            cfg = dict(iterator="picard", max_iter=kw.pop("max_iter", 50), tol=kw.pop("tol", 1e-5))
+        else:
+            return None
+        if kw:
+            raise TypeError(f"{self.solver.__name__}() got an unexpected keyword argument '{next(iter(kw))}'")
+        key = (id(f.nonlinear_op), f.nonlinear_op.training, tuple(sorted(cfg.items())))
+        if self._engine is None or self._engine[0] != key:
+            self._engine = (key, DEQSCIEngine(f.nonlinear_op, **cfg))
+        return self._engine[1]
+
+    def forward(self, x, Phi, Phi_sum, initial_point=None, train_flag=True):
+        """x is the measurement y.  Inference only: the reference's implicit-differentiation backward
+        hook (:274-280, training) is outside this build's scope; `train_flag` is ignored as in the reference."""
+        init_point = torch.zeros_like(x) if initial_point is None else initial_point
+        eng = self._engine_for()
+        if eng is not None:
+            z = eng.reconstruct(x, Phi, Phi_sum, initial_point=init_point)
+            info = eng.last_info
+            if eng.iterator == "picard":
+                rows = eng._ws[next(iter(eng._ws))].host_res
+                self.forward_res = [float(v) for v in rows[1:info["iterations"] + 1, 0]]
+            else:
+                self.forward_res = info["res"]
+            return z
+        with torch.no_grad():
+            z, self.forward_res = self.solver(lambda z: self.f(z, x, Phi, Phi_sum), init_point, **self.kwargs)
+            z = self.f(z, x, Phi, Phi_sum)
+            self.f(z, x, Phi, Phi_sum)      # the reference's f0 = f(z0): advances the sigma state (:271-272)
+        return z

@@ -1,0 +1,130 @@
+/*
+ * deqsci_hip.h - C ABI of libdeqsci_hip.so: the MI355X (gfx950) kernels of the DEQ-SCI
+ * reconstruction hot path (SCI sensing operators, GAP projection, Anderson fixed-point
+ * bookkeeping).  Plain pointers and sizes only - no torch / C++ types cross this boundary.
+ *
+ * The reference (IndigoPurple/DEQSCI) is pure Python and has no FFI; each entry point below
+ * replaces the ATen expression(s) the reference evaluates at the cited file:line.  The binding a
+ * reference maintainer would add is a ctypes stub - see INTEGRATION.md.
+ *
+ * Conventions
+ *   - All tensor pointers are DEVICE pointers to contiguous fp32, 16-byte aligned.
+ *   - Layouts: DEQSCI_LAYOUT_HWB = (bsz,H,W,B), frames innermost - the reference's API layout
+ *     (solvers/equilibrium_solvers_yaping.py:397); DEQSCI_LAYOUT_BHW = (bsz,B,H,W) planar - the
+ *     denoiser's (bsz*B,1,H,W) layout (ibid. :415).  y / Phi_sum are always (bsz,H,W).
+ *   - phi_shared != 0: Phi (and Phi_sum) carry no batch dimension - one mask for every
+ *     measurement of a clip (training/sci_equilibrium_training.py:161-176).
+ *   - Ownership: the caller owns every buffer including scratch; no entry point allocates,
+ *     frees or synchronises.  Work is enqueued on `stream`; entry points are re-entrant,
+ *     hold no global state and are safe under HIP-graph stream capture.
+ *   - Return: 0 on success; >0 = hipError_t of the failed launch; <0 = DEQSCI_ERR_*.
+ */
+#ifndef DEQSCI_HIP_H
+#define DEQSCI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEQSCI_LAYOUT_HWB 0
+#define DEQSCI_LAYOUT_BHW 1
+
+#define DEQSCI_MAX_M 8            /* largest Anderson history depth (reference uses m=5) */
+#define DEQSCI_PART_STRIDE (DEQSCI_MAX_M + 1)
+
+#define DEQSCI_ERR_NULL        (-1)   /* required pointer is NULL                      */
+#define DEQSCI_ERR_SHAPE       (-2)   /* non-positive / inconsistent sizes             */
+#define DEQSCI_ERR_ALIGN       (-3)   /* pointer not 16-byte aligned                   */
+#define DEQSCI_ERR_UNSUPPORTED (-4)   /* m > DEQSCI_MAX_M, unknown layout, ...         */
+
+typedef void* deqsci_stream_t;    /* a hipStream_t (NULL = the legacy default stream) */
+
+const char* deqsci_version(void);
+const char* deqsci_error_string(int code);
+
+/* K1  y = Phi x : y[n,h,w] = sum_b x[n,h,w,b] * Phi[n,h,w,b]
+ *     replaces A_torch_, utils/cg_utils.py:85-90.  x and phi share `layout`. */
+int deqsci_sci_forward_f32(const float* x, const float* phi, float* y,
+                           int64_t bsz, int64_t H, int64_t W, int64_t B,
+                           int layout, int phi_shared, deqsci_stream_t stream);
+
+/* K2  x = Phi^T y : x[n,h,w,b] = y[n,h,w] * Phi[n,h,w,b]
+ *     replaces At_torch_ (utils/cg_utils.py:124-129) and initial_point (:228-229). */
+int deqsci_sci_adjoint_f32(const float* y, const float* phi, float* x,
+                           int64_t bsz, int64_t H, int64_t W, int64_t B,
+                           int layout, int phi_shared, deqsci_stream_t stream);
+
+/* O4  Phi_sum = sum_b Phi with zeros replaced by 1
+ *     replaces training/sci_equilibrium_training.py:162-163.  nb = bsz, or 1 for a shared mask. */
+int deqsci_phi_sum_f32(const float* phi, float* phisum,
+                       int64_t nb, int64_t H, int64_t W, int64_t B,
+                       int layout, deqsci_stream_t stream);
+
+/* K3  fused GAP projection  z1 = z + Phi^T((y - Phi z) / Phi_sum)
+ *     replaces solvers/equilibrium_solvers_yaping.py:399-400 (5 ATen kernels, 4 temporaries)
+ *     and, when layout_out == BHW with layout_in == HWB, also the permute+contiguous at :415/:419.
+ *     z and phi are in layout_in; z1 is written in layout_out.  z1 may alias z iff the layouts match. */
+int deqsci_gap_update_f32(const float* z, const float* phi, const float* y, const float* phisum,
+                          float* z1, int64_t bsz, int64_t H, int64_t W, int64_t B,
+                          int layout_in, int layout_out, int phi_shared, deqsci_stream_t stream);
+
+/* (bsz,H,W,B) <-> (bsz,B,H,W) through an LDS tile; `to_layout` is the layout of `out`. */
+int deqsci_transpose_f32(const float* in, float* out,
+                         int64_t bsz, int64_t H, int64_t W, int64_t B,
+                         int to_layout, deqsci_stream_t stream);
+
+/* K4b out = z1 - noise, z1 and noise planar (BHW), out in layout_out
+ *     replaces `z - noise.view(bsz,c,w,h).permute(0,2,3,1)`, equilibrium_solvers_yaping.py:417,420. */
+int deqsci_residual_out_f32(const float* z1, const float* noise, float* out,
+                            int64_t bsz, int64_t H, int64_t W, int64_t B,
+                            int layout_out, deqsci_stream_t stream);
+
+/* ---- Anderson / Picard bookkeeping (solvers/new_equilibrium_utils_yaping.py:153-189, 213-222) ----
+ * History buffers F_hist, G_hist are (bsz, m, N) with G = F - X kept instead of X
+ * (X_i = F_i - G_i), N = H*W*B in whatever element order the caller iterates in.
+ * `deqsci_anderson_chunks(bsz,N)` blocks per sample each emit DEQSCI_PART_STRIDE fp32 partial sums.
+ */
+int64_t deqsci_anderson_chunks(int64_t bsz, int64_t N);
+size_t  deqsci_partials_bytes(int64_t bsz, int64_t N);           /* `partials` buffer            */
+size_t  deqsci_gram_bytes(int64_t bsz);                          /* persistent fp64 Gram + norms */
+
+/* K4  F_k = z1 - noise (noise may be NULL: F_k = z1);  G_k = F_k - x_cur;  store both into history
+ *     slot `slot`; optionally x_next = F_k; per-block partial sums of <G_k,G_j> for j < n_filled and
+ *     of |F_k|^2.  replaces :163/:183 stores, the G rows of :177 and the two norms of :184. */
+int deqsci_residual_store_f32(const float* z1, const float* noise, const float* x_cur,
+                              float* F_hist, float* G_hist, float* x_next, float* partials,
+                              int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                              deqsci_stream_t stream);
+
+/* K5+K6  finish the reduction (fp64), refresh row/column `slot` of the persistent Gram matrix,
+ *     solve the bordered (n+1)x(n+1) system [[0,1^T],[1,GG^T+lam I]] [nu;alpha] = e0 by LU with
+ *     partial pivoting, one wavefront per sample, and emit the relative residual
+ *     res[0] = |G_k| / (eps + |F_k|) over the whole batch (reference semantics, :184) and
+ *     res[1+s] per sample.  replaces torch.bmm + torch.solve + 2x .item() at :178-184.
+ *     n = 0 skips the solve (ramp-up / Picard).  alpha is (bsz, DEQSCI_MAX_M). */
+int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, float* res,
+                              int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
+                              float lam, float eps, deqsci_stream_t stream);
+
+/* K7  x_out = beta * sum_i alpha_i F_i + (1-beta) * sum_i alpha_i X_i,  X_i = F_i - G_i   (:182) */
+int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha,
+                            float* x_out, float beta, int n, int64_t bsz, int64_t N, int m,
+                            deqsci_stream_t stream);
+
+/* K7+K3  the mix above fused with the GAP projection of its result: writes x_out (the new
+ *     iterate X_k, needed for G_k and as the value andersonexp returns) and z1 = GAP(x_out).
+ *     History, phi, x_out and z1 all in `layout`. */
+int deqsci_anderson_mix_gap_f32(const float* F_hist, const float* G_hist, const float* alpha,
+                                float beta, int n, int m,
+                                const float* phi, const float* y, const float* phisum,
+                                float* x_out, float* z1,
+                                int64_t bsz, int64_t H, int64_t W, int64_t B,
+                                int layout, int phi_shared, deqsci_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEQSCI_HIP_H */

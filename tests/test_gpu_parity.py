@@ -1,0 +1,320 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs, against the committed golden vectors generated from the reference, and - at full size -
+through size-independent properties.  Tolerances: the path is fp32 floating point; north_star
+asks <= 1e-4 relative L2 / 0.01 dB end to end; single kernels are held to ~1 ulp-level bounds."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import deqsci_amd
+    from deqsci_amd import _hip, checkpoint
+    from deqsci_amd.cli import build_pipeline
+    from deqsci_amd.engine import DEQSCIEngine
+    from oracle import deqsci_oracle as orc
+
+DEV = "cuda"
+HWB, BHW = 0, 1
+
+
+def G(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def make_case(bsz, H, W, B, seed, shared=False, binary=True):
+    g = torch.Generator().manual_seed(seed)
+    nb = 1 if shared else bsz
+    Phi = (torch.rand(nb, H, W, B, generator=g) < 0.5).float() if binary else torch.rand(nb, H, W, B, generator=g)
+    Phi[:, 0, :2, :] = 0
+    x = torch.rand(bsz, H, W, B, generator=g)
+    z = torch.randn(bsz, H, W, B, generator=g)
+    Phie = Phi.expand(bsz, H, W, B)
+    y = orc.sci_forward(x, Phie)
+    return Phi, Phie, x, z, y, orc.phi_sum(Phi)
+
+
+SHAPES = [(2, 16, 16, 8), (1, 32, 32, 16), (3, 8, 12, 4), (2, 5, 7, 5), (1, 6, 6, 32), (2, 9, 4, 12), (1, 64, 64, 8)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("shared", [False, True])
+def test_ops_vs_oracle_all_layouts(shape, shared):
+    bsz, H, W, B = shape
+    Phi, Phie, x, z, y, Ps = make_case(bsz, H, W, B, seed=sum(shape), shared=shared)
+    Pse = Ps.expand(bsz, H, W)
+    want_Az, want_Aty, want_z1 = orc.sci_forward(z, Phie), orc.sci_adjoint(y, Phie), orc.gap_update(z, y, Phie, Pse)
+    dPhi, dz, dy, dPs = G(Phi), G(z), G(y), G(Ps)
+    planar = lambda t: t.permute(0, 3, 1, 2).contiguous()
+    # HWB
+    assert torch.equal(_hip.phi_sum(dPhi, HWB).cpu(), Ps)
+    assert torch.equal(_hip.sci_adjoint(dy, dPhi, HWB).cpu(), want_Aty)
+    torch.testing.assert_close(_hip.sci_forward(dz, dPhi, HWB).cpu(), want_Az, rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(_hip.gap_update(dz, dPhi, dy, dPs, HWB, HWB).cpu(), want_z1, rtol=1e-5, atol=1e-5)
+    # BHW
+    pPhi, pz = planar(dPhi), planar(dz)
+    assert torch.equal(_hip.phi_sum(pPhi, BHW).cpu(), Ps)
+    assert torch.equal(_hip.sci_adjoint(dy, pPhi, BHW).cpu(), planar(want_Aty))
+    torch.testing.assert_close(_hip.sci_forward(pz, pPhi, BHW).cpu(), want_Az, rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(_hip.gap_update(pz, pPhi, dy, dPs, BHW, BHW).cpu(), planar(want_z1), rtol=1e-5, atol=1e-5)
+    # HWB -> BHW fused transpose, and the transposes themselves
+    torch.testing.assert_close(_hip.gap_update(dz, dPhi, dy, dPs, HWB, BHW).cpu(), planar(want_z1), rtol=1e-5, atol=1e-5)
+    assert torch.equal(_hip.transpose(dz, BHW), pz)
+    assert torch.equal(_hip.transpose(pz, HWB), dz)
+    # in place
+    zz = dz.clone()
+    _hip.gap_update(zz, dPhi, dy, dPs, HWB, HWB, out=zz)
+    torch.testing.assert_close(zz.cpu(), want_z1, rtol=1e-5, atol=1e-5)
+    # residual_out
+    n = torch.randn_like(pz)
+    assert torch.equal(_hip.residual_out(pz, n, HWB), (pz - n).permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(_hip.residual_out(pz, n, BHW), pz - n)
+
+
+def test_ops_reference_golden():
+    g = np.load(os.path.join(GOLDEN, "ops.npz"))
+    for c in ("c0_", "c1_", "c2_"):
+        Phi, z, y, x = G(g[c + "Phi"]), G(g[c + "z"]), G(g[c + "y"]), G(g[c + "x"])
+        Ps = deqsci_amd.phi_sum(Phi)
+        assert np.array_equal(Ps.cpu().numpy(), g[c + "Phi_sum"])
+        assert np.array_equal(deqsci_amd.At_torch_(y, Phi).cpu().numpy(), g[c + "Aty"])
+        assert np.array_equal(deqsci_amd.initial_point(y, Phi, Ps, None).cpu().numpy(), g[c + "x0"])
+        np.testing.assert_allclose(deqsci_amd.A_torch_(x, Phi).cpu().numpy(), g[c + "y"], rtol=1e-6, atol=2e-6)
+        np.testing.assert_allclose(deqsci_amd.A_torch_(z, Phi).cpu().numpy(), g[c + "Az"], rtol=1e-6, atol=2e-6)
+        from deqsci_amd.operators import gap_update
+        np.testing.assert_allclose(gap_update(z, y, Phi, Ps).cpu().numpy(), g[c + "z1"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gap_update(G(g["grey_z"]), G(g["grey_y"]), G(g["grey_Phi"]), G(g["grey_Phi_sum"])).cpu().numpy(),
+                               g["grey_z1"], rtol=1e-5, atol=1e-5)
+
+
+def test_error_conventions():
+    with pytest.raises(_hip.DeqsciHipError):
+        deqsci_amd.A_torch_(torch.zeros(1, 4, 4, 8), torch.zeros(1, 4, 4, 8))           # CPU tensors: no fallback
+    with pytest.raises(_hip.DeqsciHipError):
+        deqsci_amd.A_torch_(torch.zeros(1, 4, 4, 8, device=DEV), torch.zeros(1, 4, 5, 8, device=DEV))
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.AndersonWorkspace(1, 64, 9, DEV)                                          # m > DEQSCI_MAX_M
+    base = torch.zeros(4 * 4 * 8 + 1, device=DEV)
+    mis = base[1:].view(1, 4, 4, 8)
+    lib = _hip.load()
+    code = lib.deqsci_sci_forward_f32(mis.data_ptr(), mis.data_ptr(), base.data_ptr(), 1, 4, 4, 8, 0, 0, None)
+    assert code == -3
+    assert lib.deqsci_sci_forward_f32(None, mis.data_ptr(), base.data_ptr(), 1, 4, 4, 8, 0, 0, None) == -1
+    assert lib.deqsci_sci_forward_f32(base.data_ptr(), base.data_ptr(), base.data_ptr(), 0, 4, 4, 8, 0, 0, None) == -2
+    assert lib.deqsci_sci_forward_f32(base.data_ptr(), base.data_ptr(), base.data_ptr(), 1, 4, 4, 8, 7, 0, None) == -4
+
+
+def test_adjointness_and_projection_full_size():
+    """Size-independent properties at BASELINE sizes (256x256x8 batch 8, 512x512x16):
+    <Phi x, y> = <x, Phi^T y>, and one GAP step lands on the data: Phi z1 = y where Phi_sum != 0."""
+    for (bsz, H, W, B) in [(8, 256, 256, 8), (2, 512, 512, 16)]:
+        g = torch.Generator(device=DEV).manual_seed(1234)
+        Phi = (torch.rand(bsz, H, W, B, device=DEV, generator=g) < 0.5).float()
+        x = torch.rand(bsz, H, W, B, device=DEV, generator=g)
+        yv = torch.randn(bsz, H, W, device=DEV, generator=g)
+        for layout in (HWB, BHW):
+            P_, x_ = (Phi, x) if layout == HWB else (Phi.permute(0, 3, 1, 2).contiguous(), x.permute(0, 3, 1, 2).contiguous())
+            lhs = (_hip.sci_forward(x_, P_, layout).double() * yv.double()).sum()
+            rhs = (x_.double() * _hip.sci_adjoint(yv, P_, layout).double()).sum()
+            assert abs(lhs - rhs) / abs(lhs) < 1e-6
+            Ps = _hip.phi_sum(P_, layout)
+            y = _hip.sci_forward(x_, P_, layout)
+            z1 = _hip.gap_update(torch.randn_like(x_), P_, y, Ps, layout, layout)
+            err = (_hip.sci_forward(z1, P_, layout) - y).abs()
+            assert err[Ps_nonzero(P_, layout)].max() < 2e-5
+            z2 = _hip.gap_update(z1, P_, y, Ps, layout, layout)          # projection is idempotent
+            assert (z2 - z1).abs().max() < 2e-5
+
+
+def Ps_nonzero(P_, layout):
+    return (P_.sum(3 if layout == HWB else 1) != 0)
+
+
+# ----------------------------------------------------------------------------- Anderson / Picard (generic f)
+def _toy(a, c):
+    return lambda z: a * z + 0.3 * torch.sin(z) + c
+
+
+@pytest.mark.parametrize("bsz", [1, 3])
+def test_anderson_generic_vs_reference_golden(bsz):
+    g = np.load(os.path.join(GOLDEN, "anderson_toy.npz"))
+    a, c, x0 = G(g[f"b{bsz}_a"]), G(g[f"b{bsz}_c"]), G(g[f"b{bsz}_x0"])
+    for it in (3, 7, 12, 40):
+        z, res = deqsci_amd.andersonexp(_toy(a, c), x0, m=5, lam=1e-2, max_iter=it, tol=1e-5, beta=1.0)
+        assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_it{it}_z"]) < 2e-5, it
+        assert abs(res - float(g[f"b{bsz}_it{it}_res"])) <= 2e-3 * float(g[f"b{bsz}_it{it}_res"]) + 1e-7
+    n = [0]
+
+    def f2(z):
+        n[0] += 1
+        return _toy(a, c)(z)
+    z, res = deqsci_amd.andersonexp(f2, x0, m=5, lam=1e-2, max_iter=40, tol=1e-3, beta=1.0)
+    assert n[0] == int(g[f"b{bsz}_early_ncalls"])
+    assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_early_z"]) < 2e-5
+    z, res = deqsci_amd.andersonexp(_toy(a, c), x0, m=3, lam=1e-3, max_iter=9, tol=1e-5, beta=0.7)
+    assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_m3beta_z"]) < 2e-5
+    z, res = deqsci_amd.forward_iteration(_toy(a, c), x0, max_iter=15, tol=1e-5)
+    assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_picard_z"]) < 1e-6
+    np.testing.assert_allclose(np.array(res), g[f"b{bsz}_picard_res"], rtol=1e-4)
+    z, res = deqsci_amd.forward_iteration(_toy(a, c), x0, max_iter=60, tol=1e-3)
+    assert len(res) == len(g[f"b{bsz}_picard_early_res"])
+    with pytest.raises(UnboundLocalError):
+        deqsci_amd.andersonexp(_toy(a, c), x0, m=5, lam=1e-2, max_iter=2)
+    with pytest.raises(IndexError):
+        deqsci_amd.andersonexp(_toy(a, c), x0, m=1, lam=1e-2, max_iter=5)
+
+
+def test_anderson_kernels_vs_oracle_odd_sizes():
+    """N not a multiple of 4 (scalar paths) and m = 8 (largest supported history)."""
+    g = torch.Generator().manual_seed(3)
+    a, c, x0 = torch.rand(2, 3, 7, 5, generator=g) * 0.5, torch.randn(2, 3, 7, 5, generator=g), torch.randn(2, 3, 7, 5, generator=g)
+    for m, beta in ((8, 1.0), (4, 0.5)):
+        want, wres = orc.andersonexp(_toy(a, c), x0, m=m, lam=1e-2, max_iter=14, tol=1e-9, beta=beta)
+        got, gres = deqsci_amd.andersonexp(_toy(G(a), G(c)), G(x0), m=m, lam=1e-2, max_iter=14, tol=1e-9, beta=beta)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < 5e-5
+        assert abs(gres - wres) < 5e-2 * wres + 1e-7
+
+
+# ----------------------------------------------------------------------------- f-map and the DEQ loop
+def _pipeline(kind, iters, iterator="anderson"):
+    solver, deq = build_pipeline(kind, checkpoint.shipped("ffdnet_gray" if kind == "ffdnet" else "cnn"), iters)
+    if iterator == "picard":
+        deq = deqsci_amd.DEQFixedPoint(solver, deqsci_amd.forward_iteration, max_iter=iters, tol=1e-5)
+    return solver, deq
+
+
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+def test_teacher_forced_f_vs_reference_trace(kind):
+    """Every one of the reference's 12 f-calls (64x64 crop, and_maxiters=10): same input -> same output."""
+    g = np.load(os.path.join(GOLDEN, f"trace_{kind}.npz"))
+    solver, _ = _pipeline(kind, 10)
+    Phi, y, Ps = G(g["Phi"]), G(g["y"]), G(g["Phi_sum"])
+    with torch.no_grad():
+        for i in range(12):
+            out = solver(G(g["fed"][i]), y, Phi, Ps)
+            assert rel_l2(out.cpu().numpy(), g["ret"][i]) < 1e-5, i
+            if kind == "ffdnet":
+                assert np.array_equal(solver.noise_sigma.cpu().numpy(), g["sigma"][i])
+
+
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+@pytest.mark.parametrize("use_engine", [True, False])
+def test_deq_loop_vs_reference_trace(kind, use_engine):
+    g = np.load(os.path.join(GOLDEN, f"trace_{kind}.npz"))
+    _, deq = _pipeline(kind, 10)
+    deq.use_engine = use_engine
+    Phi, y, Ps, x0 = G(g["Phi"]), G(g["y"]), G(g["Phi_sum"]), G(g["x0"])
+    rec = deq.forward(y, Phi, Ps, initial_point=x0, train_flag=False)
+    assert rel_l2(rec.cpu().numpy(), g["rec"]) < 1e-4
+    assert abs(deq.forward_res - float(g["res"])) < 1e-2 * float(g["res"])
+
+
+def _golden_meta(tag):
+    with open(os.path.join(GOLDEN, f"e2e_{tag}.json")) as fh:
+        return json.load(fh)
+
+
+def _clip(name):
+    d = orc.load_clip(os.path.join(orc.DATA_DIR, name))
+    return {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+
+
+E2E = [("SimpleCNN", "anderson", 180, "traffic_cacti.mat", 0, "traffic_m0", 1e-4),
+       ("SimpleCNN", "anderson", 180, "drop8_cacti.mat", 0, "drop8_m0", 1e-4),
+       ("SimpleCNN", "anderson", 180, "runner8_cacti.mat", 0, "runner8_m0", 1e-4),
+       ("SimpleCNN", "anderson", 10, "traffic_cacti.mat", 3, "traffic_m3", 1e-4),
+       ("ffdnet", "anderson", 10, "traffic_cacti.mat", 0, "traffic_m0", 1e-4),
+       ("ffdnet", "anderson", 10, "drop8_cacti.mat", 0, "drop8_m0", 1e-4),
+       ("ffdnet", "anderson", 30, "traffic_cacti.mat", 0, "traffic_m0", 1e-4),
+       ("ffdnet", "picard", 180, "traffic_cacti.mat", 0, "traffic_m0", 1e-4)]
+
+
+@pytest.mark.parametrize("kind,iterator,iters,clip,fi,key,tol", E2E)
+def test_end_to_end_vs_reference_rec(kind, iterator, iters, clip, fi, key, tol):
+    """Full 256x256x8 reconstructions against the reference's own output tensors: <= 1e-4 relative L2
+    and <= 0.01 dB (north_star).  FFDNet+Anderson is only gated up to 30 iterations because the
+    reference itself moves by 4e-2 under a 1-ulp input change at 180; the 180-iteration
+    FFDNet pin is the Picard run."""
+    tag = f"{kind}_{iterator}_{iters}" + ("_first" if iterator == "picard" else "")
+    recs = np.load(os.path.join(GOLDEN, f"e2e_{tag}_rec.npz"))
+    meta = [m for m in _golden_meta(tag)["measurements"] if m["id"] == f"{clip}:{fi}"][0]
+    d = _clip(clip)
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"][None, ..., fi].contiguous().to(DEV)
+    gt = d["gt"][None, ..., fi * 8:(fi + 1) * 8]
+    _, deq = _pipeline(kind, iters, iterator)
+    Ps = deqsci_amd.phi_sum(Phi)
+    rec = deq.forward(y, Phi, Ps, initial_point=deqsci_amd.initial_point(y, Phi, Ps, None), train_flag=False).cpu().numpy()
+    assert rel_l2(rec, recs[key]) < tol
+    assert abs(orc.psnr(rec, gt.numpy()) - meta["psnr"]) < 0.01
+    res = deq.forward_res[-1] if isinstance(deq.forward_res, list) else deq.forward_res
+    assert abs(res - meta["res"]) < 2e-2 * meta["res"]
+
+
+@pytest.mark.parametrize("kind,iters", [("SimpleCNN", 10), ("ffdnet", 10)])
+def test_harness_all_clips_vs_reference(kind, iters):
+    """The build's own test_solver_sci over data/test_gray against the reference harness run:
+    measurement order, slicing rules, per-measurement PSNR, clip means, grand mean, PNG payload count."""
+    from deqsci_amd.harness import SCITestDataset, test_solver_sci
+    meta = _golden_meta(f"{kind}_anderson_{iters}")
+    _, deq = _pipeline(kind, iters)
+    loader = torch.utils.data.DataLoader(dataset=SCITestDataset(orc.DATA_DIR), batch_size=1, shuffle=False, drop_last=True)
+    records = []
+    avg, images = test_solver_sci(deq, test_dataloader=loader, save_img_path="", verbose=False, save_image=False, records=records)
+    assert [r["id"] for r in records] == [m["id"] for m in meta["measurements"]]
+    for r, m in zip(records, meta["measurements"]):
+        assert abs(r["psnr"] - m["psnr"]) < 0.01, r["id"]
+    assert abs(avg - meta["avg_psnr"]) < 0.01
+    assert len(images) == meta["n_png_payloads"] == 64
+
+
+def test_engine_batch_equals_single_and_shared_mask():
+    """Batched measurements are independent problems: bsz=3 (shared mask) == three bsz=1 runs."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    ys = d["meas"].permute(2, 0, 1)[:3].contiguous().to(DEV)
+    net = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 12)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=12)
+    batched = eng.reconstruct(ys, Phi)
+    assert eng.last_info["f_calls"] == 13
+    per = eng.reconstruct(ys, Phi.expand(3, -1, -1, -1).contiguous())
+    assert rel_l2(per.cpu().numpy(), batched.cpu().numpy()) < 1e-6
+    for i in range(3):
+        one = eng.reconstruct(ys[i:i + 1], Phi)
+        assert rel_l2(one.cpu().numpy(), batched[i:i + 1].cpu().numpy()) < 2e-5
+
+
+class _Contract(torch.nn.Module):
+    tag = "conv2d"
+
+    def forward(self, x):
+        return 0.25 * x + 0.1
+
+
+def test_engine_early_stop_matches_oracle_semantics():
+    """tol fires: the engine must return f(X_k) for the same k as the reference algorithm, although it
+    polls the residual one iteration late."""
+    Phi, Phie, x, z, y, Ps = make_case(1, 16, 16, 8, seed=11)
+    calls = [0]
+
+    def f_cpu(zz):
+        calls[0] += 1
+        z1 = orc.gap_update(zz, y, Phie, Ps)
+        return 0.25 * z1 + 0.1
+    x0 = orc.initial_point(y, Phie)
+    for iterator, fn, kw in (("anderson", orc.andersonexp, dict(m=5, lam=1e-2, beta=1.0)), ("picard", orc.forward_iteration, {})):
+        calls[0] = 0
+        zs, res = fn(f_cpu, x0, max_iter=50, tol=1e-4, **kw)
+        n_loop = calls[0]
+        want = f_cpu(zs)
+        eng = DEQSCIEngine(_Contract(), iterator=iterator, max_iter=50, tol=1e-4)
+        got = eng.reconstruct(G(y), G(Phi))
+        assert n_loop < 40
+        assert eng.last_info["f_calls"] == n_loop + 1, (iterator, eng.last_info, n_loop)
+        assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-5
