@@ -1,0 +1,52 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/deqsci_hip.h
+declares (no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "deqsci_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(deqsci_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deqsci_amd import _hip
+    assert os.path.exists(_hip.lib_path()), "run `make` / __graft_entry__.build() first"
+    lib = ctypes.CDLL(_hip.lib_path())
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/deqsci_hip.h but not exported"
+    assert set(_hip.SIGNATURES) | set(_hip.OTHER_EXPORTS) == set(syms)
+
+
+def test_scratch_size_queries_and_error_strings():
+    from deqsci_amd import _hip
+    lib = _hip.load()
+    assert b"gfx950" in lib.deqsci_version()
+    n = lib.deqsci_anderson_chunks(8, 256 * 256 * 8)
+    assert n > 0 and lib.deqsci_partials_bytes(8, 256 * 256 * 8) == 8 * n * _hip.PART_STRIDE * 4
+    assert lib.deqsci_gram_bytes(3) % (3 * 8) == 0
+    assert lib.deqsci_anderson_chunks(0, 10) == 0
+    for code in (-1, -2, -3, -4):
+        assert len(lib.deqsci_error_string(code)) > 5
+    # argument validation happens before any launch, so it is testable without a GPU
+    assert lib.deqsci_sci_forward_f32(None, None, None, 1, 4, 4, 8, 0, 0, None) == -1
+    assert lib.deqsci_residual_store_f32(None, None, None, None, None, None, None, 1, 64, 5, 0, 1, None) == -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    p16 = (p + 15) // 16 * 16
+    assert lib.deqsci_sci_forward_f32(p16, p16, p16, 1, 2, 2, -8, 0, 0, None) == -2
+    assert lib.deqsci_sci_forward_f32(p16 + 4, p16, p16, 1, 2, 2, 8, 0, 0, None) == -3
+    assert lib.deqsci_gap_update_f32(p16, p16, p16, p16, p16, 1, 2, 2, 8, 0, 1, 0, None) == -4     # aliasing across layouts
+    assert lib.deqsci_anderson_mix_f32(p16, p16, p16, p16, 1.0, 9, 1, 8, 9, None) == -4           # m > DEQSCI_MAX_M
+
+
+def test_gfx950_code_object_present():
+    from deqsci_amd import _hip
+    blob = open(_hip.lib_path(), "rb").read()
+    assert b"gfx950" in blob and b"gfx90a" not in blob and b"sm_" not in blob

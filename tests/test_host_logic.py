@@ -1,0 +1,144 @@
+"""CPU: host-side logic of the product - denoiser modules / checkpoint keys / loader / PSNR / sigma
+table / sharding arithmetic / CLI plumbing - against the oracle and the reference goldens.
+No HIP compute happens here; the product refuses CPU tensors."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, rel_l2
+from oracle import deqsci_oracle as orc
+
+import deqsci_amd
+from deqsci_amd import _hip, checkpoint, harness
+from deqsci_amd.cli import build_denoiser, build_pipeline, main as cli_main
+from deqsci_amd.distributed import shard_bounds
+from deqsci_amd.engine import DEQSCIEngine, sigma_schedule
+
+
+def test_sigma_table_matches_reference_sequence():
+    g = np.load(os.path.join(GOLDEN, "sigma.npz"))["sigma"]
+    assert np.array_equal(sigma_schedule(len(g)), g)
+
+
+def test_denoiser_modules_load_reference_checkpoints_and_match_goldens():
+    g = np.load(os.path.join(GOLDEN, "nets.npz"))
+    x = torch.from_numpy(g["x"])
+    ff = build_denoiser("ffdnet").eval()
+    sd, _ = checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray"))
+    assert set(sd) == {k for k in ff.state_dict() if not k.endswith("num_batches_tracked")} and len(sd) == 67
+    assert "intermediate_dncnn.itermediate_dncnn.41.weight" in sd       # the reference's key spelling
+    ff.load_state_dict(sd)
+    assert sum(v.numel() for v in sd.values()) == 487744
+    with torch.no_grad():
+        for k in (0, 1, 50):
+            out = ff(x, torch.from_numpy(g[f"ffdnet_sigma_k{k}"]))
+            assert rel_l2(out.numpy(), g[f"ffdnet_noise_k{k}"]) < 1e-6
+    solver, deq = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 10, device="cpu")
+    assert sorted(solver.state_dict()) == [f"nonlinear_op.dncnn.{i}.weight" for i in (0, 2, 4, 6)]
+    with torch.no_grad():
+        assert rel_l2(solver.nonlinear_op(x).numpy(), g["cnn_noise"]) < 1e-6
+    rsn, _ = build_pipeline("RealSN_SimpleCNN", checkpoint.shipped("rsn_cnn"), 10, device="cpu")
+    assert len(rsn.state_dict()) == 12 and rsn.nonlinear_op.tag == "denoiser"
+    w = np.load(checkpoint.shipped("rsn_cnn"))["nonlinear_op.dncnn.2.weight"]
+    assert np.array_equal(rsn.nonlinear_op.dncnn[2].weight.numpy(), w)
+    with pytest.raises(NotImplementedError):
+        build_denoiser("unet")
+    with pytest.raises(FileNotFoundError):
+        checkpoint.read_state_dict("/nonexistent/ffdnet.ckpt")
+
+
+def test_folded_bn_ffdnet_matches_module():
+    from deqsci_amd.engine import _Denoiser
+    g = np.load(os.path.join(GOLDEN, "nets.npz"))
+    ff = build_denoiser("ffdnet").eval()
+    ff.load_state_dict(checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray"))[0])
+    den = _Denoiser(ff)
+    den.prepare(60, "cpu")
+    x = torch.from_numpy(g["x"]).view(1, 8, 32, 32)
+    with torch.no_grad():
+        out, is_noise = den.run(x, 50)
+    # folding BN into the conv weights re-rounds them: ~1e-5 on the (small) predicted noise, ~1e-6 on z1 - noise
+    assert is_noise and rel_l2(out.reshape(8, 1, 32, 32).numpy(), g["ffdnet_noise_k50"]) < 5e-5
+    xin = g["x"]
+    assert rel_l2(xin - out.reshape(8, 1, 32, 32).numpy(), xin - g["ffdnet_noise_k50"]) < 2e-6
+    # load_state_dict after construction must invalidate the folded copy
+    with torch.no_grad():
+        ff.intermediate_dncnn.itermediate_dncnn[0].weight.mul_(0.5)
+    den.prepare(60, "cpu")
+    with torch.no_grad():
+        out2, _ = den.run(x, 50)
+    assert rel_l2(out2.numpy(), out.numpy()) > 1e-3
+
+
+def test_loader_and_psnr_match_oracle():
+    ds = harness.SCITestDataset(orc.DATA_DIR)
+    assert ds.filelist == ["drop8_cacti.mat", "runner8_cacti.mat", "traffic_cacti.mat"] == orc.list_clips()
+    d = ds[2]
+    o = orc.load_clip(os.path.join(orc.DATA_DIR, "traffic_cacti.mat"))
+    for k in ("gt", "mask", "meas"):
+        assert d[k].dtype == np.float32 and np.array_equal(d[k], o[k])
+    assert d["gt"].shape == (256, 256, 48) and d["meas"].shape == (256, 256, 6) and d["file"] == "traffic_cacti.mat"
+    # shipped data is self-consistent: sum_b mask*orig == meas
+    assert np.abs((d["mask"] * d["gt"][..., :8]).sum(2) - d["meas"][..., 0]).max() < 1e-5
+    a, b = np.random.RandomState(0).rand(1, 8, 8, 8).astype(np.float32), np.random.RandomState(1).rand(1, 8, 8, 8).astype(np.float32)
+    assert harness.psnr(a, b) == orc.psnr(a, b)
+    img = harness.tensor_to_np(torch.tensor([[0.5, 1.5], [-1.0, 0.25]]))
+    assert img.shape == (2, 2, 1) and img.max() == 255.0 and img.min() == 0.0
+
+
+def test_product_refuses_cpu_tensors_and_missing_library(monkeypatch):
+    z = torch.zeros(1, 4, 4, 8)
+    for fn in (lambda: deqsci_amd.A_torch_(z, z), lambda: deqsci_amd.At_torch_(z[..., 0], z),
+               lambda: deqsci_amd.andersonexp(lambda t: t, z), lambda: deqsci_amd.phi_sum(z)):
+        with pytest.raises(_hip.DeqsciHipError):
+            fn()
+    eng = DEQSCIEngine(build_denoiser("SimpleCNN").eval(), max_iter=5)
+    with pytest.raises(_hip.DeqsciHipError):
+        eng.reconstruct(z[..., 0], z)
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "_LIB_PATH", "/nonexistent/libdeqsci_hip.so")
+    with pytest.raises(_hip.DeqsciHipError, match="no CPU"):
+        _hip.load()
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for M in (1, 7, 8, 64, 65):
+        for R in (1, 2, 4, 8):
+            spans = [shard_bounds(M, R, r) for r in range(R)]
+            assert spans[0][0] == 0 and max(s[1] for s in spans) == M
+            assert sum(s[1] - s[0] for s in spans) == M
+            assert all(s[2] == -(-M // R) for s in spans)
+
+
+def test_cli_flags_and_errors():
+    with pytest.raises(NotImplementedError):
+        cli_main(["--inference", "False"])
+    with pytest.raises(SystemExit):
+        cli_main(["--denoiser", "ffdnet", "--and_maxiters", "3"])        # no GPU here -> refuses, no CPU path
+    with pytest.raises(SystemExit):
+        cli_main(["--and_maxiters", "abc"])
+
+
+def test_deqfixedpoint_routing_rules():
+    solver, deq = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 7, device="cpu")
+    eng = deq._engine_for()
+    assert isinstance(eng, DEQSCIEngine) and eng.max_iter == 7 and eng.m == 5 and eng.lam == 1e-2 and eng.iterator == "anderson"
+    assert deq._engine_for() is eng                                       # cached
+    deq2 = deqsci_amd.DEQFixedPoint(solver, deqsci_amd.forward_iteration, max_iter=9, tol=1e-5)
+    assert deq2._engine_for().iterator == "picard"
+    deq3 = deqsci_amd.DEQFixedPoint(solver, lambda f, x0, **kw: (x0, 0.0))
+    assert deq3._engine_for() is None                                     # foreign iterator -> generic path
+    other = deqsci_amd.EquilibriumProxGradSCI(A=lambda x, P: x, At=deqsci_amd.At_torch_, nonlinear_operator=solver.nonlinear_op, eta=0.2)
+    assert deqsci_amd.DEQFixedPoint(other, deqsci_amd.andersonexp)._engine_for() is None
+    with pytest.raises(TypeError):
+        deqsci_amd.DEQFixedPoint(solver, deqsci_amd.forward_iteration, m=5)._engine_for()   # forward_iteration has no m
+
+
+def test_golden_metadata_present():
+    for tag in ("SimpleCNN_anderson_10", "ffdnet_anderson_10", "ffdnet_anderson_30", "ffdnet_picard_180_first"):
+        with open(os.path.join(GOLDEN, f"e2e_{tag}.json")) as fh:
+            meta = json.load(fh)
+        assert meta["measurements"] and all("psnr" in m and "sha16_clip" in m for m in meta["measurements"])
