@@ -46,13 +46,33 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
     float accf = 0.0f;
 
     if (vec) {
-        for (int64_t i = beg + 4 * threadIdx.x; i < end; i += 4 * TB) {
+        // two 1024-element sweeps per trip: 2*(NF+2) independent 16-B loads in flight per lane
+        int64_t i = beg + 4 * threadIdx.x;
+        for (; i + 4 * TB < end; i += 8 * TB) {
+            const int64_t i2 = i + 4 * TB;
+            float4 f = ld4(zs + i), f2 = ld4(zs + i2);
+            if (ns) { f = f - ld4(ns + i); f2 = f2 - ld4(ns + i2); }
+            const float4 g = f - ld4(xs + i), g2 = f2 - ld4(xs + i2);
+            float4 o[NF], o2[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) if (j != slot) { o[j] = ld4(Gall + j * N + i); o2[j] = ld4(Gall + j * N + i2); }
+            st4(Fs + i, f); st4(Fs + i2, f2);
+            st4(Gs + i, g); st4(Gs + i2, g2);
+            if (xn) { st4(xn + i, f); st4(xn + i2, f2); }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                acc[j] = dot4_fma(g, (j == slot) ? g : o[j], acc[j]);
+                acc[j] = dot4_fma(g2, (j == slot) ? g2 : o2[j], acc[j]);
+            }
+            accf = dot4_fma(f2, f2, dot4_fma(f, f, accf));
+        }
+        for (; i < end; i += 4 * TB) {
             float4 f = ld4(zs + i);
             if (ns) f = f - ld4(ns + i);
             const float4 g = f - ld4(xs + i);
             float4 o[NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) o[j] = (j == slot) ? g : ld4(Gall + j * N + i);
+            for (int j = 0; j < NF; ++j) if (j != slot) o[j] = ld4(Gall + j * N + i);
             st4(Fs + i, f);
             st4(Gs + i, g);
             if (xn) st4(xn + i, f);
@@ -97,71 +117,73 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // K5 + K6
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TB) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
-                                                            float* __restrict__ alpha, float* __restrict__ res, int bsz,
-                                                            int nchunks, int slot, int n_filled, int n, float lam, float eps) {
-    constexpr int NW = TB / WAVE;
-    __shared__ double A[NW][MAXM + 1][MAXM + 2];
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    for (int s = wave; s < bsz; s += NW) {
-        double* gs = gram + (int64_t)s * GRAM_STRIDE;
-        const float* ps = partials + (int64_t)s * nchunks * PART_STRIDE;
-        for (int j = 0; j <= n_filled; ++j) {
-            const int col = j < n_filled ? j : MAXM;
-            double a = 0.0;
-            for (int c = lane; c < nchunks; c += WAVE) a += (double)ps[(int64_t)c * PART_STRIDE + col];
-            a = wave_sum(a);
-            if (lane == 0) {
-                if (j < n_filled) { gs[slot * MAXM + j] = a; gs[j * MAXM + slot] = a; }
-                else gs[MAXM * MAXM] = a;                       // |F_k|^2
-            }
-        }
+__global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
+                                                              float* __restrict__ alpha, float* res, int bsz,
+                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps) {
+    // one wavefront per sample; the last block to arrive folds the per-sample norms into the
+    // whole-batch residual (agent-scope release -> ticket -> acquire; the ticket resets itself).
+    __shared__ double M[MAXM + 1][MAXM + 2];
+    const int s = blockIdx.x, lane = threadIdx.x;
+    double* gs = gram + (int64_t)s * GRAM_STRIDE;
+    unsigned* ticket = reinterpret_cast<unsigned*>(gram + (int64_t)bsz * GRAM_STRIDE);
+    const float* ps = partials + (int64_t)s * nchunks * PART_STRIDE;
+    for (int j = 0; j <= n_filled; ++j) {
+        const int col = j < n_filled ? j : MAXM;
+        double a = 0.0;
+        for (int c = lane; c < nchunks; c += WAVE) a += (double)ps[(int64_t)c * PART_STRIDE + col];
+        a = wave_sum(a);
         if (lane == 0) {
-            gs[MAXM * MAXM + 1] = gs[slot * MAXM + slot];        // |G_k|^2
-            if (n > 0) {
-                // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180)
-                const int nn = n + 1;
-                double (*M)[MAXM + 2] = A[wave];
-                for (int i = 0; i < nn; ++i)
-                    for (int j = 0; j < nn; ++j) {
-                        double v;
-                        if (i == 0 && j == 0) v = 0.0;
-                        else if (i == 0 || j == 0) v = 1.0;
-                        else v = gs[(i - 1) * MAXM + (j - 1)] + (i == j ? (double)lam : 0.0);
-                        M[i][j] = v;
-                    }
-                for (int i = 0; i < nn; ++i) M[i][nn] = (i == 0) ? 1.0 : 0.0;
-                for (int k = 0; k < nn; ++k) {                    // LU, partial pivoting (as LAPACK gesv)
-                    int piv = k;
-                    double best = fabs(M[k][k]);
-                    for (int i = k + 1; i < nn; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; piv = i; } }
-                    if (piv != k) for (int j = 0; j <= nn; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
-                    const double inv = 1.0 / M[k][k];
-                    for (int i = k + 1; i < nn; ++i) {
-                        const double f = M[i][k] * inv;
-                        for (int j = k; j <= nn; ++j) M[i][j] -= f * M[k][j];
-                    }
-                }
-                for (int i = nn - 1; i >= 0; --i) {
-                    double v = M[i][nn];
-                    for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
-                    M[i][nn] = v / M[i][i];
-                }
-                for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
-            }
+            if (j < n_filled) { gs[slot * MAXM + j] = a; gs[j * MAXM + slot] = a; }
+            else gs[MAXM * MAXM] = a;                           // |F_k|^2
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double sg = 0.0, sf = 0.0;
-        for (int s = 0; s < bsz; ++s) {
-            const double ff = gram[(int64_t)s * GRAM_STRIDE + MAXM * MAXM];
-            const double gg = gram[(int64_t)s * GRAM_STRIDE + MAXM * MAXM + 1];
-            res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
-            sg += gg;
-            sf += ff;
+    if (lane != 0) return;
+    const double ff = gs[MAXM * MAXM], gg = gs[slot * MAXM + slot];
+    gs[MAXM * MAXM + 1] = gg;                                   // |G_k|^2
+    res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
+    if (n > 0) {
+        // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180)
+        const int nn = n + 1;
+        for (int i = 0; i < nn; ++i)
+            for (int j = 0; j < nn; ++j) {
+                double v;
+                if (i == 0 && j == 0) v = 0.0;
+                else if (i == 0 || j == 0) v = 1.0;
+                else v = gs[(i - 1) * MAXM + (j - 1)] + (i == j ? (double)lam : 0.0);
+                M[i][j] = v;
+            }
+        for (int i = 0; i < nn; ++i) M[i][nn] = (i == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < nn; ++k) {                        // LU, partial pivoting (as LAPACK gesv)
+            int piv = k;
+            double best = fabs(M[k][k]);
+            for (int i = k + 1; i < nn; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; piv = i; } }
+            if (piv != k) for (int j = 0; j <= nn; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
+            const double inv = 1.0 / M[k][k];
+            for (int i = k + 1; i < nn; ++i) {
+                const double f = M[i][k] * inv;
+                for (int j = k; j <= nn; ++j) M[i][j] -= f * M[k][j];
+            }
         }
-        res[0] = (float)(sqrt(sg) / ((double)eps + sqrt(sf)));   // whole-batch norms, :184
+        for (int i = nn - 1; i >= 0; --i) {
+            double v = M[i][nn];
+            for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
+            M[i][nn] = v / M[i][i];
+        }
+        for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
+    }
+    if (bsz == 1) { res[0] = res[1]; return; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (unsigned)bsz - 1u) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double sg = 0.0, sf = 0.0;
+        for (int k = 0; k < bsz; ++k) {                         // fixed order: deterministic
+            sf += __hip_atomic_load(gram + (int64_t)k * GRAM_STRIDE + MAXM * MAXM, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sg += __hip_atomic_load(gram + (int64_t)k * GRAM_STRIDE + MAXM * MAXM + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        res[0] = (float)(sqrt(sg) / ((double)eps + sqrt(sf)));  // whole-batch norms, :184
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -245,38 +267,40 @@ __global__ __launch_bounds__(TB) void mix_gap_hwb_kernel(const float* __restrict
     }
 }
 
+// Planar (BHW) fused mix + GAP.  A block is BT frames x (256/BT) pixel-quads: lane (b,q) builds the
+// new iterate for ONE frame of 4 adjacent pixels (n history rows + Phi: n+1 independent 16-B loads,
+// 512-B contiguous per frame row and wave), the per-pixel frame column is staged in LDS, every lane
+// re-reads its quad's BT partial products (conflict-free ds_read_b128) to form Phi x, and writes
+// x and z1.  8x more wavefronts in flight than a lane-owns-the-column mapping at batch 8.
 template <int BT>
 __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
                                                          const float* __restrict__ alpha, float omb, int n, int m,
                                                          const float* __restrict__ phi, const float* __restrict__ y,
                                                          const float* __restrict__ phisum, float* __restrict__ x_out,
                                                          float* __restrict__ z1, int64_t P, int phi_shared) {
+    constexpr int QPB = TB / BT;
+    __shared__ __attribute__((aligned(16))) float4 part[BT][QPB];
+    const int b = threadIdx.x / QPB, q = threadIdx.x % QPB;
     const int64_t s = blockIdx.y;
-    const int64_t p = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
-    if (p >= P) return;
+    const int64_t p = ((int64_t)blockIdx.x * QPB + q) * 4;
+    const bool ok = p < P;
+    const int64_t pc = ok ? p : 0;
     const int64_t N = (int64_t)BT * P;
     const Coef c = load_coef(alpha, s, n);
-    const float* Fs = F_hist + s * m * N;
-    const float* Gs = G_hist + s * m * N;
-    const float* ps = phi + (phi_shared ? 0 : s * N) + p;
-    float4 xv[BT], pv[BT];
+    const int64_t off = (int64_t)b * P + pc;
+    const float4 xv = mix4(F_hist + s * m * N, G_hist + s * m * N, N, off, c, n, omb);
+    const float4 pv = ld4(phi + (phi_shared ? 0 : s * N) + off);
+    const float4 yv = ld4(y + s * P + pc);
+    const float4 sv = ld4(phisum + (phi_shared ? 0 : s * P) + pc);
+    part[b][q] = xv * pv;
+    __syncthreads();
+    float4 fb = part[0][q];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) {
-        xv[b] = mix4(Fs, Gs, N, b * P + p, c, n, omb);
-        pv[b] = ld4(ps + b * P);
-    }
-    const float4 yv = ld4(y + s * P + p);
-    const float4 sv = ld4(phisum + (phi_shared ? 0 : s * P) + p);
-    float4 fb = xv[0] * pv[0];
-#pragma unroll
-    for (int b = 1; b < BT; ++b) fb = fb + xv[b] * pv[b];
+    for (int k = 1; k < BT; ++k) fb = fb + part[k][q];
     const float4 r = (yv - fb) / sv;
-    float* xo = x_out + s * N + p;
-    float* zo = z1 + s * N + p;
-#pragma unroll
-    for (int b = 0; b < BT; ++b) {
-        st4(xo + b * P, xv[b]);
-        st4(zo + b * P, xv[b] + r * pv[b]);
+    if (ok) {
+        st4(x_out + s * N + off, xv);
+        st4(z1 + s * N + off, xv + r * pv);
     }
 }
 
@@ -304,7 +328,7 @@ size_t deqsci_partials_bytes(int64_t bsz, int64_t N) {
     return (size_t)(bsz * deqsci_anderson_chunks(bsz, N)) * PART_STRIDE * sizeof(float);
 }
 
-size_t deqsci_gram_bytes(int64_t bsz) { return (size_t)bsz * GRAM_STRIDE * sizeof(double); }
+size_t deqsci_gram_bytes(int64_t bsz) { return (size_t)(bsz * GRAM_STRIDE + 2) * sizeof(double); }   // + arrival ticket
 
 int deqsci_residual_store_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
                               float* x_next, float* partials, int64_t bsz, int64_t N, int m, int slot, int n_filled,
@@ -335,7 +359,7 @@ int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, f
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
-    hipLaunchKernelGGL(anderson_solve_kernel, dim3(1), dim3(TB), 0, st, partials, static_cast<double*>(gram), alpha, res,
+    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
                        (int)bsz, nchunks, slot, n_filled, n, lam, eps);
     return launch_status();
 }
@@ -377,7 +401,7 @@ int deqsci_anderson_mix_gap_f32(const float* F_hist, const float* G_hist, const 
         return launch_status();
     }
     if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0 && (B == 4 || B == 8 || B == 16)) {
-        const dim3 grid(ceil_div(P / 4, TB), bsz);
+        const dim3 grid(ceil_div(P / 4, TB / B), bsz);
         if (B == 4) hipLaunchKernelGGL(mix_gap_bhw_kernel<4>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);
         else if (B == 8) hipLaunchKernelGGL(mix_gap_bhw_kernel<8>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);
         else hipLaunchKernelGGL(mix_gap_bhw_kernel<16>, grid, dim3(TB), 0, st, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared);

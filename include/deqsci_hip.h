@@ -89,7 +89,8 @@ int deqsci_residual_out_f32(const float* z1, const float* noise, float* out,
  */
 int64_t deqsci_anderson_chunks(int64_t bsz, int64_t N);
 size_t  deqsci_partials_bytes(int64_t bsz, int64_t N);           /* `partials` buffer            */
-size_t  deqsci_gram_bytes(int64_t bsz);                          /* persistent fp64 Gram + norms */
+size_t  deqsci_gram_bytes(int64_t bsz);                          /* persistent fp64 Gram + norms + arrival
+                                                                    ticket; ZERO it once before first use */
 
 /* K4  F_k = z1 - noise (noise may be NULL: F_k = z1);  G_k = F_k - x_cur;  store both into history
  *     slot `slot`; optionally x_next = F_k; per-block partial sums of <G_k,G_j> for j < n_filled and

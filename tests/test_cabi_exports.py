@@ -30,7 +30,7 @@ def test_scratch_size_queries_and_error_strings():
     assert b"gfx950" in lib.deqsci_version()
     n = lib.deqsci_anderson_chunks(8, 256 * 256 * 8)
     assert n > 0 and lib.deqsci_partials_bytes(8, 256 * 256 * 8) == 8 * n * _hip.PART_STRIDE * 4
-    assert lib.deqsci_gram_bytes(3) % (3 * 8) == 0
+    assert lib.deqsci_gram_bytes(3) == (3 * 80 + 2) * 8
     assert lib.deqsci_anderson_chunks(0, 10) == 0
     for code in (-1, -2, -3, -4):
         assert len(lib.deqsci_error_string(code)) > 5
