@@ -55,6 +55,8 @@ def cpu_baseline(iters_sample, full_calls, H, W, B, kind):
     x = torch.rand(1, H, W, B, generator=g)
     y = orc.sci_forward(x, Phi)
     Ps = orc.phi_sum(Phi)
+    threads = min(16, os.cpu_count() or 1)              # best of an 8..128 thread sweep on the 128-core GPU host
+    torch.set_num_threads(threads)
     f = orc.ProxGradSCI(kind)
     f(orc.initial_point(y, Phi), y, Phi, Ps)           # warm-up call (oneDNN primitive creation)
     f.calls = 0
@@ -78,7 +80,9 @@ def main():
     ap.add_argument("--iters", type=int, default=180)
     ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
     ap.add_argument("--size", default="256x256x8")
-    ap.add_argument("--cpu-iters", type=int, default=14)
+    ap.add_argument("--cpu-iters", type=int, default=28)
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-fused-epilogue", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -106,12 +110,14 @@ def main():
     net.load_state_dict({k.replace("nonlinear_op.", ""): v for k, v in
                          checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
     net = net.to(dev)
-    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5)
+    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
+                       channels_last=args.channels_last, fused_epilogue=not args.no_fused_epilogue)
     y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
     gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
 
-    # per-launch HIP-event timing of the fused Phi/Phi^T+GAP-update kernel, on the stream it runs on
-    ev_pairs = []
+    # per-launch timing of the fused Phi/Phi^T+GAP-update kernel from the dispatch's own HIP-event
+    # timestamps (hipExtLaunchKernelGGL start/stop events on the stream the kernel runs on)
+    timer = _hip.KernelTimer()
     timing_on = [False]
     if not args.no_kernel_timing:
         orig = _hip.anderson_mix_gap
@@ -119,13 +125,8 @@ def main():
         def timed_mix_gap(ws, beta, n, *a):
             if not timing_on[0] or n != eng.m:
                 return orig(ws, beta, n, *a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(ws, beta, n, *a)
-            e1.record()
-            ev_pairs.append((e0, e1))
-        import deqsci_amd.engine as engine_mod
-        engine_mod._hip.anderson_mix_gap = timed_mix_gap
+            return timer.mix_gap(ws, beta, n, *a)
+        _hip.anderson_mix_gap = timed_mix_gap
 
     def step():
         rec = eng.reconstruct(y, Phi)
@@ -169,15 +170,18 @@ def main():
         "final_res": eng.last_info["res"],
     }
     if rank == 0:
-        if ev_pairs:
-            ms = [a.elapsed_time(b) for a, b in ev_pairs]
+        ms = timer.durations_ms()
+        if ms:
             avg_s = 1e-3 * sum(ms) / len(ms)
             nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_mix_gap_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")     # rocprofv3 --pmc passes, tools/pmc_traffic.sh
             if os.path.exists(tfile):
                 with open(tfile) as fh:
-                    traffic = json.load(fh).get("hbm_bytes_per_launch")
+                    for rec in json.load(fh):
+                        k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
+                        if rec["bsz"] == bsz and rec["size"] == args.size and k:
+                            traffic = k["hbm_bytes_per_launch"]
             out["roofline"] = {"kernel": f"mix_gap_bhw_kernel<{B}> (K7+K3: Anderson mix + Phi/Phi^T GAP update)",
                                "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,

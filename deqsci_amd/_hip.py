@@ -32,6 +32,12 @@ SIGNATURES = {
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                     _i64, _i64, _i64, _i64, _int, _int, _ptr],
+    "deqsci_anderson_mix_gap_timed_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
+                                          _i64, _i64, _i64, _i64, _int, _int, _ptr, _ptr, _ptr],
+    "deqsci_bias_relu_f32": [_ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr],
+    "deqsci_event_create": [ctypes.POINTER(_ptr)],
+    "deqsci_event_destroy": [_ptr],
+    "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
 }
 OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
                  "deqsci_partials_bytes", "deqsci_gram_bytes")
@@ -260,3 +266,58 @@ def anderson_mix_gap(ws, beta, n, phi, y, phisum, x_out, z1, layout):
         _check(load().deqsci_anderson_mix_gap_f32(_p(ws.F), _p(ws.G), _p(ws.alpha), float(beta), n, ws.m, _p(phi, "Phi"),
                                                   _p(y, "y"), _p(phisum, "Phi_sum"), _p(x_out, "x_out"), _p(z1, "z1"),
                                                   bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream()), "anderson_mix_gap")
+
+
+def bias_relu_(h, bias, relu=True):
+    """In-place h = max(h + bias[c], 0) for a 4-D activation, NCHW-contiguous or channels_last."""
+    n, c, hh, ww = h.shape
+    if h.is_contiguous():
+        cl = 0
+    elif h.is_contiguous(memory_format=torch.channels_last):
+        cl = 1
+    else:
+        raise DeqsciHipError("bias_relu_: activation must be contiguous (NCHW or channels_last)")
+    if h.dtype != torch.float32 or not h.is_cuda:
+        raise DeqsciHipError("bias_relu_: fp32 GPU tensor required")
+    with _dev(h):
+        _check(load().deqsci_bias_relu_f32(h.data_ptr(), _p(bias, "bias"), n, c, hh * ww, cl, 1 if relu else 0, _stream()),
+               "bias_relu")
+    return h
+
+
+# ----------------------------------------------------------------------------- measurement helpers (bench.py)
+class KernelTimer:
+    """Per-launch kernel durations of the fused mix+GAP kernel from the dispatch's own timestamps
+    (deqsci_anderson_mix_gap_timed_f32); read after the stream has been synchronised."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def _event(self):
+        h = _ptr()
+        _check(load().deqsci_event_create(ctypes.byref(h)), "event_create")
+        return h
+
+    def mix_gap(self, ws, beta, n, phi, y, phisum, x_out, z1, layout):
+        bsz, H, W, B = _dims(layout, z1.shape)
+        e0, e1 = self._event(), self._event()
+        with _dev(ws.F):
+            _check(load().deqsci_anderson_mix_gap_timed_f32(
+                _p(ws.F), _p(ws.G), _p(ws.alpha), float(beta), n, ws.m, _p(phi, "Phi"), _p(y, "y"), _p(phisum, "Phi_sum"),
+                _p(x_out, "x_out"), _p(z1, "z1"), bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream(), e0, e1),
+                "anderson_mix_gap_timed")
+        self.pairs.append((e0, e1))
+
+    def durations_ms(self):
+        out = []
+        ms = _f32()
+        for e0, e1 in self.pairs:
+            _check(load().deqsci_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "event_elapsed_ms")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for e0, e1 in self.pairs:
+            load().deqsci_event_destroy(e0)
+            load().deqsci_event_destroy(e1)
+        self.pairs = []

@@ -56,8 +56,10 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True):
+    def __init__(self, net, fold_bn=True, channels_last=False, fused_epilogue=True):
         self.net = net
+        self.channels_last = channels_last
+        self.fused_epilogue = fused_epilogue
         self.tag = getattr(net, "tag", None)
         if self.tag not in ("conv2d", "conv3d", "ffdnet", "denoiser", "3d_denoiser"):
             raise NotImplementedError(f"unknown nonlinear_op tag {self.tag!r}")
@@ -94,7 +96,8 @@ class _Denoiser:
                 relu = i < len(mods) and isinstance(mods[i], torch.nn.ReLU)
                 if relu:
                     i += 1
-                layers.append((w.contiguous(), b, relu))
+                w = w.contiguous(memory_format=torch.channels_last) if self.channels_last else w.contiguous()
+                layers.append((w, b, relu))
             self.fast = layers
 
     def prepare(self, n_calls, device):
@@ -109,10 +112,17 @@ class _Denoiser:
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
                 h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
+                if self.channels_last:
+                    h = h.contiguous(memory_format=torch.channels_last)
+                fused = self.fused_epilogue and h.is_cuda
                 for w, b, relu in self.fast:
-                    h = F.conv2d(h, w, b, padding=1)
-                    if relu:
-                        h = F.relu_(h)
+                    if fused and b is not None:
+                        # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
+                        h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
+                    else:
+                        h = F.conv2d(h, w, b, padding=1)
+                        if relu:
+                            h = F.relu_(h)
                 out = F.pixel_shuffle(h, 2)
             else:
                 out = self.net(x, sig)
@@ -127,10 +137,10 @@ class _Denoiser:
 
 class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
-                 fold_bn=True, extra_call=False, poll_residual=True):
+                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=False, fused_epilogue=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
-        self.den = _Denoiser(denoiser, fold_bn=fold_bn)
+        self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue)
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
         self.max_iter, self.tol = int(max_iter), float(tol)

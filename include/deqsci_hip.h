@@ -125,6 +125,26 @@ int deqsci_anderson_mix_gap_f32(const float* F_hist, const float* G_hist, const 
                                 int64_t bsz, int64_t H, int64_t W, int64_t B,
                                 int layout, int phi_shared, deqsci_stream_t stream);
 
+/* Denoiser epilogue: h = max(h + bias[c], 0) in place (relu = 0: bias only), h (n,c,hw) NCHW-contiguous or
+ *     channels_last.  Fuses the BatchNorm(eval)+ReLU of networks/ffdnet/models.py:53-58 - folded into the
+ *     preceding conv's weights plus this per-channel bias - into one pass instead of PyTorch's two. */
+int deqsci_bias_relu_f32(float* h, const float* bias, int64_t n, int64_t c, int64_t hw,
+                         int channels_last, int relu, deqsci_stream_t stream);
+
+/* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
+ * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
+ * without the marker-packet overhead of events recorded around a launch. */
+int deqsci_anderson_mix_gap_timed_f32(const float* F_hist, const float* G_hist, const float* alpha,
+                                      float beta, int n, int m,
+                                      const float* phi, const float* y, const float* phisum,
+                                      float* x_out, float* z1,
+                                      int64_t bsz, int64_t H, int64_t W, int64_t B,
+                                      int layout, int phi_shared, deqsci_stream_t stream,
+                                      void* start_event, void* stop_event);
+int deqsci_event_create(void** ev);
+int deqsci_event_destroy(void* ev);
+int deqsci_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream is synchronised */
+
 #ifdef __cplusplus
 }
 #endif

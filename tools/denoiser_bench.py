@@ -31,9 +31,22 @@ def main():
     net = build_denoiser("ffdnet").eval()
     net.load_state_dict(checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray"))[0])
     net = net.to(dev)
-    den = _Denoiser(net)
+    den = _Denoiser(net, fused_epilogue=False)
     den.prepare(8, dev)
-    for nimg in (8, 64, 128):
+    variants = {"nchw+fused_epilogue": _Denoiser(net), "channels_last+fused_epilogue": _Denoiser(net, channels_last=True),
+                "channels_last unfused": _Denoiser(net, channels_last=True, fused_epilogue=False)}
+    for v in variants.values():
+        v.prepare(8, dev)
+    for nimg in (8, 64):
+        xx = torch.rand(nimg // 8, 8, 256, 256, device=dev)
+        with torch.no_grad():
+            ref = den.run(xx, 3)[0]
+            for name, v in variants.items():
+                got = v.run(xx, 3)[0]
+                err = float((got - ref).norm() / ref.norm())
+                tt = timeit(lambda: v.run(xx, 3))
+                print(json.dumps({"variant": "ffdnet folded " + name, "images": nimg, "ms": round(tt * 1e3, 3), "rel_err_vs_unfused": err}), flush=True)
+    for nimg in (8, 64):
         x = torch.rand(nimg // 8, 8, 256, 256, device=dev)
         gflop = 127.0 * nimg / 8
         with torch.no_grad():
