@@ -24,7 +24,7 @@ namespace deqsci {
 // ------------------------------------------------------------------------------------------------
 // K4
 // ------------------------------------------------------------------------------------------------
-template <int NF>   // number of filled history slots INCLUDING the one being written
+template <int NF, int POL>   // NF = number of filled history slots INCLUDING the one being written
 __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restrict__ z1, const float* __restrict__ noise,
                                                             const float* x_cur, float* __restrict__ F_hist,
                                                             float* __restrict__ G_hist, float* x_next,
@@ -51,15 +51,15 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
         int64_t i = beg + 4 * threadIdx.x;
         for (; i + 4 * TB < end; i += 8 * TB) {
             const int64_t i2 = i + 4 * TB;
-            float4 f = ld4(zs + i), f2 = ld4(zs + i2);
-            if (ns) { f = f - ld4(ns + i); f2 = f2 - ld4(ns + i2); }
-            const float4 g = f - ld4(xs + i), g2 = f2 - ld4(xs + i2);
+            float4 f = ldp<POL>(zs + i), f2 = ldp<POL>(zs + i2);
+            if (ns) { f = f - ldp<POL>(ns + i); f2 = f2 - ldp<POL>(ns + i2); }
+            const float4 g = f - ldp<POL>(xs + i), g2 = f2 - ldp<POL>(xs + i2);
             float4 o[NF], o2[NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) if (j != slot) { o[j] = ld4(Gall + j * N + i); o2[j] = ld4(Gall + j * N + i2); }
-            st4(Fs + i, f); st4(Fs + i2, f2);
-            st4(Gs + i, g); st4(Gs + i2, g2);
-            if (xn) { st4(xn + i, f); st4(xn + i2, f2); }
+            for (int j = 0; j < NF; ++j) if (j != slot) { o[j] = ldp<POL>(Gall + j * N + i); o2[j] = ldp<POL>(Gall + j * N + i2); }
+            stp<POL>(Fs + i, f); stp<POL>(Fs + i2, f2);
+            stp<POL>(Gs + i, g); stp<POL>(Gs + i2, g2);
+            if (xn) { stp<POL>(xn + i, f); stp<POL>(xn + i2, f2); }
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 acc[j] = dot4_fma(g, (j == slot) ? g : o[j], acc[j]);
@@ -68,15 +68,15 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
             accf = dot4_fma(f2, f2, dot4_fma(f, f, accf));
         }
         for (; i < end; i += 4 * TB) {
-            float4 f = ld4(zs + i);
-            if (ns) f = f - ld4(ns + i);
-            const float4 g = f - ld4(xs + i);
+            float4 f = ldp<POL>(zs + i);
+            if (ns) f = f - ldp<POL>(ns + i);
+            const float4 g = f - ldp<POL>(xs + i);
             float4 o[NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) if (j != slot) o[j] = ld4(Gall + j * N + i);
-            st4(Fs + i, f);
-            st4(Gs + i, g);
-            if (xn) st4(xn + i, f);
+            for (int j = 0; j < NF; ++j) if (j != slot) o[j] = ldp<POL>(Gall + j * N + i);
+            stp<POL>(Fs + i, f);
+            stp<POL>(Gs + i, g);
+            if (xn) stp<POL>(xn + i, f);
 #pragma unroll
             for (int j = 0; j < NF; ++j) acc[j] = dot4_fma(g, (j == slot) ? g : o[j], acc[j]);
             accf = dot4_fma(f, f, accf);
@@ -201,19 +201,21 @@ __device__ __forceinline__ Coef load_coef(const float* alpha, int64_t s, int n) 
 }
 
 // x = beta * sum a_i F_i + (1-beta) * sum a_i (F_i - G_i) = sum a_i F_i - (1-beta) sum a_i G_i
+template <int POL>
 __device__ __forceinline__ float4 mix4(const float* Fs, const float* Gs, int64_t N, int64_t off, const Coef& c, int n, float omb) {
     float4 x = f4(0.0f);
 #pragma unroll
-    for (int i = 0; i < MAXM; ++i) if (i < n) x = fma4(c.a[i], ld4(Fs + i * N + off), x);
+    for (int i = 0; i < MAXM; ++i) if (i < n) x = fma4(c.a[i], ldp<POL>(Fs + i * N + off), x);
     if (omb != 0.0f) {
         float4 g = f4(0.0f);
 #pragma unroll
-        for (int i = 0; i < MAXM; ++i) if (i < n) g = fma4(c.a[i], ld4(Gs + i * N + off), g);
+        for (int i = 0; i < MAXM; ++i) if (i < n) g = fma4(c.a[i], ldp<POL>(Gs + i * N + off), g);
         x = fma4(-omb, g, x);
     }
     return x;
 }
 
+template <int POL>
 __global__ __launch_bounds__(TB) void mix_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
                                                  const float* __restrict__ alpha, float* __restrict__ x_out, float omb, int n,
                                                  int64_t N, int m, int vec) {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(TB) void mix_kernel(const float* __restrict__ F_his
     float* xs = x_out + s * N;
     if (vec) {
         const int64_t i = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
-        if (i < N) st4(xs + i, mix4(Fs, Gs, N, i, c, n, omb));
+        if (i < N) stp<POL>(xs + i, mix4<POL>(Fs, Gs, N, i, c, n, omb));
     } else {
         const int64_t i0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
         const int64_t i1 = i0 + 4 < N ? i0 + 4 : N;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(TB) void mix_kernel(const float* __restrict__ F_his
 
 constexpr int UNR = 2;
 
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void mix_gap_hwb_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
                                                          const float* __restrict__ alpha, float omb, int n, int m,
                                                          const float* __restrict__ phi, const float* __restrict__ y,
@@ -257,13 +259,13 @@ __global__ __launch_bounds__(TB) void mix_gap_hwb_kernel(const float* __restrict
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
         const int64_t qc = q < Q ? q : Q - 1;
-        const float4 x = mix4(Fs, Gs, N, qc * 4, c, n, omb);
-        const float4 pv = ld4(ps + qc * 4);
+        const float4 x = mix4<POL>(Fs, Gs, N, qc * 4, c, n, omb);
+        const float4 pv = ldp<POL>(ps + qc * 4);
         const float fb = group_sum<LP>(dot4_seq(x, pv));
         const float r = (ys[qc / LP] - fb) / ss[qc / LP];
         if (q < Q) {
-            st4(x_out + s * N + q * 4, x);
-            st4(z1 + s * N + q * 4, x + r * pv);
+            stp<POL>(x_out + s * N + q * 4, x);
+            stp<POL>(z1 + s * N + q * 4, x + r * pv);
         }
     }
 }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(TB) void mix_gap_hwb_kernel(const float* __restrict
 // 512-B contiguous per frame row and wave), the per-pixel frame column is staged in LDS, every lane
 // re-reads its quad's BT partial products (conflict-free ds_read_b128) to form Phi x, and writes
 // x and z1.  8x more wavefronts in flight than a lane-owns-the-column mapping at batch 8.
-template <int BT>
+template <int BT, int POL>
 __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict__ F_hist, const float* __restrict__ G_hist,
                                                          const float* __restrict__ alpha, float omb, int n, int m,
                                                          const float* __restrict__ phi, const float* __restrict__ y,
@@ -289,8 +291,8 @@ __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict
     const int64_t N = (int64_t)BT * P;
     const Coef c = load_coef(alpha, s, n);
     const int64_t off = (int64_t)b * P + pc;
-    const float4 xv = mix4(F_hist + s * m * N, G_hist + s * m * N, N, off, c, n, omb);
-    const float4 pv = ld4(phi + (phi_shared ? 0 : s * N) + off);
+    const float4 xv = mix4<POL>(F_hist + s * m * N, G_hist + s * m * N, N, off, c, n, omb);
+    const float4 pv = ldp<POL>(phi + (phi_shared ? 0 : s * N) + off);
     const float4 yv = ld4(y + s * P + pc);
     const float4 sv = ld4(phisum + (phi_shared ? 0 : s * P) + pc);
     part[b][q] = xv * pv;
@@ -300,10 +302,18 @@ __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict
     for (int k = 1; k < BT; ++k) fb = fb + part[k][q];
     const float4 r = (yv - fb) / sv;
     if (ok) {
-        st4(x_out + s * N + off, xv);
-        st4(z1 + s * N + off, xv + r * pv);
+        stp<POL>(x_out + s * N + off, xv);
+        stp<POL>(z1 + s * N + off, xv + r * pv);
     }
 }
+
+#define POL2_DISPATCH(pol, ...)                                            \
+    switch (pol) {                                                         \
+        case POL_NTL:  { constexpr int POL = POL_NTL; __VA_ARGS__; } break;  \
+        case POL_NTS:  { constexpr int POL = POL_NTS; __VA_ARGS__; } break;  \
+        case POL_NTLS: { constexpr int POL = POL_NTLS; __VA_ARGS__; } break; \
+        default:       { constexpr int POL = POL_DEFAULT; __VA_ARGS__; } break; \
+    }
 
 static inline int64_t chunk_elems(int64_t bsz, int64_t N) {
     // ~2048 blocks over the whole batch, each block a whole number of 1024-element sweeps (>= 2)
@@ -344,7 +354,8 @@ int deqsci_residual_store_f32(const float* z1, const float* noise, const float* 
     const int64_t chunk = chunk_elems(bsz, N);
     const dim3 grid(ceil_div(N, chunk), bsz);
     const int vec = (N % 4 == 0) ? 1 : 0;
-#define RS_CASE(NF) case NF: hipLaunchKernelGGL(residual_store_kernel<NF>, grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec); break;
+    const int pol = pick_policy(bsz * N * 4 * (n_filled + 4), POL_NTLS);
+#define RS_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec)); break;
     switch (n_filled) {
         RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
         default: return DEQSCI_ERR_UNSUPPORTED;
@@ -372,8 +383,9 @@ int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const floa
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(F_hist) || !aligned16(G_hist) || !aligned16(x_out)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mix_kernel, dim3(ceil_div(ceil_div(N, 4), TB), bsz), dim3(TB), 0, st, F_hist, G_hist, alpha, x_out,
-                       1.0f - beta, n, N, m, (N % 4 == 0) ? 1 : 0);
+    const int pol = pick_policy(bsz * N * 4 * (n + 1), POL_NTLS);
+    POL2_DISPATCH(pol, hipLaunchKernelGGL(mix_kernel<POL>, dim3(ceil_div(ceil_div(N, 4), TB), bsz), dim3(TB), 0, st, F_hist, G_hist, alpha, x_out,
+                                          1.0f - beta, n, N, m, (N % 4 == 0) ? 1 : 0));
     return launch_status();
 }
 
@@ -390,25 +402,26 @@ static int mix_gap_impl(const float* F_hist, const float* G_hist, const float* a
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W, N = P * B;
     const float omb = 1.0f - beta;
+    const int pol = pick_policy(bsz * P * (4 * B * (n + 3) + 8), POL_NTLS);
     // hipExtLaunchKernelGGL stamps ev0/ev1 with the dispatch's own begin/end (what rocprofv3 reports);
     // with null events it is an ordinary launch.
-#define MG_LAUNCH(KERNEL, GRID) hipExtLaunchKernelGGL(KERNEL, GRID, dim3(TB), 0, st, ev0, ev1, 0, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared)
+#define MG_LAUNCH(KERNEL, TP1, GRID) POL2_DISPATCH(pol, hipExtLaunchKernelGGL((KERNEL<TP1, POL>), GRID, dim3(TB), 0, st, ev0, ev1, 0, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared))
     if (layout == DEQSCI_LAYOUT_HWB && (B == 4 || B == 8 || B == 16 || B == 32)) {
         const int LPv = (int)(B / 4);
         const dim3 grid(ceil_div(P * LPv, TB * UNR), bsz);
         switch (LPv) {
-            case 1: MG_LAUNCH(mix_gap_hwb_kernel<1>, grid); break;
-            case 2: MG_LAUNCH(mix_gap_hwb_kernel<2>, grid); break;
-            case 4: MG_LAUNCH(mix_gap_hwb_kernel<4>, grid); break;
-            default: MG_LAUNCH(mix_gap_hwb_kernel<8>, grid); break;
+            case 1: MG_LAUNCH(mix_gap_hwb_kernel, 1, grid); break;
+            case 2: MG_LAUNCH(mix_gap_hwb_kernel, 2, grid); break;
+            case 4: MG_LAUNCH(mix_gap_hwb_kernel, 4, grid); break;
+            default: MG_LAUNCH(mix_gap_hwb_kernel, 8, grid); break;
         }
         return launch_status();
     }
     if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0 && (B == 4 || B == 8 || B == 16)) {
         const dim3 grid(ceil_div(P / 4, TB / B), bsz);
-        if (B == 4) MG_LAUNCH(mix_gap_bhw_kernel<4>, grid);
-        else if (B == 8) MG_LAUNCH(mix_gap_bhw_kernel<8>, grid);
-        else MG_LAUNCH(mix_gap_bhw_kernel<16>, grid);
+        if (B == 4) { MG_LAUNCH(mix_gap_bhw_kernel, 4, grid); }
+        else if (B == 8) { MG_LAUNCH(mix_gap_bhw_kernel, 8, grid); }
+        else { MG_LAUNCH(mix_gap_bhw_kernel, 16, grid); }
         return launch_status();
     }
 #undef MG_LAUNCH

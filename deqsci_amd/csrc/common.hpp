@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "deqsci_hip.h"
 
@@ -12,6 +13,38 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Streaming ("nt") forms for the big once-through tensors (z, Phi, history rows, activations): on MI355X a
+// 2-read/1-write fp32 stream moves 5.6 TB/s with default-policy accesses and 6.7 TB/s with nt loads AND nt
+// stores (tools/ubench/gap_variants.hip) - the lines are not kept in L2/MALL where nothing would re-read them.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4s(const float* p) {
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4s(float* p, float4 v) {
+    const v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+// Cache policy of a kernel's big streams, chosen by the launcher: bit 0 = nt loads, bit 1 = nt stores.
+// Same-box sweep of every kernel on rotating buffer sets (tools/policy_sweep.sh, profiles/r01_policy_sweep.txt):
+// nt loads AND nt stores win or tie everywhere (K3 77 -> 65 us = 5.7 -> 6.7 TB/s, K7+K3 196 -> 172 us), so every
+// launch that touches at least STREAM_MIN_BYTES streams; smaller launches keep the default policy so a small
+// working set stays in L2 / Infinity Cache for the next kernel.
+constexpr int POL_DEFAULT = 0, POL_NTL = 1, POL_NTS = 2, POL_NTLS = 3;
+constexpr int64_t STREAM_MIN_BYTES = 64ll << 20;
+template <int POL> __device__ __forceinline__ float4 ldp(const float* p) { return (POL & 1) ? ld4s(p) : ld4(p); }
+template <int POL> __device__ __forceinline__ void stp(float* p, float4 v) { if (POL & 2) st4s(p, v); else st4(p, v); }
+inline int forced_policy() {      // tuning knob only (tools/kernel_bench.py --policy-sweep): DEQSCI_FORCE_POLICY=0..3
+    static const int v = [] { const char* e = getenv("DEQSCI_FORCE_POLICY"); return e ? atoi(e) : -1; }();
+    return v;
+}
+inline int pick_policy(int64_t bytes, int streaming_policy) {
+    const int f = forced_policy();
+    if (f >= 0 && f <= 3) return f;
+    return bytes >= STREAM_MIN_BYTES ? streaming_policy : POL_DEFAULT;
+}
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 __device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }

@@ -30,7 +30,7 @@ constexpr int TS = TP + 4;      // LDS row stride (floats): 16-B aligned rows, b
 // ------------------------------------------------------------------------------------------------
 // HWB fast paths: B = 4*LP, lane -> (pixel, quarter)
 // ------------------------------------------------------------------------------------------------
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void forward_hwb_kernel(const float* __restrict__ x, const float* __restrict__ phi,
                                                          float* __restrict__ y, int64_t P, int phi_shared) {
     const int64_t n = blockIdx.y;
@@ -44,8 +44,8 @@ __global__ __launch_bounds__(TB) void forward_hwb_kernel(const float* __restrict
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
         const int64_t qc = q < Q ? q : Q - 1;
-        xv[j] = ld4(xs + qc * 4);
-        pv[j] = ld4(ps + qc * 4);
+        xv[j] = ldp<POL>(xs + qc * 4);
+        pv[j] = ldp<POL>(ps + qc * 4);
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(TB) void forward_hwb_kernel(const float* __restrict
     }
 }
 
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void adjoint_hwb_kernel(const float* __restrict__ y, const float* __restrict__ phi,
                                                          float* __restrict__ x, int64_t P, int phi_shared) {
     const int64_t n = blockIdx.y;
@@ -70,17 +70,17 @@ __global__ __launch_bounds__(TB) void adjoint_hwb_kernel(const float* __restrict
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
         const int64_t qc = q < Q ? q : Q - 1;
-        pv[j] = ld4(ps + qc * 4);
+        pv[j] = ldp<POL>(ps + qc * 4);
         yv[j] = ys[qc / LP];
     }
 #pragma unroll
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
-        if (q < Q) st4(xs + q * 4, yv[j] * pv[j]);
+        if (q < Q) stp<POL>(xs + q * 4, yv[j] * pv[j]);
     }
 }
 
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void phisum_hwb_kernel(const float* __restrict__ phi, float* __restrict__ out, int64_t P) {
     const int64_t n = blockIdx.y;
     const int64_t Q = P * LP;
@@ -91,14 +91,14 @@ __global__ __launch_bounds__(TB) void phisum_hwb_kernel(const float* __restrict_
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
         const int64_t qc = q < Q ? q : Q - 1;
-        const float4 p = ld4(ps + qc * 4);
+        const float4 p = ldp<POL>(ps + qc * 4);
         const float s = group_sum<LP>(((p.x + p.y) + p.z) + p.w);
         if (q < Q && (q & (LP - 1)) == 0) os[q / LP] = (s == 0.0f) ? 1.0f : s;
     }
 }
 
 // z1 may alias z: every element is read and written by the same lane, loads precede stores.
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void gap_hwb_kernel(const float* z, const float* __restrict__ phi,
                                                      const float* __restrict__ y, const float* __restrict__ phisum,
                                                      float* z1, int64_t P, int phi_shared) {
@@ -116,8 +116,8 @@ __global__ __launch_bounds__(TB) void gap_hwb_kernel(const float* z, const float
     for (int j = 0; j < UNR; ++j) {
         const int64_t q = base + j * TB;
         const int64_t qc = q < Q ? q : Q - 1;
-        zv[j] = ld4(zs + qc * 4);
-        pv[j] = ld4(ps + qc * 4);
+        zv[j] = ldp<POL>(zs + qc * 4);
+        pv[j] = ldp<POL>(ps + qc * 4);
         yv[j] = ys[qc / LP];
         sv[j] = ss[qc / LP];
     }
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(TB) void gap_hwb_kernel(const float* z, const float
         const int64_t q = base + j * TB;
         const float fb = group_sum<LP>(dot4_seq(zv[j], pv[j]));
         const float r = (yv[j] - fb) / sv[j];
-        if (q < Q) st4(os + q * 4, zv[j] + r * pv[j]);
+        if (q < Q) stp<POL>(os + q * 4, zv[j] + r * pv[j]);
     }
 }
 
 // HWB in, BHW out: GAP projection fused with the (H,W,B)->(B,H,W) transpose the denoiser needs.
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void gap_hwb2bhw_kernel(const float* __restrict__ z, const float* __restrict__ phi,
                                                          const float* __restrict__ y, const float* __restrict__ phisum,
                                                          float* __restrict__ z1, int64_t P, int phi_shared) {
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(TB) void gap_hwb2bhw_kernel(const float* __restrict
         const int pl = e / LP, qq = e % LP;
         int64_t p = pix0 + pl;
         if (p >= P) p = P - 1;
-        zv[j] = ld4(zs + p * B + 4 * qq);
-        pv[j] = ld4(ps + p * B + 4 * qq);
+        zv[j] = ldp<POL>(zs + p * B + 4 * qq);
+        pv[j] = ldp<POL>(ps + p * B + 4 * qq);
         yv[j] = ys[p];
         sv[j] = ss[p];
     }
@@ -173,12 +173,12 @@ __global__ __launch_bounds__(TB) void gap_hwb2bhw_kernel(const float* __restrict
         const int e = j * TB + threadIdx.x;
         const int b = e / (TP / 4), p4 = e % (TP / 4);
         const int64_t p = pix0 + 4 * p4;
-        if (p < P) st4(os + b * P + p, *reinterpret_cast<const float4*>(tile + b * TS + 4 * p4));
+        if (p < P) stp<POL>(os + b * P + p, *reinterpret_cast<const float4*>(tile + b * TS + 4 * p4));
     }
 }
 
 // planar in (z1, noise), HWB out: out = z1 - noise
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void residual_out_bhw2hwb_kernel(const float* __restrict__ z1, const float* __restrict__ noise,
                                                                   float* __restrict__ out, int64_t P) {
     constexpr int B = 4 * LP;
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(TB) void residual_out_bhw2hwb_kernel(const float* _
         const int b = e / (TP / 4), p4 = e % (TP / 4);
         const int64_t p = pix0 + 4 * p4;
         if (p < P) {
-            float4 v = ld4(zs + b * P + p);
-            if (ns) v = v - ld4(ns + b * P + p);
+            float4 v = ldp<POL>(zs + b * P + p);
+            if (ns) v = v - ldp<POL>(ns + b * P + p);
             *reinterpret_cast<float4*>(tile + b * TS + 4 * p4) = v;
         }
     }
@@ -207,13 +207,13 @@ __global__ __launch_bounds__(TB) void residual_out_bhw2hwb_kernel(const float* _
         const int64_t p = pix0 + pl;
         if (p < P) {
             const float* t = tile + (4 * qq) * TS + pl;
-            st4(os + p * B + 4 * qq, make_float4(t[0], t[TS], t[2 * TS], t[3 * TS]));
+            stp<POL>(os + p * B + 4 * qq, make_float4(t[0], t[TS], t[2 * TS], t[3 * TS]));
         }
     }
 }
 
 // HWB -> BHW plain transpose (LP fast path)
-template <int LP>
+template <int LP, int POL>
 __global__ __launch_bounds__(TB) void transpose_hwb2bhw_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t P) {
     constexpr int B = 4 * LP;
     __shared__ __attribute__((aligned(16))) float tile[B * TS];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TB) void transpose_hwb2bhw_kernel(const float* __re
         const int pl = e / LP, qq = e % LP;
         const int64_t p = pix0 + pl;
         if (p < P) {
-            const float4 v = ld4(is + p * B + 4 * qq);
+            const float4 v = ldp<POL>(is + p * B + 4 * qq);
             float* t = tile + (4 * qq) * TS + pl;
             t[0] = v.x; t[TS] = v.y; t[2 * TS] = v.z; t[3 * TS] = v.w;
         }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TB) void transpose_hwb2bhw_kernel(const float* __re
         const int e = j * TB + threadIdx.x;
         const int b = e / (TP / 4), p4 = e % (TP / 4);
         const int64_t p = pix0 + 4 * p4;
-        if (p < P) st4(os + b * P + p, *reinterpret_cast<const float4*>(tile + b * TS + 4 * p4));
+        if (p < P) stp<POL>(os + b * P + p, *reinterpret_cast<const float4*>(tile + b * TS + 4 * p4));
     }
 }
 
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TB) void transpose_generic_kernel(const float* __re
 // ------------------------------------------------------------------------------------------------
 // BHW (planar) fast paths: lane -> 4 adjacent pixels, frame column in registers
 // ------------------------------------------------------------------------------------------------
-template <int BT>
+template <int BT, int POL>
 __global__ __launch_bounds__(TB) void gap_bhw_kernel(const float* z, const float* __restrict__ phi,
                                                      const float* __restrict__ y, const float* __restrict__ phisum,
                                                      float* z1, int64_t P, int phi_shared) {
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TB) void gap_bhw_kernel(const float* z, const float
     const float* ps = phi + (phi_shared ? 0 : n * BT * P) + p;
     float4 zv[BT], pv[BT];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) { zv[b] = ld4(zs + b * P); pv[b] = ld4(ps + b * P); }
+    for (int b = 0; b < BT; ++b) { zv[b] = ldp<POL>(zs + b * P); pv[b] = ldp<POL>(ps + b * P); }
     const float4 yv = ld4(y + n * P + p);
     const float4 sv = ld4(phisum + (phi_shared ? 0 : n * P) + p);
     float4 fb = zv[0] * pv[0];
@@ -286,9 +286,10 @@ __global__ __launch_bounds__(TB) void gap_bhw_kernel(const float* z, const float
     const float4 r = (yv - fb) / sv;
     float* os = z1 + n * BT * P + p;
 #pragma unroll
-    for (int b = 0; b < BT; ++b) st4(os + b * P, zv[b] + r * pv[b]);
+    for (int b = 0; b < BT; ++b) stp<POL>(os + b * P, zv[b] + r * pv[b]);
 }
 
+template <int POL>
 __global__ __launch_bounds__(TB) void forward_bhw_kernel(const float* __restrict__ x, const float* __restrict__ phi,
                                                          float* __restrict__ y, int64_t P, int B, int phi_shared) {
     const int64_t n = blockIdx.y;
@@ -296,12 +297,13 @@ __global__ __launch_bounds__(TB) void forward_bhw_kernel(const float* __restrict
     if (p >= P) return;
     const float* xs = x + n * B * P + p;
     const float* ps = phi + (phi_shared ? 0 : n * B * P) + p;
-    float4 acc = ld4(xs) * ld4(ps);
+    float4 acc = ldp<POL>(xs) * ldp<POL>(ps);
 #pragma unroll 8
-    for (int b = 1; b < B; ++b) acc = acc + ld4(xs + b * P) * ld4(ps + b * P);
-    st4(y + n * P + p, acc);
+    for (int b = 1; b < B; ++b) acc = acc + ldp<POL>(xs + b * P) * ldp<POL>(ps + b * P);
+    stp<POL>(y + n * P + p, acc);
 }
 
+template <int POL>
 __global__ __launch_bounds__(TB) void adjoint_bhw_kernel(const float* __restrict__ y, const float* __restrict__ phi,
                                                          float* __restrict__ x, int64_t P, int B, int phi_shared) {
     const int64_t n = blockIdx.y;
@@ -311,30 +313,32 @@ __global__ __launch_bounds__(TB) void adjoint_bhw_kernel(const float* __restrict
     const float* ps = phi + (phi_shared ? 0 : n * B * P) + p;
     float* xs = x + n * B * P + p;
 #pragma unroll 8
-    for (int b = 0; b < B; ++b) st4(xs + b * P, yv * ld4(ps + b * P));
+    for (int b = 0; b < B; ++b) stp<POL>(xs + b * P, yv * ldp<POL>(ps + b * P));
 }
 
+template <int POL>
 __global__ __launch_bounds__(TB) void phisum_bhw_kernel(const float* __restrict__ phi, float* __restrict__ out, int64_t P, int B) {
     const int64_t n = blockIdx.y;
     const int64_t p = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
     if (p >= P) return;
     const float* ps = phi + n * B * P + p;
-    float4 acc = ld4(ps);
+    float4 acc = ldp<POL>(ps);
 #pragma unroll 8
-    for (int b = 1; b < B; ++b) acc = acc + ld4(ps + b * P);
+    for (int b = 1; b < B; ++b) acc = acc + ldp<POL>(ps + b * P);
     acc.x = acc.x == 0.0f ? 1.0f : acc.x; acc.y = acc.y == 0.0f ? 1.0f : acc.y;
     acc.z = acc.z == 0.0f ? 1.0f : acc.z; acc.w = acc.w == 0.0f ? 1.0f : acc.w;
-    st4(out + n * P + p, acc);
+    stp<POL>(out + n * P + p, acc);
 }
 
 // out = a - b (b may be null), flat float4 stream
+template <int POL>
 __global__ __launch_bounds__(TB) void sub_flat_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       float* __restrict__ out, int64_t n4, int64_t tail_from, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i < n4) {
-        float4 v = ld4(a + 4 * i);
-        if (b) v = v - ld4(b + 4 * i);
-        st4(out + 4 * i, v);
+        float4 v = ldp<POL>(a + 4 * i);
+        if (b) v = v - ldp<POL>(b + 4 * i);
+        stp<POL>(out + 4 * i, v);
     }
     if (i == 0) for (int64_t t = tail_from; t < total; ++t) out[t] = a[t] - (b ? b[t] : 0.0f);
 }
@@ -386,12 +390,19 @@ static inline int check_dims(int64_t bsz, int64_t H, int64_t W, int64_t B, int l
     return 0;
 }
 
-#define LP_DISPATCH(B, CALL)                         \
+#define LP_DISPATCH(B, ...)                          \
     switch ((int)(B)) {                              \
-        case 4:  { constexpr int LP = 1; CALL; } break; \
-        case 8:  { constexpr int LP = 2; CALL; } break; \
-        case 16: { constexpr int LP = 4; CALL; } break; \
-        default: { constexpr int LP = 8; CALL; } break; \
+        case 4:  { constexpr int LP = 1; __VA_ARGS__; } break; \
+        case 8:  { constexpr int LP = 2; __VA_ARGS__; } break; \
+        case 16: { constexpr int LP = 4; __VA_ARGS__; } break; \
+        default: { constexpr int LP = 8; __VA_ARGS__; } break; \
+    }
+#define POL_DISPATCH(pol, ...)                                   \
+    switch (pol) {                                               \
+        case POL_NTL:  { constexpr int POL = POL_NTL; __VA_ARGS__; } break;  \
+        case POL_NTS:  { constexpr int POL = POL_NTS; __VA_ARGS__; } break;  \
+        case POL_NTLS: { constexpr int POL = POL_NTLS; __VA_ARGS__; } break; \
+        default:       { constexpr int POL = POL_DEFAULT; __VA_ARGS__; } break; \
     }
 
 }  // namespace deqsci
@@ -420,10 +431,11 @@ int deqsci_sci_forward_f32(const float* x, const float* phi, float* y, int64_t b
     if (!aligned16(x) || !aligned16(phi) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
+    const int pol = pick_policy(bsz * P * (8 * B + 4), POL_NTLS);
     if (layout == DEQSCI_LAYOUT_HWB && lp_ok(B)) {
-        LP_DISPATCH(B, hipLaunchKernelGGL(forward_hwb_kernel<LP>, dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, x, phi, y, P, phi_shared));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((forward_hwb_kernel<LP, POL>), dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, x, phi, y, P, phi_shared)));
     } else if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0) {
-        hipLaunchKernelGGL(forward_bhw_kernel, dim3(ceil_div(P / 4, TB), bsz), dim3(TB), 0, st, x, phi, y, P, (int)B, phi_shared);
+        POL_DISPATCH(pol, hipLaunchKernelGGL(forward_bhw_kernel<POL>, dim3(ceil_div(P / 4, TB), bsz), dim3(TB), 0, st, x, phi, y, P, (int)B, phi_shared));
     } else {
         int64_t sp, sb; strides(layout, P, B, sp, sb);
         hipLaunchKernelGGL(generic_kernel<OP_FORWARD>, dim3(ceil_div(P, TB), bsz), dim3(TB), 0, st, x, phi, nullptr, nullptr, y, P, (int)B, sp, sb, sp, sb, phi_shared);
@@ -438,10 +450,11 @@ int deqsci_sci_adjoint_f32(const float* y, const float* phi, float* x, int64_t b
     if (!aligned16(x) || !aligned16(phi) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
+    const int pol = pick_policy(bsz * P * (8 * B + 4), POL_NTLS);
     if (layout == DEQSCI_LAYOUT_HWB && lp_ok(B)) {
-        LP_DISPATCH(B, hipLaunchKernelGGL(adjoint_hwb_kernel<LP>, dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, y, phi, x, P, phi_shared));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((adjoint_hwb_kernel<LP, POL>), dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, y, phi, x, P, phi_shared)));
     } else if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0) {
-        hipLaunchKernelGGL(adjoint_bhw_kernel, dim3(ceil_div(P / 4, TB), bsz), dim3(TB), 0, st, y, phi, x, P, (int)B, phi_shared);
+        POL_DISPATCH(pol, hipLaunchKernelGGL(adjoint_bhw_kernel<POL>, dim3(ceil_div(P / 4, TB), bsz), dim3(TB), 0, st, y, phi, x, P, (int)B, phi_shared));
     } else {
         int64_t sp, sb; strides(layout, P, B, sp, sb);
         hipLaunchKernelGGL(generic_kernel<OP_ADJOINT>, dim3(ceil_div(P, TB), bsz), dim3(TB), 0, st, y, phi, nullptr, nullptr, x, P, (int)B, sp, sb, sp, sb, phi_shared);
@@ -456,10 +469,11 @@ int deqsci_phi_sum_f32(const float* phi, float* phisum, int64_t nb, int64_t H, i
     if (!aligned16(phi) || !aligned16(phisum)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
+    const int pol = pick_policy(nb * P * (4 * B + 4), POL_NTLS);
     if (layout == DEQSCI_LAYOUT_HWB && lp_ok(B)) {
-        LP_DISPATCH(B, hipLaunchKernelGGL(phisum_hwb_kernel<LP>, dim3(ceil_div(P * LP, TB * UNR), nb), dim3(TB), 0, st, phi, phisum, P));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((phisum_hwb_kernel<LP, POL>), dim3(ceil_div(P * LP, TB * UNR), nb), dim3(TB), 0, st, phi, phisum, P)));
     } else if (layout == DEQSCI_LAYOUT_BHW && P % 4 == 0) {
-        hipLaunchKernelGGL(phisum_bhw_kernel, dim3(ceil_div(P / 4, TB), nb), dim3(TB), 0, st, phi, phisum, P, (int)B);
+        POL_DISPATCH(pol, hipLaunchKernelGGL(phisum_bhw_kernel<POL>, dim3(ceil_div(P / 4, TB), nb), dim3(TB), 0, st, phi, phisum, P, (int)B));
     } else {
         int64_t sp, sb; strides(layout, P, B, sp, sb);
         hipLaunchKernelGGL(generic_kernel<OP_PHISUM>, dim3(ceil_div(P, TB), nb), dim3(TB), 0, st, phi, nullptr, nullptr, nullptr, phisum, P, (int)B, sp, sb, sp, sb, 0);
@@ -477,15 +491,16 @@ int deqsci_gap_update_f32(const float* z, const float* phi, const float* y, cons
     if (layout_in != layout_out && z == z1) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
+    const int pol = pick_policy(bsz * P * (12 * B + 8), POL_NTLS);
     if (layout_in == DEQSCI_LAYOUT_HWB && layout_out == DEQSCI_LAYOUT_HWB && lp_ok(B)) {
-        LP_DISPATCH(B, hipLaunchKernelGGL(gap_hwb_kernel<LP>, dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((gap_hwb_kernel<LP, POL>), dim3(ceil_div(P * LP, TB * UNR), bsz), dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared)));
     } else if (layout_in == DEQSCI_LAYOUT_BHW && layout_out == DEQSCI_LAYOUT_BHW && P % 4 == 0 && (B == 4 || B == 8 || B == 16)) {
         const dim3 grid(ceil_div(P / 4, TB), bsz);
-        if (B == 4) hipLaunchKernelGGL(gap_bhw_kernel<4>, grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared);
-        else if (B == 8) hipLaunchKernelGGL(gap_bhw_kernel<8>, grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared);
-        else hipLaunchKernelGGL(gap_bhw_kernel<16>, grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared);
+        if (B == 4) { POL_DISPATCH(pol, hipLaunchKernelGGL((gap_bhw_kernel<4, POL>), grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared)); }
+        else if (B == 8) { POL_DISPATCH(pol, hipLaunchKernelGGL((gap_bhw_kernel<8, POL>), grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared)); }
+        else { POL_DISPATCH(pol, hipLaunchKernelGGL((gap_bhw_kernel<16, POL>), grid, dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared)); }
     } else if (layout_in == DEQSCI_LAYOUT_HWB && layout_out == DEQSCI_LAYOUT_BHW && lp_ok(B) && P % 4 == 0) {
-        LP_DISPATCH(B, hipLaunchKernelGGL(gap_hwb2bhw_kernel<LP>, dim3(ceil_div(P, TP), bsz), dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((gap_hwb2bhw_kernel<LP, POL>), dim3(ceil_div(P, TP), bsz), dim3(TB), 0, st, z, phi, y, phisum, z1, P, phi_shared)));
     } else {
         int64_t isp, isb, osp, osb;
         strides(layout_in, P, B, isp, isb);
@@ -504,11 +519,12 @@ int deqsci_transpose_f32(const float* in, float* out, int64_t bsz, int64_t H, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
     const dim3 grid(ceil_div(P, TP), bsz);
+    const int pol = pick_policy(bsz * P * 8 * B, POL_NTLS);
     if (lp_ok(B) && P % 4 == 0) {
         if (to_layout == DEQSCI_LAYOUT_BHW) {
-            LP_DISPATCH(B, hipLaunchKernelGGL(transpose_hwb2bhw_kernel<LP>, grid, dim3(TB), 0, st, in, out, P));
+            POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((transpose_hwb2bhw_kernel<LP, POL>), grid, dim3(TB), 0, st, in, out, P)));
         } else {
-            LP_DISPATCH(B, hipLaunchKernelGGL(residual_out_bhw2hwb_kernel<LP>, grid, dim3(TB), 0, st, in, (const float*)nullptr, out, P));
+            POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((residual_out_bhw2hwb_kernel<LP, POL>), grid, dim3(TB), 0, st, in, (const float*)nullptr, out, P)));
         }
     } else {
         const size_t lds = (size_t)B * (TP + 1) * sizeof(float);
@@ -530,12 +546,13 @@ int deqsci_residual_out_f32(const float* z1, const float* noise, float* out, int
     if (!aligned16(z1) || !aligned16(noise) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t P = H * W;
+    const int pol = pick_policy(bsz * P * 12 * B, POL_NTLS);
     if (layout_out == DEQSCI_LAYOUT_BHW) {
         const int64_t total = bsz * P * B, n4 = total / 4;
-        hipLaunchKernelGGL(sub_flat_kernel, dim3(ceil_div(n4 > 0 ? n4 : 1, TB)), dim3(TB), 0, st, z1, noise, out, n4, n4 * 4, total);
+        POL_DISPATCH(pol, hipLaunchKernelGGL(sub_flat_kernel<POL>, dim3(ceil_div(n4 > 0 ? n4 : 1, TB)), dim3(TB), 0, st, z1, noise, out, n4, n4 * 4, total));
     } else if (lp_ok(B) && P % 4 == 0) {
         if (out == z1 || out == noise) return DEQSCI_ERR_UNSUPPORTED;
-        LP_DISPATCH(B, hipLaunchKernelGGL(residual_out_bhw2hwb_kernel<LP>, dim3(ceil_div(P, TP), bsz), dim3(TB), 0, st, z1, noise, out, P));
+        POL_DISPATCH(pol, LP_DISPATCH(B, hipLaunchKernelGGL((residual_out_bhw2hwb_kernel<LP, POL>), dim3(ceil_div(P, TP), bsz), dim3(TB), 0, st, z1, noise, out, P)));
     } else {
         return DEQSCI_ERR_UNSUPPORTED;   // caller composes sub (BHW) + deqsci_transpose_f32
     }

@@ -56,7 +56,7 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True, channels_last=False, fused_epilogue=True):
+    def __init__(self, net, fold_bn=True, channels_last=True, fused_epilogue=True):
         self.net = net
         self.channels_last = channels_last
         self.fused_epilogue = fused_epilogue
@@ -137,7 +137,7 @@ class _Denoiser:
 
 class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
-                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=False, fused_epilogue=True):
+                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=True, fused_epilogue=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue)

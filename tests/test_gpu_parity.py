@@ -318,3 +318,44 @@ def test_engine_early_stop_matches_oracle_semantics():
         assert n_loop < 40
         assert eng.last_info["f_calls"] == n_loop + 1, (iterator, eng.last_info, n_loop)
         assert rel_l2(got.cpu().numpy(), want.numpy()) < 1e-5
+
+
+# ----------------------------------------------------------------------------- denoiser epilogue + engine variants
+@pytest.mark.parametrize("shape", [(3, 64, 8, 12), (2, 4, 6, 6), (5, 8, 16, 4)])
+def test_bias_relu_epilogue_vs_torch(shape):
+    g = torch.Generator(device=DEV).manual_seed(7)
+    h = torch.randn(shape, device=DEV, generator=g)
+    b = torch.randn(shape[1], device=DEV, generator=g)
+    want = torch.relu(h + b.view(1, -1, 1, 1))
+    assert torch.equal(_hip.bias_relu_(h.clone(), b), want)
+    assert torch.equal(_hip.bias_relu_(h.clone(), b, relu=False), h + b.view(1, -1, 1, 1))
+    hc = h.clone().contiguous(memory_format=torch.channels_last)
+    out = _hip.bias_relu_(hc, b)
+    assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, want)
+
+
+@pytest.mark.parametrize("channels_last,fused", [(False, True), (True, True), (True, False), (False, False)])
+def test_engine_ffdnet_variants_vs_reference(channels_last, fused):
+    """Every denoiser fast-path variant of the engine holds the same end-to-end gates:
+    FFDNet Anderson@30 and the 12-call trace, <= 1e-4."""
+    recs = np.load(os.path.join(GOLDEN, "e2e_ffdnet_anderson_30_rec.npz"))
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"][None, ..., 0].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 30)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=30, channels_last=channels_last, fused_epilogue=fused)
+    rec = eng.reconstruct(y, Phi).cpu().numpy()
+    assert rel_l2(rec, recs["traffic_m0"]) < 1e-4
+    g = np.load(os.path.join(GOLDEN, "trace_ffdnet.npz"))
+    eng10 = DEQSCIEngine(net, max_iter=10, channels_last=channels_last, fused_epilogue=fused)
+    rec = eng10.reconstruct(G(g["y"]), G(g["Phi"]), G(g["Phi_sum"]), initial_point=G(g["x0"]))
+    assert rel_l2(rec.cpu().numpy(), g["rec"]) < 1e-4
+
+
+def test_engine_ffdnet_picard_180_channels_last():
+    recs = np.load(os.path.join(GOLDEN, "e2e_ffdnet_picard_180_first_rec.npz"))
+    d = _clip("traffic_cacti.mat")
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
+    eng = DEQSCIEngine(net, iterator="picard", max_iter=180, channels_last=True)
+    rec = eng.reconstruct(d["meas"][None, ..., 0].contiguous().to(DEV), d["mask"][None].to(DEV)).cpu().numpy()
+    assert rel_l2(rec, recs["traffic_m0"]) < 1e-4
