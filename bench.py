@@ -111,7 +111,7 @@ def main():
                          checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
     net = net.to(dev)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
-                       channels_last=not args.no_channels_last, fused_epilogue=not args.no_fused_epilogue)
+                       channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue)
     y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
     gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
 

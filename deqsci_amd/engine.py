@@ -56,9 +56,12 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True, channels_last=True, fused_epilogue=True):
+    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True):
+        from .networks import FFDNet
         self.net = net
-        self.channels_last = channels_last
+        # measured on MI355X (profiles/r01_denoiser_variants.jsonl): MIOpen's fp32 Winograd is 8 % faster in
+        # channels_last for FFDNet's 128x128x64 layers and 11 % slower for SimpleCNN's 256x256x64 ones
+        self.channels_last = isinstance(net, FFDNet) if channels_last is None else bool(channels_last)
         self.fused_epilogue = fused_epilogue
         self.tag = getattr(net, "tag", None)
         if self.tag not in ("conv2d", "conv3d", "ffdnet", "denoiser", "3d_denoiser"):
@@ -82,12 +85,19 @@ class _Denoiser:
             return
         self._wkey = key
         self.fast = None
+        from .networks import DnCNN
+        seq = None
         if isinstance(net, FFDNet) and not net.training and net.num_input_channels == 1 and self.fold_bn:
-            mods = list(net.intermediate_dncnn.itermediate_dncnn)
+            seq = net.intermediate_dncnn.itermediate_dncnn
+        elif isinstance(net, DnCNN) and not net.training and self.fold_bn and all(
+                isinstance(mod, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU)) for mod in net.dncnn):
+            seq = net.dncnn                       # SimpleCNN / DnCNN-17: conv [+BN] + ReLU blocks
+        if seq is not None:
+            mods = list(seq)
             layers, i = [], 0
             while i < len(mods):
                 conv = mods[i]
-                assert isinstance(conv, torch.nn.Conv2d)
+                assert isinstance(conv, torch.nn.Conv2d) and conv.bias is None
                 w, b = conv.weight.detach(), None
                 i += 1
                 if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm2d):
@@ -99,6 +109,20 @@ class _Denoiser:
                 w = w.contiguous(memory_format=torch.channels_last) if self.channels_last else w.contiguous()
                 layers.append((w, b, relu))
             self.fast = layers
+
+    def _run_stack(self, h):
+        if self.channels_last:
+            h = h.contiguous(memory_format=torch.channels_last)
+        fused = self.fused_epilogue and h.is_cuda
+        for w, b, relu in self.fast:
+            if fused and b is not None:
+                # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
+                h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
+            else:
+                h = F.conv2d(h, w, b, padding=1)
+                if relu:
+                    h = F.relu_(h)
+        return h
 
     def prepare(self, n_calls, device):
         self._refresh()
@@ -112,22 +136,14 @@ class _Denoiser:
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
                 h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
-                if self.channels_last:
-                    h = h.contiguous(memory_format=torch.channels_last)
-                fused = self.fused_epilogue and h.is_cuda
-                for w, b, relu in self.fast:
-                    if fused and b is not None:
-                        # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
-                        h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
-                    else:
-                        h = F.conv2d(h, w, b, padding=1)
-                        if relu:
-                            h = F.relu_(h)
+                h = self._run_stack(h)
                 out = F.pixel_shuffle(h, 2)
             else:
                 out = self.net(x, sig)
             return out.reshape(bsz, B, H, W), True
         if self.tag == "denoiser":
+            if self.fast is not None:
+                return self._run_stack(x).reshape(bsz, B, H, W), True
             return self.net(x).reshape(bsz, B, H, W), True
         if self.tag == "conv2d":
             return self.net(x).reshape(bsz, B, H, W), False
@@ -137,7 +153,7 @@ class _Denoiser:
 
 class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
-                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=True, fused_epilogue=True):
+                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue)

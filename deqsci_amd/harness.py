@@ -61,9 +61,11 @@ def write_png(path, img):
 
 
 def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, verbose=True, save_image=True,
-                    device="cuda", records=None):
+                    device="cuda", records=None, batch_measurements=False):
     """Per clip: Phi_sum; drop*/runner* keep measurement 0; per measurement x0 = At(y,Phi), DEQ forward,
-    PSNR; clip mean; grand mean.  Returns (avg_psnr, {png_path: HxWx1 float image})."""
+    PSNR; clip mean; grand mean.  Returns (avg_psnr, {png_path: HxWx1 float image}).
+    batch_measurements=True (not in the reference) hands all measurements of a clip to the solver as ONE
+    batch sharing the clip's mask; identical results unless the whole-batch tolerance test fires."""
     all_images = {}
     psnr_sum_for_avg, num_for_avg = 0, 0
     for sample_batch in test_dataloader:
@@ -76,12 +78,21 @@ def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, ve
             y_batch = y_batch[:, :, :, 0].unsqueeze(3)
         psnr_sum = 0
         bsz, h, w, f = y_batch.shape
+        batched = None
+        if batch_measurements and f > 1:
+            yb = y_batch[0].permute(2, 0, 1).contiguous()
+            with torch.no_grad():
+                x0 = operators.initial_point(yb, Phi, Phi_sum, gt_batch)
+            batched = deep_eq_module.forward(yb, Phi, Phi_sum, initial_point=x0, train_flag=False)
         for fi in range(f):
             gt = gt_batch[:, :, :, fi * 8:(fi + 1) * 8]
             y = y_batch[:, :, :, fi].contiguous()
-            with torch.no_grad():
-                initial_point = operators.initial_point(y, Phi, Phi_sum, gt_batch)
-            reconstruction = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=initial_point, train_flag=False)
+            if batched is not None:
+                reconstruction = batched[fi:fi + 1]
+            else:
+                with torch.no_grad():
+                    initial_point = operators.initial_point(y, Phi, Phi_sum, gt_batch)
+                reconstruction = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=initial_point, train_flag=False)
             rec_np = reconstruction.clip(0, 1).cpu().detach().numpy()
             PSNR = psnr(rec_np, gt.cpu().numpy())
             if records is not None:

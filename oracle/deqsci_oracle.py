@@ -151,10 +151,14 @@ class ProxGradSCI:
 
 
 # ----------------------------------------------------------------------------- fixed-point drivers
-def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
+def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, gram_dtype=None):
     """Anderson acceleration exactly as solvers/new_equilibrium_utils_yaping.py:153-189:
     slot k % m, Gram over the first n=min(k,m) slots, bordered (n+1) system, returns the
-    last INPUT to f and the last relative residual (global over the batch)."""
+    last INPUT to f and the last relative residual (global over the batch).
+    gram_dtype=torch.float64 (NOT the reference's behaviour) accumulates G G^T exactly: the reference's
+    fp32 `torch.bmm` over N = H*W*B terms carries ~sqrt(N)*eps relative error (2.6e-4 on a Gram entry at
+    512x512x16, tests/test_oracle_golden.py), which the HIP path - fp64 finish of fp32 partials - does
+    not reproduce; large-N parity tests compare against this exact-Gram form."""
     bsz = x0.shape[0]
     N = x0[0].numel()
     X = torch.zeros(bsz, m, N, dtype=x0.dtype)
@@ -173,7 +177,11 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
         last = k
         n = min(k, m)
         G = Fh[:, :n] - X[:, :n]
-        Hm[:, 1:n + 1, 1:n + 1] = torch.bmm(G, G.transpose(1, 2)) + lam * torch.eye(n, dtype=x0.dtype)[None]
+        if gram_dtype is None:
+            gram = torch.bmm(G, G.transpose(1, 2))
+        else:
+            gram = torch.bmm(G.to(gram_dtype), G.to(gram_dtype).transpose(1, 2)).to(x0.dtype)
+        Hm[:, 1:n + 1, 1:n + 1] = gram + lam * torch.eye(n, dtype=x0.dtype)[None]
         alpha = torch.linalg.solve(Hm[:, :n + 1, :n + 1], rhs[:, :n + 1])[:, 1:n + 1, 0]
         X[:, k % m] = beta * (alpha[:, None] @ Fh[:, :n])[:, 0] + (1 - beta) * (alpha[:, None] @ X[:, :n])[:, 0]
         Fh[:, k % m] = f(X[:, k % m].reshape(x0.shape)).reshape(bsz, -1)
