@@ -182,7 +182,7 @@ def main():
                         k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
                         if rec["bsz"] == bsz and rec["size"] == args.size and k:
                             traffic = k["hbm_bytes_per_launch"]
-            out["roofline"] = {"kernel": f"mix_gap_bhw_kernel<{B}> (K7+K3: Anderson mix + Phi/Phi^T GAP update)",
+            out["roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}, 3> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update)",
                                "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms)}

@@ -14,8 +14,10 @@ from collections import defaultdict
 
 def short(name):
     m = re.search(r"deqsci::(\w+)(<[^>]*>)?", name)
-    if m:
-        return m.group(1) + (m.group(2) or "")
+    if m:                                     # template args: <shape, cache policy> -> keep the shape argument only
+        arg = m.group(2) or ""
+        first = arg.strip("<>").split(",")[0].strip() if arg else ""
+        return m.group(1) + (f"<{first}>" if first and m.group(1) not in ("forward_bhw_kernel", "adjoint_bhw_kernel", "phisum_bhw_kernel", "sub_flat_kernel", "mix_kernel") else "")
     return None
 
 
