@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=28)
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--no-fused-epilogue", action="store_true")
+    ap.add_argument("--no-fused-edges", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -104,6 +105,8 @@ def main():
     from deqsci_amd.cli import build_denoiser
     from deqsci_amd.engine import DEQSCIEngine
 
+    # MIOpen find mode (cudnn.benchmark) is deliberately left off: on this conv it picks a slower igemm tile
+    # (642 us vs 579 us) and writes that choice into the user find-db (measured, tools/gpu_12.sh).
     H, W, B = (int(v) for v in args.size.split("x"))
     bsz = args.batch_per_gpu
     net = build_denoiser(args.denoiser).eval()
@@ -111,7 +114,8 @@ def main():
                          checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
     net = net.to(dev)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
-                       channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue)
+                       channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
+                       fused_edges=not args.no_fused_edges)
     y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
     gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
 

@@ -35,6 +35,8 @@ SIGNATURES = {
     "deqsci_anderson_mix_gap_timed_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                           _i64, _i64, _i64, _i64, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_bias_relu_f32": [_ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr],
+    "deqsci_ffdnet_tail_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_ffdnet_head_f32": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -283,6 +285,51 @@ def bias_relu_(h, bias, relu=True):
         _check(load().deqsci_bias_relu_f32(h.data_ptr(), _p(bias, "bias"), n, c, hh * ww, cl, 1 if relu else 0, _stream()),
                "bias_relu")
     return h
+
+
+def pack_tail_weights(w):
+    """(4,64,3,3) conv weight -> [half(2)][tap(9)][cin(32)][cout(4)] for deqsci_ffdnet_tail_f32."""
+    if tuple(w.shape) != (4, 64, 3, 3):
+        raise DeqsciHipError(f"ffdnet tail expects a (4,64,3,3) weight, got {tuple(w.shape)}")
+    return w.detach().float().permute(2, 3, 1, 0).reshape(9, 2, 32, 4).permute(1, 0, 2, 3).contiguous()
+
+
+def ffdnet_tail(h, w_packed, out=None, in_bias=None):
+    """h (n,64,H,W) channels_last -> planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h', w, pad=1), 2) with
+    h' = h, or relu(h + in_bias[c]) when in_bias is given (previous layer's epilogue fused into the read)."""
+    n, c, H, W = h.shape
+    if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
+        raise DeqsciHipError("ffdnet_tail: fp32 channels_last GPU activation with 64 channels required")
+    o = out if out is not None else torch.empty((n, 1, 2 * H, 2 * W), device=h.device, dtype=torch.float32)
+    with _dev(h):
+        _check(load().deqsci_ffdnet_tail_f32(h.data_ptr(), _p(w_packed, "w_packed"), _p(in_bias, "in_bias", True), _p(o, "out"),
+                                             n, H, W, _stream()), "ffdnet_tail")
+    return o
+
+
+def pack_head_weights(w):
+    """(64,5,3,3) conv weight -> [ch*9+tap (45)][cout//4 (16)][cout%4 (4)] for deqsci_ffdnet_head_f32."""
+    if tuple(w.shape) != (64, 5, 3, 3):
+        raise DeqsciHipError(f"ffdnet head expects a (64,5,3,3) weight, got {tuple(w.shape)}")
+    return w.detach().float().reshape(16, 4, 45).permute(2, 0, 1).contiguous()
+
+
+def ffdnet_head(x, w_packed, sigma, out=None):
+    """x (n,1,2H,2W) planar, sigma (n,) or (1,) -> relu(conv3x3(cat(sigma map, pixel_unshuffle(x,2)), w)) as a
+    channels_last (n,64,H,W) activation."""
+    n, c, H2, W2 = x.shape
+    if c != 1 or H2 % 2 or W2 % 2:
+        raise DeqsciHipError(f"ffdnet_head: (n,1,even,even) image required, got {tuple(x.shape)}")
+    if sigma.numel() not in (1, n) or sigma.dtype != torch.float32 or not sigma.is_cuda:
+        raise DeqsciHipError("ffdnet_head: sigma must be a fp32 GPU tensor with 1 or n elements")
+    H, W = H2 // 2, W2 // 2
+    o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32,
+                                                  memory_format=torch.channels_last)
+    with _dev(x):
+        _check(load().deqsci_ffdnet_head_f32(_p(x, "x"), _p(w_packed, "w_packed"), sigma.data_ptr(),
+                                             0 if sigma.numel() == 1 else sigma.stride(0), o.data_ptr(), n, H, W, _stream()),
+               "ffdnet_head")
+    return o
 
 
 # ----------------------------------------------------------------------------- measurement helpers (bench.py)

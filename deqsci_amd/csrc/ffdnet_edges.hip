@@ -1,0 +1,167 @@
+// FFDNet edge layers fused with the reference's hand-written layout layers (networks/ffdnet/functions.py):
+//
+//   tail: conv3x3(64 -> 4, pad 1, no bias) + upsamplefeatures (functions.py:62-81, = pixel_shuffle 2)
+//         reading the channels_last activation once and writing the planar full-resolution noise image.
+//         MIOpen runs this 4-output-channel layer as a 64x16-tile implicit GEMM (424 us at 64 images of
+//         128x128x64, plus a 32 us zero-fill and a 10 us shuffle copy); it is 4.8 GFLOP over 268 MB, i.e.
+//         a VALU/HBM-balanced stencil, not a GEMM.
+//
+// Mapping (tail): block = 8 x 32 half-resolution positions, one lane per position, 4 accumulators (the 2x2
+// output pixels).  The 64 input channels are staged through LDS in two halves of 32 ([10 x 34 pixels][32+4]
+// floats = 49 KB -> 3 blocks per CU); the +4 pad makes the per-lane ds_read_b128 conflict-free.  Weights are
+// wave-uniform and pre-packed [half][tap][cin][cout], so they come through the scalar cache (s_load) and
+// every v_fma takes its weight from an SGPR: 144 ds_read_b128 feed 2304 FMAs per lane.
+#include "common.hpp"
+
+namespace deqsci {
+
+constexpr int TT_H = 8, TT_W = 32;                 // output tile (half-res positions)
+constexpr int TT_IW = TT_W + 2, TT_IH = TT_H + 2;  // input tile with halo
+constexpr int TT_CH = 32;                          // channels per LDS pass
+constexpr int TT_PS = TT_CH + 4;                   // LDS pixel stride (floats)
+
+__global__ __launch_bounds__(TB) void ffdnet_tail_kernel(const float* __restrict__ h, const float* __restrict__ wp,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float tile[TT_IH * TT_IW * TT_PS];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * TT_H, c0 = blockIdx.x * TT_W;
+    const int lr = threadIdx.x / TT_W, lc = threadIdx.x % TT_W;
+    const float* hn = h + (int64_t)n * H * W * 64;
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        // stage [TT_IH][TT_IW][32] (zero outside the image): 8 float4 per pixel
+        for (int e = threadIdx.x; e < TT_IH * TT_IW * (TT_CH / 4); e += TB) {
+            const int pix = e / (TT_CH / 4), q = e % (TT_CH / 4);
+            const int pr = pix / TT_IW, pc = pix % TT_IW;
+            const int gr = r0 + pr - 1, gc = c0 + pc - 1;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
+                v = ld4(hn + ((int64_t)gr * W + gc) * 64 + half * TT_CH + 4 * q);
+                if (bias) {      // the previous layer's folded-BN bias + ReLU applied on the way in (padding stays 0)
+                    const float4 b = ld4(bias + half * TT_CH + 4 * q);
+                    v.x = fmaxf(v.x + b.x, 0.0f); v.y = fmaxf(v.y + b.y, 0.0f); v.z = fmaxf(v.z + b.z, 0.0f); v.w = fmaxf(v.w + b.w, 0.0f);
+                }
+            }
+            *reinterpret_cast<float4*>(tile + pix * TT_PS + 4 * q) = v;
+        }
+        __syncthreads();
+        const float* wh = wp + half * 9 * TT_CH * 4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const float* tp = tile + ((lr + tap / 3) * TT_IW + (lc + tap % 3)) * TT_PS;
+            const float* wt = wh + tap * TT_CH * 4;
+#pragma unroll
+            for (int c4 = 0; c4 < TT_CH / 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(tp + 4 * c4);
+                const float* w = wt + c4 * 16;
+                acc0 = fmaf(v.x, w[0], acc0);  acc1 = fmaf(v.x, w[1], acc1);  acc2 = fmaf(v.x, w[2], acc2);  acc3 = fmaf(v.x, w[3], acc3);
+                acc0 = fmaf(v.y, w[4], acc0);  acc1 = fmaf(v.y, w[5], acc1);  acc2 = fmaf(v.y, w[6], acc2);  acc3 = fmaf(v.y, w[7], acc3);
+                acc0 = fmaf(v.z, w[8], acc0);  acc1 = fmaf(v.z, w[9], acc1);  acc2 = fmaf(v.z, w[10], acc2); acc3 = fmaf(v.z, w[11], acc3);
+                acc0 = fmaf(v.w, w[12], acc0); acc1 = fmaf(v.w, w[13], acc1); acc2 = fmaf(v.w, w[14], acc2); acc3 = fmaf(v.w, w[15], acc3);
+            }
+        }
+        __syncthreads();
+    }
+    const int r = r0 + lr, c = c0 + lc;
+    if (r < H && c < W) {       // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
+        float* o = out + (int64_t)n * 4 * H * W + (int64_t)(2 * r) * (2 * W) + 2 * c;
+        *reinterpret_cast<float2*>(o) = make_float2(acc0, acc1);
+        *reinterpret_cast<float2*>(o + 2 * W) = make_float2(acc2, acc3);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: concatenate_input_noise_map (functions.py:16-53: sigma map + 2x2 pixel-unshuffle, channel 2i+j)
+//       + conv3x3(5 -> 64, pad 1, no bias) + ReLU, reading the planar full-resolution image and writing the
+//       channels_last (n,H,W,64) activation once.  PyTorch runs cat, unshuffle, a layout copy, MIOpen's
+//       zero-fill + conv and a ReLU sweep for this (~250 us at 64 images); it is 6 GFLOP and one 268 MB write.
+// Mapping: 16 lanes per output position, each owning 4 output channels with their 4 x 45 weights resident in
+// VGPRs for the whole 32 x 32-position tile; a wavefront handles 4 neighbouring positions, so its store is one
+// contiguous 1 KiB.  The 68 x 68 full-resolution patch sits in LDS (zero outside the image = the conv's zero
+// padding of the unshuffled channels); the 16 lanes of a position read it by broadcast.
+constexpr int HD_T = 32;                      // tile side in half-res positions
+constexpr int HD_P = 2 * HD_T + 4;            // patch side in full-res pixels
+constexpr int HD_PS = HD_P + 2;               // LDS row stride (even: float2 reads stay 8-B aligned)
+
+__global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                         const float* __restrict__ sigma, int sigma_stride,
+                                                         float* __restrict__ h, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float patch[HD_P * HD_PS];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * HD_T, c0 = blockIdx.x * HD_T;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* xn = x + (int64_t)n * H2 * W2;
+    for (int e = threadIdx.x; e < HD_P * HD_P; e += TB) {
+        const int pr = e / HD_P, pc = e % HD_P;
+        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
+        patch[pr * HD_PS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
+    }
+    const int cq = threadIdx.x % 16, slot = threadIdx.x / 16;
+    float4 wr[45];                                  // [ch*9 + tap] -> 4 output channels 4cq..4cq+3
+#pragma unroll
+    for (int k = 0; k < 45; ++k) wr[k] = ld4(wq + (k * 16 + cq) * 4);
+    const float sig = sigma[(int64_t)n * sigma_stride];
+    __syncthreads();
+    float* hn = h + (int64_t)n * H * W * 64;
+#pragma unroll 1
+    for (int it = 0; it < HD_T * HD_T / 16; ++it) {
+        const int q = it * 16 + slot;
+        const int lr = q / HD_T, lc = q % HD_T;
+        const int r = r0 + lr, c = c0 + lc;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {         // channel 0: the sigma map, zero in the conv's padding ring
+            const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
+            const float sv = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+            acc = fma4(sv, wr[tap], acc);
+        }
+#pragma unroll
+        for (int prow = 0; prow < 6; ++prow) {      // full-res rows 2r-2 .. 2r+3: dr = prow/2 - 1, i = prow%2
+            const float* pp = patch + (2 * lr + prow) * HD_PS + 2 * lc;
+            const float2 a = *reinterpret_cast<const float2*>(pp);
+            const float2 b = *reinterpret_cast<const float2*>(pp + 2);
+            const float2 d = *reinterpret_cast<const float2*>(pp + 4);
+            const float v[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
+#pragma unroll
+            for (int pcol = 0; pcol < 6; ++pcol) {  // dc = pcol/2 - 1, j = pcol%2
+                const int ch = 1 + 2 * (prow % 2) + (pcol % 2);
+                const int tap = (prow / 2) * 3 + (pcol / 2);
+                acc = fma4(v[pcol], wr[ch * 9 + tap], acc);
+            }
+        }
+        if (r < H && c < W) {
+            acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f);
+            st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
+        }
+    }
+}
+
+}  // namespace deqsci
+
+using namespace deqsci;
+
+extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, float* h,
+                                      int64_t n, int64_t H, int64_t W, deqsci_stream_t stream) {
+    if (!x || !w_packed || !sigma || !h) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)ceil_div(W, HD_T), (unsigned)ceil_div(H, HD_T), (unsigned)n);
+    hipLaunchKernelGGL(ffdnet_head_kernel, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
+    return launch_status();
+}
+
+extern "C" int deqsci_ffdnet_tail_f32(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n, int64_t H,
+                                      int64_t W, deqsci_stream_t stream) {
+    if (!h || !w_packed || !out) return DEQSCI_ERR_NULL;
+    if (in_bias && !aligned16(in_bias)) return DEQSCI_ERR_ALIGN;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(h) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)ceil_div(W, TT_W), (unsigned)ceil_div(H, TT_H), (unsigned)n);
+    hipLaunchKernelGGL(ffdnet_tail_kernel, grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
+    return launch_status();
+}

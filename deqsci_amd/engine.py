@@ -56,9 +56,10 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True):
+    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True):
         from .networks import FFDNet
         self.net = net
+        self.fused_edges = fused_edges
         # measured on MI355X (profiles/r01_denoiser_variants.jsonl): MIOpen's fp32 Winograd is 8 % faster in
         # channels_last for FFDNet's 128x128x64 layers and 11 % slower for SimpleCNN's 256x256x64 ones
         self.channels_last = isinstance(net, FFDNet) if channels_last is None else bool(channels_last)
@@ -85,6 +86,7 @@ class _Denoiser:
             return
         self._wkey = key
         self.fast = None
+        self.tail_w = self.head_w = None
         from .networks import DnCNN
         seq = None
         if isinstance(net, FFDNet) and not net.training and net.num_input_channels == 1 and self.fold_bn:
@@ -109,12 +111,31 @@ class _Denoiser:
                 w = w.contiguous(memory_format=torch.channels_last) if self.channels_last else w.contiguous()
                 layers.append((w, b, relu))
             self.fast = layers
+            self.tail_w = self.head_w = None
+            if (isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[-1][1] is None
+                    and not layers[-1][2] and tuple(layers[-1][0].shape) == (4, 64, 3, 3) and layers[-1][0].is_cuda):
+                # last layer + upsamplefeatures as one HIP stencil kernel (csrc/ffdnet_edges.hip)
+                self.tail_w = _hip.pack_tail_weights(layers[-1][0])
+                if layers[0][1] is None and layers[0][2] and tuple(layers[0][0].shape) == (64, 5, 3, 3):
+                    # concatenate_input_noise_map + first conv + ReLU likewise
+                    self.head_w = _hip.pack_head_weights(layers[0][0])
 
-    def _run_stack(self, h):
+    def _run_stack(self, h, skip_last=False, skip_first=False, defer_last_epilogue=False):
+        """defer_last_epilogue: leave the bias+ReLU of the last executed layer to the consumer (the fused
+        FFDNet tail applies it while staging its input) and return (raw conv output, bias)."""
         if self.channels_last:
             h = h.contiguous(memory_format=torch.channels_last)
         fused = self.fused_epilogue and h.is_cuda
-        for w, b, relu in self.fast:
+        todo = self.fast[(1 if skip_first else 0):(-1 if skip_last else None)]
+        if defer_last_epilogue:
+            w, b, relu = todo[-1]
+            assert b is not None and relu
+            return F.conv2d(self._run_layers(h, todo[:-1], fused), w, None, padding=1), b
+        return self._run_layers(h, todo, fused)
+
+    @staticmethod
+    def _run_layers(h, layers, fused):
+        for w, b, relu in layers:
             if fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
@@ -135,9 +156,20 @@ class _Denoiser:
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
-                h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
-                h = self._run_stack(h)
-                out = F.pixel_shuffle(h, 2)
+                if self.head_w is not None and x.is_cuda:
+                    h, first_done = _hip.ffdnet_head(x, self.head_w, self.sigma_table[call:call + 1]), True
+                else:
+                    h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
+                    first_done = False
+                if self.tail_w is not None and h.is_cuda:
+                    defer = self.fused_epilogue and self.fast[-2][1] is not None and self.fast[-2][2]
+                    if defer:
+                        raw, b = self._run_stack(h, skip_last=True, skip_first=first_done, defer_last_epilogue=True)
+                        out = _hip.ffdnet_tail(raw, self.tail_w, in_bias=b)
+                    else:
+                        out = _hip.ffdnet_tail(self._run_stack(h, skip_last=True, skip_first=first_done), self.tail_w)
+                else:
+                    out = F.pixel_shuffle(self._run_stack(h, skip_first=first_done), 2)
             else:
                 out = self.net(x, sig)
             return out.reshape(bsz, B, H, W), True
@@ -153,10 +185,12 @@ class _Denoiser:
 
 class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
-                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True):
+                 fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
+                 fused_edges=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
-        self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue)
+        self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
+                             fused_edges=fused_edges)
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
         self.max_iter, self.tol = int(max_iter), float(tol)

@@ -131,6 +131,21 @@ int deqsci_anderson_mix_gap_f32(const float* F_hist, const float* G_hist, const 
 int deqsci_bias_relu_f32(float* h, const float* bias, int64_t n, int64_t c, int64_t hw,
                          int channels_last, int relu, deqsci_stream_t stream);
 
+/* FFDNet tail: conv3x3(64 -> 4, pad 1, no bias) fused with `upsamplefeatures` (networks/ffdnet/functions.py:62-81,
+ *     = pixel_shuffle 2).  h is the channels_last activation (n,H,W,64); w_packed is the (4,64,3,3) weight
+ *     re-ordered [half(2)][tap(9)][cin(32)][cout(4)]; out is the planar (n,1,2H,2W) predicted-noise image.
+ *     in_bias (64 floats, may be NULL): h is the previous layer's RAW conv output and max(h + in_bias[c], 0)
+ *     (its folded BatchNorm bias + ReLU) is applied while the tile is staged - one activation sweep less. */
+int deqsci_ffdnet_tail_f32(const float* h, const float* w_packed, const float* in_bias, float* out,
+                           int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
+
+/* FFDNet head: `concatenate_input_noise_map` (networks/ffdnet/functions.py:16-53: sigma map + 2x2 pixel-unshuffle)
+ *     + conv3x3(5 -> 64, pad 1, no bias) + ReLU.  x is the planar (n,1,2H,2W) image, sigma[i*sigma_stride] the noise
+ *     level of image i (stride 0 = one value for all), w_packed the (64,5,3,3) weight re-ordered
+ *     [ch*9+tap (45)][cout/4 (16)][cout%4 (4)]; h is written as the channels_last (n,H,W,64) activation. */
+int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride,
+                           float* h, int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
+
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
  * without the marker-packet overhead of events recorded around a launch. */

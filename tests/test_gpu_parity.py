@@ -347,8 +347,9 @@ def test_bias_relu_epilogue_vs_torch(shape):
     assert out.is_contiguous(memory_format=torch.channels_last) and torch.equal(out, want)
 
 
-@pytest.mark.parametrize("channels_last,fused", [(False, True), (True, True), (True, False), (False, False)])
-def test_engine_ffdnet_variants_vs_reference(channels_last, fused):
+@pytest.mark.parametrize("channels_last,fused,edges", [(False, True, True), (True, True, True), (True, True, False),
+                                                       (True, False, True), (False, False, False)])
+def test_engine_ffdnet_variants_vs_reference(channels_last, fused, edges):
     """Every denoiser fast-path variant of the engine holds the same end-to-end gates:
     FFDNet Anderson@30 and the 12-call trace, <= 1e-4."""
     recs = np.load(os.path.join(GOLDEN, "e2e_ffdnet_anderson_30_rec.npz"))
@@ -356,11 +357,11 @@ def test_engine_ffdnet_variants_vs_reference(channels_last, fused):
     Phi = d["mask"][None].to(DEV)
     y = d["meas"][None, ..., 0].contiguous().to(DEV)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 30)[0].nonlinear_op
-    eng = DEQSCIEngine(net, max_iter=30, channels_last=channels_last, fused_epilogue=fused)
+    eng = DEQSCIEngine(net, max_iter=30, channels_last=channels_last, fused_epilogue=fused, fused_edges=edges)
     rec = eng.reconstruct(y, Phi).cpu().numpy()
     assert rel_l2(rec, recs["traffic_m0"]) < 1e-4
     g = np.load(os.path.join(GOLDEN, "trace_ffdnet.npz"))
-    eng10 = DEQSCIEngine(net, max_iter=10, channels_last=channels_last, fused_epilogue=fused)
+    eng10 = DEQSCIEngine(net, max_iter=10, channels_last=channels_last, fused_epilogue=fused, fused_edges=edges)
     rec = eng10.reconstruct(G(g["y"]), G(g["Phi"]), G(g["Phi_sum"]), initial_point=G(g["x0"]))
     assert rel_l2(rec.cpu().numpy(), g["rec"]) < 1e-4
 
@@ -397,3 +398,64 @@ def test_engine_512x512x16_vs_oracle():
         assert rel_l2(got, want64.numpy()) < 2e-5
         assert rel_l2(got, want32.numpy()) < 1e-3
         assert abs(eng.last_info["res"] - wres) < 2e-3 * wres and eng.last_info["f_calls"] == 7
+
+
+def test_engine_is_deterministic_and_options():
+    """Reductions are two-stage with fixed order (no atomics on data): two runs are bit-identical; the
+    optional dead f-call and disabling residual polling do not change the result."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"].permute(2, 0, 1)[:2].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 14)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=14)
+    a = eng.reconstruct(y, Phi).clone()
+    info = dict(eng.last_info)
+    b = eng.reconstruct(y, Phi)
+    assert torch.equal(a, b) and eng.last_info["res"] == info["res"] and info["f_calls"] == 15
+    eng2 = DEQSCIEngine(net, max_iter=14, extra_call=True, poll_residual=False)
+    c = eng2.reconstruct(y, Phi)
+    assert torch.equal(a, c) and eng2.last_info["f_calls"] == 16 and eng2.last_info["res"] == info["res"]
+    assert len(info["res_per_sample"]) == 2 and all(r > 0 for r in info["res_per_sample"])
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 32), (2, 13, 37), (1, 128, 128), (5, 8, 64)])
+def test_ffdnet_tail_kernel_vs_torch(shape):
+    """conv3x3(64->4) + pixel_shuffle(2) as one HIP stencil vs F.conv2d + F.pixel_shuffle (incl. ragged tiles)."""
+    import torch.nn.functional as Fn
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(3)
+    h = torch.randn(n, 64, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(4, 64, 3, 3, device=DEV, generator=g) * 0.05
+    want = Fn.pixel_shuffle(Fn.conv2d(h.double(), w.double(), padding=1), 2)
+    got = _hip.ffdnet_tail(h, _hip.pack_tail_weights(w))
+    assert got.shape == (n, 1, 2 * H, 2 * W)
+    ref32 = Fn.pixel_shuffle(Fn.conv2d(h, w, padding=1), 2)
+    e_got = float((got.double() - want).norm() / want.norm())
+    e_ref = float((ref32.double() - want).norm() / want.norm())
+    assert e_got < 1e-6 and e_got < 4 * e_ref + 1e-7
+    # with the previous layer's bias + ReLU folded into the read
+    b = torch.randn(64, device=DEV, generator=g)
+    hb = torch.relu(h + b.view(1, -1, 1, 1))
+    want_b = Fn.pixel_shuffle(Fn.conv2d(hb.double(), w.double(), padding=1), 2)
+    got_b = _hip.ffdnet_tail(h, _hip.pack_tail_weights(w), in_bias=b)
+    assert float((got_b.double() - want_b).norm() / want_b.norm()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96)])
+def test_ffdnet_head_kernel_vs_torch(shape):
+    """sigma map + pixel_unshuffle + conv3x3(5->64) + ReLU as one HIP kernel vs the torch ops (incl. ragged
+    tiles, per-image sigma and the zero-padded sigma ring at the border)."""
+    import torch.nn.functional as Fn
+    n, H2, W2 = shape
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(n, 1, H2, W2, device=DEV, generator=g)
+    w = torch.randn(64, 5, 3, 3, device=DEV, generator=g) * 0.1
+    for sig in (torch.rand(n, device=DEV, generator=g), torch.rand(1, device=DEV, generator=g)):
+        inp = torch.cat((sig.expand(n).view(n, 1, 1, 1).expand(n, 1, H2 // 2, W2 // 2), Fn.pixel_unshuffle(x, 2)), 1)
+        want = torch.relu(Fn.conv2d(inp.double(), w.double(), padding=1))
+        ref32 = torch.relu(Fn.conv2d(inp, w, padding=1))
+        got = _hip.ffdnet_head(x, _hip.pack_head_weights(w), sig)
+        assert got.shape == (n, 64, H2 // 2, W2 // 2) and got.is_contiguous(memory_format=torch.channels_last)
+        e_got = float((got.double() - want).norm() / want.norm())
+        e_ref = float((ref32.double() - want).norm() / want.norm())
+        assert e_got < 1e-6 and e_got < 4 * e_ref + 1e-7
