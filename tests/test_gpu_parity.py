@@ -459,3 +459,47 @@ def test_ffdnet_head_kernel_vs_torch(shape):
         e_got = float((got.double() - want).norm() / want.norm())
         e_ref = float((ref32.double() - want).norm() / want.norm())
         assert e_got < 1e-6 and e_got < 4 * e_ref + 1e-7
+
+
+class _Affine(torch.nn.Module):
+    """Deterministic toy plugin with tag 'denoiser' (predicts noise): used to drive the engine kernels with
+    settings the shipped denoisers never use (m != 5, beta != 1, B = 4 / 16, shared vs per-sample masks)."""
+    tag = "denoiser"
+
+    def forward(self, x):
+        return 0.4 * x - 0.05
+
+
+@pytest.mark.parametrize("cfg", [dict(B=8, m=3, beta=0.7, lam=1e-3, bsz=2, shared=False),
+                                 dict(B=4, m=8, beta=1.0, lam=1e-2, bsz=1, shared=False),
+                                 dict(B=16, m=5, beta=0.5, lam=1e-2, bsz=3, shared=True),
+                                 dict(B=5, m=4, beta=0.9, lam=1e-2, bsz=2, shared=False)])
+def test_engine_anderson_settings_vs_oracle(cfg):
+    """mix_gap with the (1-beta) G term, history depths 3..8, B in {4,5,8,16} (B=5: unfused generic kernels)."""
+    B, bsz = cfg["B"], cfg["bsz"]
+    Phi, Phie, x, z, y, Ps = make_case(bsz, 24, 20, B, seed=B + cfg["m"], shared=cfg["shared"])
+    Pse = Ps.expand(bsz, 24, 20)
+
+    def f_cpu(zz):
+        z1 = orc.gap_update(zz, y, Phie, Pse)
+        return z1 - (0.4 * z1 - 0.05)
+    zs, res = orc.andersonexp(f_cpu, orc.initial_point(y, Phie), m=cfg["m"], lam=cfg["lam"], max_iter=11, tol=1e-9, beta=cfg["beta"])
+    want = f_cpu(zs)
+    eng = DEQSCIEngine(_Affine(), max_iter=11, m=cfg["m"], beta=cfg["beta"], lam=cfg["lam"], tol=1e-9)
+    got = eng.reconstruct(G(y), G(Phi))
+    assert rel_l2(got.cpu().numpy(), want.numpy()) < 2e-5
+    assert abs(eng.last_info["res"] - res) < 2e-2 * res + 1e-9
+
+
+def test_cli_end_to_end(tmp_path):
+    """The reference's test_*.sh usage through the build's CLI: loads the shipped archive, runs the harness over
+    data/test_gray, prints PSNRs and writes the 64 PNGs."""
+    from deqsci_amd.cli import main as cli_main
+    avg = cli_main(["--denoiser", "SimpleCNN", "--testpath", orc.DATA_DIR + "/", "--savepath", str(tmp_path) + "/",
+                    "--and_maxiters", "10", "--inference", "True"])
+    assert abs(avg - _golden_meta("SimpleCNN_anderson_10")["avg_psnr"]) < 0.01
+    pngs = sorted(os.listdir(tmp_path))
+    assert len(pngs) == 64 and "traffic_cacti.mat_reconstruction_47.png" in pngs
+    from PIL import Image
+    im = np.asarray(Image.open(os.path.join(tmp_path, "drop8_cacti.mat_reconstruction_0.png")))
+    assert im.shape == (256, 256) and im.dtype == np.uint8 and im.std() > 5
