@@ -18,9 +18,17 @@ def load_test_data(matfile):
     import scipy.io as sio
     try:
         f = sio.loadmat(matfile)
-    except NotImplementedError as e:                      # MATLAB v7.3 (HDF5): needs h5py, absent here
-        raise NotImplementedError(f"{matfile}: MATLAB v7.3 files need h5py (SURVEY section 8(f-2))") from e
-    return {'gt': np.float32(f['orig']) / 255, 'mask': np.float32(f['mask']), 'meas': np.float32(f['meas']) / 255}
+        meas, mask, orig = np.float32(f['meas']), np.float32(f['mask']), np.float32(f['orig'])
+    except NotImplementedError:                           # MATLAB v7.3 = HDF5, stored in MATLAB (column-major) order
+        try:
+            import h5py
+        except ImportError as e:
+            raise NotImplementedError(f"{matfile}: MATLAB v7.3 files need h5py, which is not installed") from e
+        with h5py.File(matfile, 'r') as f:                # utils/sci_dataloader.py:249-254
+            meas = np.float32(f['meas']).transpose()
+            mask = np.float32(f['mask']).transpose()
+            orig = np.float32(f['orig']).transpose()
+    return {'gt': orig / 255, 'mask': mask, 'meas': meas / 255}
 
 
 def directory_filelist(target_directory):

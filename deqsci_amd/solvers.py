@@ -182,3 +182,73 @@ class DEQFixedPoint(nn.Module):
             z = self.f(z, x, Phi, Phi_sum)
             self.f(z, x, Phi, Phi_sum)      # the reference's f0 = f(z0): advances the sigma state (:271-272)
         return z
+
+
+# ----------------------------------------------------------------------------- ADMM variant
+class EquilibriumADMMSCI(nn.Module):
+    """solvers/equilibrium_solvers_yaping.py:438-465: one ADMM iterate (z,u) -> (z',u').  The projection is
+    the same K3 kernel applied to (z+u) with Phi_sum + 1e-8; the denoiser sees z' - u and returns the CLEAN
+    image (dispatch on `nonlinear_op.conv3d`, as in the reference)."""
+
+    def __init__(self, A, At, nonlinear_operator, eta, minval=-1, maxval=1):
+        super().__init__()
+        self.A, self.At = A, At
+        self.nonlinear_op = nonlinear_operator
+        self.minval, self.maxval = minval, maxval
+
+    def forward(self, z, u, y, Phi, Phi_sum):
+        bsz, w, h, c = z.shape
+        zu = _hip.f32c(z + u)
+        if self.A is A_torch_ and self.At is At_torch_:
+            zp = _hip.gap_update(zu, _hip.f32c(Phi), _hip.f32c(y), _hip.f32c(Phi_sum + 1e-8), LAYOUT_HWB, LAYOUT_BHW)
+        else:
+            fb = self.A(zu, Phi)
+            zp = _hip.transpose(_hip.f32c(zu + self.At((y - fb) / (Phi_sum + 1e-8), Phi)), LAYOUT_BHW)
+        vin = zp - _hip.transpose(_hip.f32c(u), LAYOUT_BHW)
+        if not self.nonlinear_op.conv3d:
+            den = self.nonlinear_op(vin.view(bsz * c, 1, w, h)).reshape(bsz, c, w, h)
+        else:
+            den = self.nonlinear_op(vin.view(bsz, 1, c, w, h)).reshape(bsz, c, w, h)
+        z_new = _hip.transpose(zp, LAYOUT_HWB)
+        u_new = u - _hip.residual_out(zp, _hip.f32c(den), LAYOUT_HWB)          # u - (z - z_tplus1)
+        return z_new, u_new
+
+
+def initial_point_admm(y, Phi, Phi_sum=None, gt=None):
+    """utils/cg_utils.py:238-239."""
+    return [At_torch_(y, Phi), torch.zeros_like(Phi)]
+
+
+def admmexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-2, beta=1.0):
+    """solvers/new_equilibrium_utils_yaping.py:396-413: plain ADMM fixed-point iteration; on convergence the
+    PREVIOUS (X,U) is returned, as in the reference.  m, lam, beta are accepted and unused there too."""
+    X, U = x0[0], x0[1]
+    bsz, N = X.shape[0], X[0].numel()
+    ws = _hip.AndersonWorkspace(bsz, N, 1, X.device)
+    res = None
+    for k in range(2, max_iter):
+        new_X, new_U = f(X, U)
+        _hip.residual_store(ws, _hip.f32c(new_X).reshape(bsz, N), None, _hip.f32c(X).reshape(bsz, N), 0, 1, None)
+        _hip.anderson_solve(ws, 0, 1, 0, 0.0, 1e-5)
+        res = ws.res[0, 0].item()
+        if res < tol:
+            break
+        X, U = new_X, new_U
+    if res is None:
+        raise UnboundLocalError("local variable 'res' referenced before assignment")
+    return X, U, res
+
+
+class DEQFixedPointADMM(nn.Module):
+    """solvers/new_equilibrium_utils_yaping.py:416-451 (inference part)."""
+
+    def __init__(self, f, solver1, solver2, **kwargs):
+        super().__init__()
+        self.f, self.solver1, self.solver2, self.kwargs = f, solver1, solver2, kwargs
+        self.forward_res = None
+
+    def forward(self, x, Phi, Phi_sum, initial_point=None, train_flag=True):
+        init_point = [torch.zeros_like(x), torch.zeros_like(x)] if initial_point is None else initial_point
+        with torch.no_grad():
+            z, u, self.forward_res = self.solver1(lambda z, u: self.f(z, u, x, Phi, Phi_sum), init_point, **self.kwargs)
+        return z

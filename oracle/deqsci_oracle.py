@@ -215,6 +215,29 @@ def deq_forward(fmap, iterator, y, Phi, Phi_sum, x0, **kw):
     return z, res
 
 
+# ----------------------------------------------------------------------------- ADMM variant
+def admm_step(denoise, z, u, y, Phi, Phi_sum):
+    """EquilibriumADMMSCI.forward, solvers/equilibrium_solvers_yaping.py:449-465 (2-D denoiser branch)."""
+    bsz, H, Wd, B = z.shape
+    zu = z + u
+    z1 = zu + sci_adjoint((y - sci_forward(zu, Phi)) / (Phi_sum + 1e-8), Phi)
+    den = denoise((z1 - u).permute(0, 3, 1, 2).contiguous().view(bsz * B, 1, H, Wd)).view(bsz, B, H, Wd).permute(0, 2, 3, 1)
+    return z1, u - (z1 - den)
+
+
+def admmexp(f, x0, max_iter=50, tol=1e-2):
+    """solvers/new_equilibrium_utils_yaping.py:396-413."""
+    X, U = x0
+    res = None
+    for _ in range(2, max_iter):
+        nX, nU = f(X, U)
+        res = (nX - X).norm().item() / (1e-5 + nX.norm().item())
+        if res < tol:
+            break
+        X, U = nX, nU
+    return X, U, res
+
+
 # ----------------------------------------------------------------------------- harness
 def psnr(rec, gt):
     """10 log10(1 / mean((clip(rec,0,1)-gt)^2)): skimage PSNR for float input, data_range 1

@@ -337,6 +337,40 @@ def weights():
     print("weights ->", wd)
 
 
+
+
+# --------------------------------------------------------------------------- g7 (ADMM variant)
+class _ToyDenoiser(torch.nn.Module):
+    conv3d = False
+
+    def forward(self, x):
+        return 0.8 * x + 0.02 * torch.tanh(x)
+
+
+def g7():
+    from solvers.equilibrium_solvers_yaping import EquilibriumADMMSCI
+    from utils.cg_utils import initial_point_admm
+    g = torch.Generator().manual_seed(99)
+    Phi = (torch.rand(2, 12, 16, 8, generator=g) < 0.5).float()
+    Phi[:, 0, :2, :] = 0
+    x = torch.rand(2, 12, 16, 8, generator=g)
+    y = A_torch_(x, Phi)
+    Phi_sum = torch.sum(Phi, axis=3)
+    Phi_sum[Phi_sum == 0] = 1
+    f = EquilibriumADMMSCI(A=A_torch_, At=At_torch_, nonlinear_operator=_ToyDenoiser(), eta=0.2)
+    init = initial_point_admm(y, Phi, Phi_sum, None)
+    out = {"Phi": Phi, "y": y, "Phi_sum": Phi_sum, "x0": init[0], "u0": init[1]}
+    z1, u1 = f(init[0], init[1], y, Phi, Phi_sum)
+    out["step_z"], out["step_u"] = z1, u1
+    for it, tol in ((8, 1e-9), (40, 5e-2)):
+        deq = eq_utils.DEQFixedPointADMM(f, eq_utils.admmexp, None, max_iter=it, tol=tol)
+        z = deq.forward(y, Phi, Phi_sum, initial_point=[init[0].clone(), init[1].clone()])
+        out[f"it{it}_z"] = z
+        out[f"it{it}_res"] = torch.tensor(deq.forward_res, dtype=torch.float64)
+    np.savez_compressed(HERE + "/admm_toy.npz", **{k: v.numpy() for k, v in out.items()})
+    print("g7 ->", HERE + "/admm_toy.npz")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     for arg in sys.argv[1:]:

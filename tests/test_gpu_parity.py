@@ -503,3 +503,27 @@ def test_cli_end_to_end(tmp_path):
     from PIL import Image
     im = np.asarray(Image.open(os.path.join(tmp_path, "drop8_cacti.mat_reconstruction_0.png")))
     assert im.shape == (256, 256) and im.dtype == np.uint8 and im.std() > 5
+
+
+class _ToyClean(torch.nn.Module):
+    conv3d = False
+
+    def forward(self, x):
+        return 0.8 * x + 0.02 * torch.tanh(x)
+
+
+def test_admm_variant_vs_reference_golden():
+    """EquilibriumADMMSCI / admmexp / DEQFixedPointADMM / initial_point_admm against the reference."""
+    g = np.load(os.path.join(GOLDEN, "admm_toy.npz"))
+    Phi, y, Ps = G(g["Phi"]), G(g["y"]), G(g["Phi_sum"])
+    f = deqsci_amd.EquilibriumADMMSCI(A=deqsci_amd.A_torch_, At=deqsci_amd.At_torch_, nonlinear_operator=_ToyClean(), eta=0.2)
+    init = deqsci_amd.initial_point_admm(y, Phi, Ps, None)
+    assert np.array_equal(init[0].cpu().numpy(), g["x0"]) and float(init[1].abs().max()) == 0.0
+    z1, u1 = f(init[0], init[1], y, Phi, Ps)
+    np.testing.assert_allclose(z1.cpu().numpy(), g["step_z"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(u1.cpu().numpy(), g["step_u"], rtol=1e-5, atol=1e-5)
+    for it, tol in ((8, 1e-9), (40, 5e-2)):
+        deq = deqsci_amd.DEQFixedPointADMM(f, deqsci_amd.admmexp, None, max_iter=it, tol=tol)
+        z = deq.forward(y, Phi, Ps, initial_point=[init[0].clone(), init[1].clone()])
+        assert rel_l2(z.cpu().numpy(), g[f"it{it}_z"]) < 1e-5
+        assert abs(deq.forward_res - float(g[f"it{it}_res"])) < 1e-3 * float(g[f"it{it}_res"]) + 1e-6   # 4.5e-8 at it=8: round-off level

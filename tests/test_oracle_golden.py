@@ -160,3 +160,14 @@ def test_reference_fp32_gram_loses_digits_at_large_n():
     a, ra = orc.andersonexp(f, x0, m=3, lam=1e-2, max_iter=6, tol=0.0)
     b, rb = orc.andersonexp(f, x0, m=3, lam=1e-2, max_iter=6, tol=0.0, gram_dtype=torch.float64)
     assert rel_l2(a, b) < 1e-5
+
+
+def test_admm_variant_golden():
+    g = np.load(os.path.join(GOLDEN, "admm_toy.npz"))
+    Phi, y, Ps, x0, u0 = (T(g[k]) for k in ("Phi", "y", "Phi_sum", "x0", "u0"))
+    den = lambda x: 0.8 * x + 0.02 * torch.tanh(x)
+    z1, u1 = orc.admm_step(den, x0, u0, y, Phi, Ps)
+    assert torch.equal(z1, T(g["step_z"])) and torch.equal(u1, T(g["step_u"]))
+    for it, tol in ((8, 1e-9), (40, 5e-2)):
+        z, u, res = orc.admmexp(lambda a, b: orc.admm_step(den, a, b, y, Phi, Ps), [x0, u0], max_iter=it, tol=tol)
+        assert torch.equal(z, T(g[f"it{it}_z"])) and res == float(g[f"it{it}_res"])
