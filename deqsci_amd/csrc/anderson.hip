@@ -316,8 +316,11 @@ __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict
     }
 
 static inline int64_t chunk_elems(int64_t bsz, int64_t N) {
-    // ~2048 blocks over the whole batch, each block a whole number of 1024-element sweeps (>= 2)
-    int64_t per_sample = 2048 / (bsz > 0 ? bsz : 1);
+    // target number of blocks over the whole batch (16384 measured best of 1024..32768 at bsz 64, flat at bsz 8;
+    // tuning knob DEQSCI_K4_BLOCKS), each block a whole number of
+    // 1024-element sweeps (>= 2)
+    static const int64_t target = [] { const char* e = getenv("DEQSCI_K4_BLOCKS"); return e ? atoll(e) : 16384ll; }();
+    int64_t per_sample = target / (bsz > 0 ? bsz : 1);
     if (per_sample < 1) per_sample = 1;
     int64_t chunk = ceil_div(ceil_div(N, per_sample), 1024) * 1024;
     if (chunk < 2048) chunk = 2048;
