@@ -50,3 +50,16 @@ def test_gfx950_code_object_present():
     from deqsci_amd import _hip
     blob = open(_hip.lib_path(), "rb").read()
     assert b"gfx950" in blob and b"gfx90a" not in blob and b"sm_" not in blob
+
+
+def test_binding_argument_counts_match_header():
+    """Every prototype in include/deqsci_hip.h has as many parameters as the ctypes signature the Python
+    binding declares for it (a drifted binding would corrupt the call frame silently)."""
+    from deqsci_amd import _hip
+    src = open(os.path.join(ROOT, "include", "deqsci_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = dict(re.findall(r"\bint\s+(deqsci_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", src, flags=re.S))
+    assert set(_hip.SIGNATURES) <= set(protos)
+    for name, argtypes in _hip.SIGNATURES.items():
+        params = [p for p in protos[name].split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
