@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--no-channels-last", action="store_true")
     ap.add_argument("--no-fused-epilogue", action="store_true")
     ap.add_argument("--no-fused-edges", action="store_true")
+    ap.add_argument("--no-winograd", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -115,7 +116,7 @@ def main():
     net = net.to(dev)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
-                       fused_edges=not args.no_fused_edges)
+                       fused_edges=not args.no_fused_edges, winograd=not args.no_winograd)
     y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
     gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
 

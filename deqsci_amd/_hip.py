@@ -37,6 +37,7 @@ SIGNATURES = {
     "deqsci_bias_relu_f32": [_ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr],
     "deqsci_ffdnet_tail_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_ffdnet_head_f32": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_conv3x3_c64_winograd_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -329,6 +330,28 @@ def ffdnet_head(x, w_packed, sigma, out=None):
         _check(load().deqsci_ffdnet_head_f32(_p(x, "x"), _p(w_packed, "w_packed"), sigma.data_ptr(),
                                              0 if sigma.numel() == 1 else sigma.stride(0), o.data_ptr(), n, H, W, _stream()),
                "ffdnet_head")
+    return o
+
+
+def pack_winograd_weights(w):
+    """(64,64,3,3) conv weight -> U = G g G^T of Winograd F(2x2,3x3), ordered [cin chunk][xi][cout][cin%8]."""
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise DeqsciHipError(f"winograd conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = G @ w.detach().double() @ G.t()                      # (cout, cin, 4, 4)
+    U = U.permute(2, 3, 0, 1).reshape(16, 64, 8, 8)          # [xi][cout][chunk][cin%8]
+    return U.permute(2, 0, 1, 3).contiguous().float()        # [chunk][xi][cout][cin%8]
+
+
+def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):
+    """x (n,64,H,W) channels_last -> relu(conv3x3(x, w, pad=1) + bias) as a new channels_last tensor."""
+    n, c, H, W = x.shape
+    if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
+        raise DeqsciHipError("conv3x3_c64_winograd: fp32 channels_last GPU activation with 64 channels required")
+    o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+    with _dev(x):
+        _check(load().deqsci_conv3x3_c64_winograd_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
+                                                      n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd")
     return o
 
 

@@ -56,13 +56,15 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True):
+    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True):
         from .networks import FFDNet
         self.net = net
         self.fused_edges = fused_edges
-        # measured on MI355X (profiles/r01_denoiser_variants.jsonl): MIOpen's fp32 Winograd is 8 % faster in
-        # channels_last for FFDNet's 128x128x64 layers and 11 % slower for SimpleCNN's 256x256x64 ones
-        self.channels_last = isinstance(net, FFDNet) if channels_last is None else bool(channels_last)
+        self.winograd = winograd
+        # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
+        # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
+        # 128x128x64 layers, 11 % slower for SimpleCNN's 256x256x64 ones.
+        self.channels_last = (winograd or isinstance(net, FFDNet)) if channels_last is None else bool(channels_last)
         self.fused_epilogue = fused_epilogue
         self.tag = getattr(net, "tag", None)
         if self.tag not in ("conv2d", "conv3d", "ffdnet", "denoiser", "3d_denoiser"):
@@ -86,6 +88,7 @@ class _Denoiser:
             return
         self._wkey = key
         self.fast = None
+        self.wino = None
         self.tail_w = self.head_w = None
         from .networks import DnCNN
         seq = None
@@ -111,6 +114,10 @@ class _Denoiser:
                 w = w.contiguous(memory_format=torch.channels_last) if self.channels_last else w.contiguous()
                 layers.append((w, b, relu))
             self.fast = layers
+            # 64->64 layers: Winograd F(2x2,3x3) on the fp32 matrix cores with bias+ReLU fused (csrc/winograd.hip)
+            self.wino = [(_hip.pack_winograd_weights(w) if (self.winograd and self.channels_last and w.is_cuda
+                                                             and tuple(w.shape) == (64, 64, 3, 3)) else None)
+                         for w, _, _ in layers]
             self.tail_w = self.head_w = None
             if (isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[-1][1] is None
                     and not layers[-1][2] and tuple(layers[-1][0].shape) == (4, 64, 3, 3) and layers[-1][0].is_cuda):
@@ -122,21 +129,28 @@ class _Denoiser:
 
     def _run_stack(self, h, skip_last=False, skip_first=False, defer_last_epilogue=False):
         """defer_last_epilogue: leave the bias+ReLU of the last executed layer to the consumer (the fused
-        FFDNet tail applies it while staging its input) and return (raw conv output, bias)."""
+        FFDNet tail applies it while staging its input) and return (raw conv output, bias) - only when that
+        layer runs on MIOpen; the Winograd kernel applies bias+ReLU in its own epilogue for free."""
         if self.channels_last:
             h = h.contiguous(memory_format=torch.channels_last)
         fused = self.fused_epilogue and h.is_cuda
-        todo = self.fast[(1 if skip_first else 0):(-1 if skip_last else None)]
+        lo, hi = (1 if skip_first else 0), (len(self.fast) - 1 if skip_last else len(self.fast))
+        idx = list(range(lo, hi))
         if defer_last_epilogue:
-            w, b, relu = todo[-1]
+            last = idx[-1]
+            w, b, relu = self.fast[last]
+            if self.wino[last] is not None and h.is_cuda:
+                return self._run_layers(h, idx, fused), None
             assert b is not None and relu
-            return F.conv2d(self._run_layers(h, todo[:-1], fused), w, None, padding=1), b
-        return self._run_layers(h, todo, fused)
+            return F.conv2d(self._run_layers(h, idx[:-1], fused), w, None, padding=1), b
+        return self._run_layers(h, idx, fused)
 
-    @staticmethod
-    def _run_layers(h, layers, fused):
-        for w, b, relu in layers:
-            if fused and b is not None:
+    def _run_layers(self, h, idx, fused):
+        for i in idx:
+            w, b, relu = self.fast[i]
+            if self.wino[i] is not None and h.is_cuda and h.is_contiguous(memory_format=torch.channels_last):
+                h = _hip.conv3x3_c64_winograd(h, self.wino[i], b, relu)
+            elif fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
             else:
@@ -186,11 +200,11 @@ class _Denoiser:
 class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True):
+                 fused_edges=True, winograd=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges)
+                             fused_edges=fused_edges, winograd=winograd)
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
         self.max_iter, self.tol = int(max_iter), float(tol)

@@ -527,3 +527,26 @@ def test_admm_variant_vs_reference_golden():
         z = deq.forward(y, Phi, Ps, initial_point=[init[0].clone(), init[1].clone()])
         assert rel_l2(z.cpu().numpy(), g[f"it{it}_z"]) < 1e-5
         assert abs(deq.forward_res - float(g[f"it{it}_res"])) < 1e-3 * float(g[f"it{it}_res"]) + 1e-6   # 4.5e-8 at it=8: round-off level
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 128, 128), (3, 20, 36), (1, 18, 14)])
+def test_winograd_conv64_vs_torch(shape):
+    """Winograd F(2x2,3x3) MFMA conv 64->64 (+bias+ReLU) vs conv2d in fp64: transpose-detecting (random asymmetric
+    weights), ragged tile edges, with and without the fused epilogue."""
+    import torch.nn.functional as Fn
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn(n, 64, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05
+    b = torch.randn(64, device=DEV, generator=g)
+    U = _hip.pack_winograd_weights(w)
+    ref = Fn.conv2d(x.double(), w.double(), padding=1)
+    ref32 = Fn.conv2d(x, w, padding=1)
+    got = _hip.conv3x3_c64_winograd(x, U, None, relu=False)
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape
+    e_got = float((got.double() - ref).norm() / ref.norm())
+    e_ref = float((ref32.double() - ref).norm() / ref.norm())
+    assert e_got < 2e-6, (e_got, e_ref)
+    got2 = _hip.conv3x3_c64_winograd(x, U, b, relu=True)
+    want2 = torch.relu(ref + b.double().view(1, -1, 1, 1))
+    assert float((got2.double() - want2).norm() / want2.norm()) < 2e-6

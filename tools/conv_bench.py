@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""64->64 3x3 conv layer (+bias+ReLU): MIOpen (channels_last igemm + HIP epilogue) vs the Winograd MFMA kernel."""
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deqsci_amd import _hip  # noqa: E402
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+for (N, H, W) in ((64, 128, 128), (8, 128, 128), (64, 256, 256)):
+    x = torch.randn(N, 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device="cuda")
+    U = _hip.pack_winograd_weights(w)
+    out = torch.empty_like(x, memory_format=torch.channels_last)
+    fl = 2 * 64 * 64 * 9 * H * W * N
+    t_mi = timeit(lambda: _hip.bias_relu_(F.conv2d(x, wcl, None, padding=1), b, True))
+    t_wg = timeit(lambda: _hip.conv3x3_c64_winograd(x, U, b, True, out=out))
+    print(json.dumps({"images": N, "HxW": f"{H}x{W}", "miopen_igemm_plus_epilogue_us": round(t_mi, 1), "winograd_mfma_fused_us": round(t_wg, 1),
+                      "speedup": round(t_mi / t_wg, 2), "winograd_direct_equiv_TFLOPs": round(fl / t_wg / 1e6, 1),
+                      "winograd_mfma_util": round((fl / 2.25) / t_wg / 1e6 / 157.3, 3)}), flush=True)
