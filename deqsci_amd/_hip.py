@@ -37,6 +37,8 @@ SIGNATURES = {
     "deqsci_bias_relu_f32": [_ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr],
     "deqsci_ffdnet_tail_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_ffdnet_head_f32": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_conv3x3_c64_to_1_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_conv3x3_c1_to_64_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
@@ -305,6 +307,44 @@ def ffdnet_tail(h, w_packed, out=None, in_bias=None):
     with _dev(h):
         _check(load().deqsci_ffdnet_tail_f32(h.data_ptr(), _p(w_packed, "w_packed"), _p(in_bias, "in_bias", True), _p(o, "out"),
                                              n, H, W, _stream()), "ffdnet_tail")
+    return o
+
+
+def pack_c64_to_1_weights(w):
+    """(1,64,3,3) conv weight -> [half(2)][tap(9)][cin(32)] for deqsci_conv3x3_c64_to_1_f32."""
+    if tuple(w.shape) != (1, 64, 3, 3):
+        raise DeqsciHipError(f"expected a (1,64,3,3) weight, got {tuple(w.shape)}")
+    return w.detach().float().permute(2, 3, 1, 0).reshape(9, 2, 32).permute(1, 0, 2).contiguous()
+
+
+def conv3x3_c64_to_1(h, w_packed, out=None, in_bias=None):
+    """h (n,64,H,W) channels_last -> planar (n,1,H,W) = conv3x3(h', w, pad=1), h' = h or relu(h + in_bias[c])."""
+    n, c, H, W = h.shape
+    if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
+        raise DeqsciHipError("conv3x3_c64_to_1: fp32 channels_last GPU activation with 64 channels required")
+    o = out if out is not None else torch.empty((n, 1, H, W), device=h.device, dtype=torch.float32)
+    with _dev(h):
+        _check(load().deqsci_conv3x3_c64_to_1_f32(h.data_ptr(), _p(w_packed, "w_packed"), _p(in_bias, "in_bias", True), _p(o, "out"),
+                                                  n, H, W, _stream()), "conv3x3_c64_to_1")
+    return o
+
+
+def pack_c1_to_64_weights(w):
+    """(64,1,3,3) conv weight -> [tap(9)][cout//4(16)][cout%4(4)] for deqsci_conv3x3_c1_to_64_f32."""
+    if tuple(w.shape) != (64, 1, 3, 3):
+        raise DeqsciHipError(f"expected a (64,1,3,3) weight, got {tuple(w.shape)}")
+    return w.detach().float().reshape(16, 4, 9).permute(2, 0, 1).contiguous()
+
+
+def conv3x3_c1_to_64(x, w_packed, relu=True, out=None):
+    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation."""
+    n, c, H, W = x.shape
+    if c != 1:
+        raise DeqsciHipError(f"conv3x3_c1_to_64: (n,1,H,W) image required, got {tuple(x.shape)}")
+    o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    with _dev(x):
+        _check(load().deqsci_conv3x3_c1_to_64_f32(_p(x, "x"), _p(w_packed, "w_packed"), o.data_ptr(), n, H, W, 1 if relu else 0,
+                                                  _stream()), "conv3x3_c1_to_64")
     return o
 
 

@@ -20,14 +20,17 @@ constexpr int TT_IW = TT_W + 2, TT_IH = TT_H + 2;  // input tile with halo
 constexpr int TT_CH = 32;                          // channels per LDS pass
 constexpr int TT_PS = TT_CH + 4;                   // LDS pixel stride (floats)
 
-__global__ __launch_bounds__(TB) void ffdnet_tail_kernel(const float* __restrict__ h, const float* __restrict__ wp,
-                                                         const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
+template <int COUT>   // 4: FFDNet tail (2x2 pixel shuffle on the way out); 1: plain 64 -> 1 layer (SimpleCNN tail)
+__global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__ h, const float* __restrict__ wp,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
     __shared__ __attribute__((aligned(16))) float tile[TT_IH * TT_IW * TT_PS];
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * TT_H, c0 = blockIdx.x * TT_W;
     const int lr = threadIdx.x / TT_W, lc = threadIdx.x % TT_W;
     const float* hn = h + (int64_t)n * H * W * 64;
-    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         // stage [TT_IH][TT_IW][32] (zero outside the image): 8 float4 per pixel
@@ -46,28 +49,67 @@ __global__ __launch_bounds__(TB) void ffdnet_tail_kernel(const float* __restrict
             *reinterpret_cast<float4*>(tile + pix * TT_PS + 4 * q) = v;
         }
         __syncthreads();
-        const float* wh = wp + half * 9 * TT_CH * 4;
+        const float* wh = wp + half * 9 * TT_CH * COUT;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const float* tp = tile + ((lr + tap / 3) * TT_IW + (lc + tap % 3)) * TT_PS;
-            const float* wt = wh + tap * TT_CH * 4;
+            const float* wt = wh + tap * TT_CH * COUT;
 #pragma unroll
             for (int c4 = 0; c4 < TT_CH / 4; ++c4) {
                 const float4 v = *reinterpret_cast<const float4*>(tp + 4 * c4);
-                const float* w = wt + c4 * 16;
-                acc0 = fmaf(v.x, w[0], acc0);  acc1 = fmaf(v.x, w[1], acc1);  acc2 = fmaf(v.x, w[2], acc2);  acc3 = fmaf(v.x, w[3], acc3);
-                acc0 = fmaf(v.y, w[4], acc0);  acc1 = fmaf(v.y, w[5], acc1);  acc2 = fmaf(v.y, w[6], acc2);  acc3 = fmaf(v.y, w[7], acc3);
-                acc0 = fmaf(v.z, w[8], acc0);  acc1 = fmaf(v.z, w[9], acc1);  acc2 = fmaf(v.z, w[10], acc2); acc3 = fmaf(v.z, w[11], acc3);
-                acc0 = fmaf(v.w, w[12], acc0); acc1 = fmaf(v.w, w[13], acc1); acc2 = fmaf(v.w, w[14], acc2); acc3 = fmaf(v.w, w[15], acc3);
+                const float* w = wt + c4 * 4 * COUT;
+#pragma unroll
+                for (int o = 0; o < COUT; ++o)
+                    acc[o] = fmaf(v.w, w[3 * COUT + o], fmaf(v.z, w[2 * COUT + o], fmaf(v.y, w[COUT + o], fmaf(v.x, w[o], acc[o]))));
             }
         }
         __syncthreads();
     }
     const int r = r0 + lr, c = c0 + lc;
-    if (r < H && c < W) {       // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
-        float* o = out + (int64_t)n * 4 * H * W + (int64_t)(2 * r) * (2 * W) + 2 * c;
-        *reinterpret_cast<float2*>(o) = make_float2(acc0, acc1);
-        *reinterpret_cast<float2*>(o + 2 * W) = make_float2(acc2, acc3);
+    if (r < H && c < W) {
+        if (COUT == 4) {        // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
+            float* o = out + (int64_t)n * 4 * H * W + (int64_t)(2 * r) * (2 * W) + 2 * c;
+            *reinterpret_cast<float2*>(o) = make_float2(acc[0], acc[COUT > 1 ? 1 : 0]);
+            *reinterpret_cast<float2*>(o + 2 * W) = make_float2(acc[COUT > 2 ? 2 : 0], acc[COUT > 3 ? 3 : 0]);
+        } else {
+            out[(int64_t)n * H * W + (int64_t)r * W + c] = acc[0];
+        }
+    }
+}
+
+// plain head: conv3x3(1 -> 64, pad 1, no bias) [+ ReLU], planar (n,1,H,W) image in, channels_last (n,H,W,64) out.
+// Same mapping as the FFDNet head below: 16 lanes per position x 4 output channels each, 9 x 4 weights in
+// registers, a 34 x 34 patch in LDS read by broadcast; the kernel is bound by its 256 B/position store.
+constexpr int H1_T = 32, H1_P = H1_T + 2, H1_PS = H1_P + 1;
+__global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                           float* __restrict__ h, int H, int W, int relu) {
+    __shared__ float patch[H1_P * H1_PS];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * H1_T, c0 = blockIdx.x * H1_T;
+    const float* xn = x + (int64_t)n * H * W;
+    for (int e = threadIdx.x; e < H1_P * H1_P; e += TB) {
+        const int pr = e / H1_P, pc = e % H1_P;
+        const int gr = r0 - 1 + pr, gc = c0 - 1 + pc;
+        patch[pr * H1_PS + pc] = (gr >= 0 && gr < H && gc >= 0 && gc < W) ? xn[(int64_t)gr * W + gc] : 0.0f;
+    }
+    const int cq = threadIdx.x % 16, slot = threadIdx.x / 16;
+    float4 wr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = ld4(wq + (k * 16 + cq) * 4);
+    __syncthreads();
+    float* hn = h + (int64_t)n * H * W * 64;
+#pragma unroll 2
+    for (int it = 0; it < H1_T * H1_T / 16; ++it) {
+        const int q = it * 16 + slot;
+        const int lr = q / H1_T, lc = q % H1_T;
+        const int r = r0 + lr, c = c0 + lc;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc = fma4(patch[(lr + tap / 3) * H1_PS + lc + tap % 3], wr[tap], acc);
+        if (r < H && c < W) {
+            if (relu) { acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f); }
+            st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
+        }
     }
 }
 
@@ -162,6 +204,30 @@ extern "C" int deqsci_ffdnet_tail_f32(const float* h, const float* w_packed, con
     if (!aligned16(h) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(W, TT_W), (unsigned)ceil_div(H, TT_H), (unsigned)n);
-    hipLaunchKernelGGL(ffdnet_tail_kernel, grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
+    hipLaunchKernelGGL(edge_tail_kernel<4>, grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
+    return launch_status();
+}
+
+extern "C" int deqsci_conv3x3_c64_to_1_f32(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n,
+                                           int64_t H, int64_t W, deqsci_stream_t stream) {
+    if (!h || !w_packed || !out) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(h) || !aligned16(w_packed) || (in_bias && !aligned16(in_bias))) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)ceil_div(W, TT_W), (unsigned)ceil_div(H, TT_H), (unsigned)n);
+    hipLaunchKernelGGL(edge_tail_kernel<1>, grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
+    return launch_status();
+}
+
+extern "C" int deqsci_conv3x3_c1_to_64_f32(const float* x, const float* w_packed, float* h, int64_t n, int64_t H, int64_t W,
+                                           int relu, deqsci_stream_t stream) {
+    if (!x || !w_packed || !h) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)ceil_div(W, H1_T), (unsigned)ceil_div(H, H1_T), (unsigned)n);
+    hipLaunchKernelGGL(conv_c1_to_64_kernel, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu);
     return launch_status();
 }

@@ -90,6 +90,7 @@ class _Denoiser:
         self.fast = None
         self.wino = None
         self.tail_w = self.head_w = None
+        self.plain_head_w = self.plain_tail_w = None
         from .networks import DnCNN
         seq = None
         if isinstance(net, FFDNet) and not net.training and net.num_input_channels == 1 and self.fold_bn:
@@ -119,6 +120,13 @@ class _Denoiser:
                                                              and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
             self.tail_w = self.head_w = None
+            self.plain_head_w = self.plain_tail_w = None
+            if (not isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[0][0].is_cuda):
+                # SimpleCNN-style stacks: 1 -> 64 (+ReLU) and 64 -> 1 edge layers as HIP stencils (csrc/ffdnet_edges.hip)
+                if tuple(layers[0][0].shape) == (64, 1, 3, 3) and layers[0][1] is None:
+                    self.plain_head_w = _hip.pack_c1_to_64_weights(layers[0][0])
+                if tuple(layers[-1][0].shape) == (1, 64, 3, 3) and layers[-1][1] is None and not layers[-1][2]:
+                    self.plain_tail_w = _hip.pack_c64_to_1_weights(layers[-1][0])
             if (isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[-1][1] is None
                     and not layers[-1][2] and tuple(layers[-1][0].shape) == (4, 64, 3, 3) and layers[-1][0].is_cuda):
                 # last layer + upsamplefeatures as one HIP stencil kernel (csrc/ffdnet_edges.hip)
@@ -189,6 +197,15 @@ class _Denoiser:
             return out.reshape(bsz, B, H, W), True
         if self.tag == "denoiser":
             if self.fast is not None:
+                if x.is_cuda and (self.plain_head_w is not None or self.plain_tail_w is not None):
+                    first = self.plain_head_w is not None
+                    h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2]) if first else x
+                    if self.plain_tail_w is not None:
+                        h = self._run_stack(h, skip_first=first, skip_last=True)
+                        out = _hip.conv3x3_c64_to_1(h.contiguous(memory_format=torch.channels_last), self.plain_tail_w)
+                    else:
+                        out = self._run_stack(h, skip_first=first)
+                    return out.reshape(bsz, B, H, W), True
                 return self._run_stack(x).reshape(bsz, B, H, W), True
             return self.net(x).reshape(bsz, B, H, W), True
         if self.tag == "conv2d":

@@ -139,6 +139,15 @@ int deqsci_bias_relu_f32(float* h, const float* bias, int64_t n, int64_t c, int6
 int deqsci_ffdnet_tail_f32(const float* h, const float* w_packed, const float* in_bias, float* out,
                            int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
 
+/* The same two stencils without the FFDNet layout layers - SimpleCNN's edge layers
+ *     (networks/provable/model/SimpleCNN_models.py:43-57): conv3x3(64 -> 1) from a channels_last (n,H,W,64) activation to
+ *     a planar (n,1,H,W) image (w_packed [half(2)][tap(9)][cin(32)], optional in_bias + ReLU on the way in), and
+ *     conv3x3(1 -> 64) [+ ReLU] from a planar image to channels_last (w_packed [tap(9)][cout/4(16)][cout%4(4)]). */
+int deqsci_conv3x3_c64_to_1_f32(const float* h, const float* w_packed, const float* in_bias, float* out,
+                                int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
+int deqsci_conv3x3_c1_to_64_f32(const float* x, const float* w_packed, float* h,
+                                int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream);
+
 /* FFDNet head: `concatenate_input_noise_map` (networks/ffdnet/functions.py:16-53: sigma map + 2x2 pixel-unshuffle)
  *     + conv3x3(5 -> 64, pad 1, no bias) + ReLU.  x is the planar (n,1,2H,2W) image, sigma[i*sigma_stride] the noise
  *     level of image i (stride 0 = one value for all), w_packed the (64,5,3,3) weight re-ordered

@@ -550,3 +550,29 @@ def test_winograd_conv64_vs_torch(shape):
     got2 = _hip.conv3x3_c64_winograd(x, U, b, relu=True)
     want2 = torch.relu(ref + b.double().view(1, -1, 1, 1))
     assert float((got2.double() - want2).norm() / want2.norm()) < 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 24), (1, 256, 256), (3, 33, 70)])
+def test_plain_edge_kernels_vs_torch(shape):
+    """conv3x3 1->64 (+ReLU) planar -> channels_last and conv3x3 64->1 channels_last -> planar (SimpleCNN edges)."""
+    import torch.nn.functional as Fn
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(13)
+    x = torch.randn(n, 1, H, W, device=DEV, generator=g)
+    w1 = torch.randn(64, 1, 3, 3, device=DEV, generator=g) * 0.2
+    want = torch.relu(Fn.conv2d(x.double(), w1.double(), padding=1))
+    got = _hip.conv3x3_c1_to_64(x, _hip.pack_c1_to_64_weights(w1), relu=True)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got.double() - want).norm() / want.norm()) < 1e-6
+    got_lin = _hip.conv3x3_c1_to_64(x, _hip.pack_c1_to_64_weights(w1), relu=False)
+    want_lin = Fn.conv2d(x.double(), w1.double(), padding=1)
+    assert float((got_lin.double() - want_lin).norm() / want_lin.norm()) < 1e-6
+    h = torch.randn(n, 64, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w2 = torch.randn(1, 64, 3, 3, device=DEV, generator=g) * 0.05
+    want2 = Fn.conv2d(h.double(), w2.double(), padding=1)
+    got2 = _hip.conv3x3_c64_to_1(h, _hip.pack_c64_to_1_weights(w2))
+    assert got2.shape == (n, 1, H, W) and float((got2.double() - want2).norm() / want2.norm()) < 1e-6
+    b = torch.randn(64, device=DEV, generator=g)
+    want3 = Fn.conv2d(torch.relu(h.double() + b.double().view(1, -1, 1, 1)), w2.double(), padding=1)
+    got3 = _hip.conv3x3_c64_to_1(h, _hip.pack_c64_to_1_weights(w2), in_bias=b)
+    assert float((got3.double() - want3).norm() / want3.norm()) < 1e-6
