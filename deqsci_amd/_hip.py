@@ -374,13 +374,15 @@ def ffdnet_head(x, w_packed, sigma, out=None):
 
 
 def pack_winograd_weights(w):
-    """(64,64,3,3) conv weight -> U = G g G^T of Winograd F(2x2,3x3), ordered [cin chunk][xi][cout][cin%8]."""
+    """(64,64,3,3) conv weight -> U = G g G^T of Winograd F(2x2,3x3) in the kernel's MFMA-lane order
+    [cin chunk c (8)][xi (16)][cout half wn (2)][q (4)][i (16)][j (2)][s (2)] with cout = 32 wn + 16 j + i and
+    cin = 8 c + 2 q + s, so that LDS staging is a linear copy and a lane's B operands are 16 contiguous bytes."""
     if tuple(w.shape) != (64, 64, 3, 3):
         raise DeqsciHipError(f"winograd conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
     U = G @ w.detach().double() @ G.t()                      # (cout, cin, 4, 4)
-    U = U.permute(2, 3, 0, 1).reshape(16, 64, 8, 8)          # [xi][cout][chunk][cin%8]
-    return U.permute(2, 0, 1, 3).contiguous().float()        # [chunk][xi][cout][cin%8]
+    U = U.permute(2, 3, 0, 1).reshape(16, 2, 2, 16, 8, 4, 2)  # [xi][wn][j][i][c][q][s]
+    return U.permute(4, 0, 1, 5, 3, 2, 6).contiguous().float()   # [c][xi][wn][q][i][j][s]
 
 
 def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):

@@ -29,49 +29,76 @@ namespace deqsci {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WG_CK = 8;            // input channels per chunk
-constexpr int WG_VS = 12;           // LDS row stride in floats (8 + 4 pad): ds_read_b64 of 32 lanes hits 64 distinct banks
+
 constexpr int WG_NCHUNK = 64 / WG_CK;
-constexpr int WG_T = 32;            // Winograd tiles per block: 4 rows x 8 columns = 8 x 16 output pixels
+
 #ifndef WG_ABLATE        // tuning harness only (tools/ubench/winograd_ablate.sh): 1 = no MFMA, 2 = no global loads/transform
 #define WG_ABLATE 0
 #endif
 
-// Block = 32 tiles x all 64 output channels, 4 wavefronts, TWO blocks resident per CU (72 KB LDS, <= 256 registers)
-// so one block's input transform / barriers / epilogue run under the other block's MFMAs.  Wave w owns tiles
+// Block = 32 tiles x all 64 output channels, 4 wavefronts, TWO blocks resident per CU (<= 80 KB LDS, <= 256 registers)
+// so one block's staging / barriers / epilogue run under the other block's MFMAs.  Wave w owns tiles
 // [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
 // v_mfma_f32_16x16x4_f32 (128 registers), and holds every value the output transform of its (tile, cout) needs.
+//
+// Data movement (the first versions were bound by narrow global loads, not by the matrix pipe):
+//   * the RAW input tile (10 x 18 pixels) is staged in LDS one 32-channel half at a time with full-line
+//     (128 B per pixel) coalesced loads; pixel stride 34 floats / row stride 624 floats make the per-lane patch
+//     reads conflict-free;
+//   * each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch for its 2 channels of
+//     the chunk (16 ds_read_b64) and computes V = B^T d B in registers: the A operands of all 16 xi never touch
+//     LDS again (no V buffer, no transform threads, no second barrier for V);
+//   * the pre-transformed weights of a chunk go through LDS in MFMA-lane order (host-packed), so staging is a
+//     linear 32 KB copy and each lane's B operands for one xi are ONE conflict-free ds_read_b128.
+constexpr int WG_RAW_PS = 34;                 // floats per staged pixel (32 channels + 2)
+constexpr int WG_RAW_RS = 624;                // floats per staged pixel row (18 * 34 = 612, +12: 2 rows == 32 banks apart)
+constexpr int WG_RAW_ROWS = 10, WG_RAW_COLS = 18;
+
 __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int H, int W, int relu) {
-    __shared__ __attribute__((aligned(16))) float Vs[16 * WG_T * WG_VS];     // V[xi][tile][cin]   24 KB
-    __shared__ __attribute__((aligned(16))) float Us[16 * 64 * WG_VS];       // U[xi][cout][cin]   48 KB
+    __shared__ __attribute__((aligned(16))) float Raw[WG_RAW_ROWS * WG_RAW_RS];   // 24.4 KB
+    __shared__ __attribute__((aligned(16))) float Us[16 * 2 * 64 * 4];           // U[xi][cout half][MFMA lane][j][2]   32 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave >> 1, wn = wave & 1;
     const int n = blockIdx.z;
     const int ty0 = blockIdx.y * 4, tx0 = blockIdx.x * 8;          // tile coordinates of the block
     const float* xn = x + (int64_t)n * H * W * 64;
+    const int py0 = 2 * ty0 - 1, px0 = 2 * tx0 - 1;                // image coordinates of staged pixel (0,0)
 
-    // transform role: tile t (0..31), input channel ci (0..7) of the chunk
-    const int t = tid >> 3, ci = tid & 7;
-    const int iy0 = 2 * (ty0 + (t >> 3)) - 1, ix0 = 2 * (tx0 + (t & 7)) - 1;
-    // branch-free patch addressing: out-of-image pixels read a clamped (valid) address and are zeroed by a select
-    int poff[16];
-    unsigned pmask = 0;
+    // ---- staging roles: raw half = 180 pixels x 8 float4 (6 per thread, last partly idle); U chunk = 8 float4 per thread
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 8;          // 1440
+    constexpr int RAW_PER_THREAD = (RAW_F4 + TB - 1) / TB;         // 6
+    float4 rawv[RAW_PER_THREAD];
+    auto fetch_raw = [&](int half) {
 #pragma unroll
-    for (int pr = 0; pr < 4; ++pr)
-#pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-            const int iy = iy0 + pr, ix = ix0 + pc;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        for (int k = 0; k < RAW_PER_THREAD; ++k) {
+            const int e = k * TB + tid;
+            const int pix = e >> 3, q4 = e & 7;
+            const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
+            const int iy = py0 + pr, ix = px0 + pc;
+            const bool ok = e < RAW_F4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
             const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            poff[pr * 4 + pc] = (cy * W + cx) * 64 + ci;
-            pmask |= (ok ? 1u : 0u) << (pr * 4 + pc);
+            float4 v = ld4(xn + ((int64_t)cy * W + cx) * 64 + half * 32 + 4 * q4);      // clamped address, zero-select
+            if (!ok) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            rawv[k] = v;
         }
-    float d[16];
-    float4 u[8];
-    auto fetch = [&](int c) {
+    };
+    auto store_raw = [&]() {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = xn[poff[k] + c * WG_CK];
+        for (int k = 0; k < RAW_PER_THREAD; ++k) {
+            const int e = k * TB + tid;
+            if (e < RAW_F4) {
+                const int pix = e >> 3, q4 = e & 7;
+                const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
+                float* dst = Raw + pr * WG_RAW_RS + pc * WG_RAW_PS + 4 * q4;           // 8-B aligned (34 floats = 136 B)
+                *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
+                *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
+            }
+        }
+    };
+    float4 u[8];
+    auto fetch_u = [&](int c) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) u[j] = ld4(Ug + (int64_t)c * (16 * 64 * WG_CK) + (j * TB + tid) * 4);
     };
@@ -82,80 +109,74 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[xi][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    // MFMA operand addresses: lane (i = lane&15, q = lane>>4) reads cin {2q, 2q+1}; k index of the MFMA = q
-    const float* va = Vs + (16 * wt + (lane & 15)) * WG_VS + 2 * (lane >> 4);
-    const float* ub = Us + (32 * wn + (lane & 15)) * WG_VS + 2 * (lane >> 4);
+    // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16*wt + i and channels {2q, 2q+1} of the chunk
+    const int mi = lane & 15, mq = lane >> 4;
+    const int tl_a = 16 * wt + mi;
+    const float* patch = Raw + (2 * (tl_a >> 3)) * WG_RAW_RS + (2 * (tl_a & 7)) * WG_RAW_PS + 2 * mq;
+    const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's B operands {j=0: cin 2q,2q+1; j=1: ...}: 16 B
 
-    fetch(0);
+    fetch_raw(0);
+    fetch_u(0);
 #pragma unroll 1
     for (int c = 0; c < WG_NCHUNK; ++c) {
-#if WG_ABLATE == 2
-        if (c > 0) goto mfma_phase;
-#endif
+        const int cc = c & 3;
+        __syncthreads();                                      // every wave is done with the previous chunk's LDS reads
+        if (cc == 0) store_raw();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(Us + (j * TB + tid) * 4) = u[j];   // linear 32 KB copy
+        __syncthreads();
+        if (c + 1 < WG_NCHUNK) fetch_u(c + 1);                // next chunk's global loads fly under this chunk's MFMAs
+        if (c == 3) fetch_raw(1);
+
+        // ---- input transform in registers: V = B^T d B for (tile, 2 channels); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        float2 v[16];
         {
-            // ---- input transform V = B^T d B; B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+            float2 w[16];
+            const float* pp = patch + 8 * cc;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) if (!((pmask >> k) & 1u)) d[k] = 0.0f;
-            float w[16];
-#pragma unroll
-            for (int pc = 0; pc < 4; ++pc) {                      // rows: w = B^T d
-                const float d0 = d[pc], d1 = d[4 + pc], d2 = d[8 + pc], d3 = d[12 + pc];
-                w[pc] = d0 - d2;
-                w[4 + pc] = d1 + d2;
-                w[8 + pc] = d2 - d1;
-                w[12 + pc] = d1 - d3;
-            }
-            __syncthreads();                                      // previous chunk's MFMAs are done with LDS
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {                      // columns: V = w B
-                const float w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
-                float* vrow = Vs + ((pr * 4) * WG_T + t) * WG_VS + ci;
-                vrow[0] = w0 - w2;
-                vrow[WG_T * WG_VS] = w1 + w2;
-                vrow[2 * WG_T * WG_VS] = w2 - w1;
-                vrow[3 * WG_T * WG_VS] = w1 - w3;
+            for (int pc = 0; pc < 4; ++pc) {                  // rows: w = B^T d (column pc of the patch)
+                const float2 d0 = *reinterpret_cast<const float2*>(pp + pc * WG_RAW_PS);
+                const float2 d1 = *reinterpret_cast<const float2*>(pp + WG_RAW_RS + pc * WG_RAW_PS);
+                const float2 d2 = *reinterpret_cast<const float2*>(pp + 2 * WG_RAW_RS + pc * WG_RAW_PS);
+                const float2 d3 = *reinterpret_cast<const float2*>(pp + 3 * WG_RAW_RS + pc * WG_RAW_PS);
+                w[pc] = make_float2(d0.x - d2.x, d0.y - d2.y);
+                w[4 + pc] = make_float2(d1.x + d2.x, d1.y + d2.y);
+                w[8 + pc] = make_float2(d2.x - d1.x, d2.y - d1.y);
+                w[12 + pc] = make_float2(d1.x - d3.x, d1.y - d3.y);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {                         // weights: Ug[c][xi][cout][8] -> Us[xi][cout][12]
-                const int e = (j * TB + tid) * 4;
-                *reinterpret_cast<float4*>(Us + (e >> 3) * WG_VS + (e & 7)) = u[j];
+            for (int pr = 0; pr < 4; ++pr) {                  // columns: V = w B
+                const float2 w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
+                v[pr * 4] = make_float2(w0.x - w2.x, w0.y - w2.y);
+                v[pr * 4 + 1] = make_float2(w1.x + w2.x, w1.y + w2.y);
+                v[pr * 4 + 2] = make_float2(w2.x - w1.x, w2.y - w1.y);
+                v[pr * 4 + 3] = make_float2(w1.x - w3.x, w1.y - w3.y);
             }
-            __syncthreads();
-            fetch(c + 1 < WG_NCHUNK ? c + 1 : c);                 // next chunk's global loads fly under the MFMA phase
         }
-#if WG_ABLATE == 2
-    mfma_phase:
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        // MFMA phase: per xi three ds_read_b64 (A, B for the two cout tiles) feed four MFMAs; the reads of xi+1 are
-        // issued before the MFMAs of xi, consecutive MFMAs alternate accumulators (40-cycle dependent latency)
-        float2 a = *reinterpret_cast<const float2*>(va);
-        float2 b0 = *reinterpret_cast<const float2*>(ub), b1 = *reinterpret_cast<const float2*>(ub + 16 * WG_VS);
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        // ---- MFMA phase: per xi ONE ds_read_b128 (this lane's B operands for both cout tiles and both k-steps, stored
+        // in lane order so a wavefront reads 1 KiB contiguous) feeds four MFMAs; the read of xi+1 is issued before the
+        // MFMAs of xi; consecutive MFMAs alternate accumulators (40-cycle dependent latency)
+        float4 b = *reinterpret_cast<const float4*>(ub);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            float2 an = a, b0n = b0, b1n = b1;
-            if (xi + 1 < 16) {
-                an = *reinterpret_cast<const float2*>(va + (xi + 1) * WG_T * WG_VS);
-                b0n = *reinterpret_cast<const float2*>(ub + (xi + 1) * 64 * WG_VS);
-                b1n = *reinterpret_cast<const float2*>(ub + (xi + 1) * 64 * WG_VS + 16 * WG_VS);
-            }
+            float4 bn = b;
+            if (xi + 1 < 16) bn = *reinterpret_cast<const float4*>(ub + (xi + 1) * (2 * 64 * 4));
 #if WG_ABLATE == 1
-            acc[xi][0][0] += a.x * b0.x + a.y * b0.y;
-            acc[xi][1][0] += a.x * b1.x + a.y * b1.y;
+            acc[xi][0][0] += v[xi].x * b.x + v[xi].y * b.y;
+            acc[xi][1][0] += v[xi].x * b.z + v[xi].y * b.w;
 #else
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc[xi][1], 0, 0, 0);
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].x, b.x, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].x, b.z, acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.y, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.w, acc[xi][1], 0, 0, 0);
 #endif
-            a = an;
-            b0 = b0n;
-            b1 = b1n;
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);   // the three ds_read_b64 of xi+1 ...
+            b = bn;
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of xi+1 ...
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then the four MFMAs of xi
         }
-        __builtin_amdgcn_sched_barrier(0);                    // keep the next transform (and its vmcnt wait) BELOW the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; bias; ReLU; store

@@ -157,7 +157,8 @@ int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* s
 
 /* conv3x3(64 -> 64, pad 1, stride 1) + per-channel bias + ReLU as Winograd F(2x2,3x3) on the fp32 matrix cores.
  *     x, y channels_last (n,H,W,64), x != y; u_packed = the (64,64,3,3) weight transformed U = G g G^T and ordered
- *     [cin chunk (8)][xi (16)][cout (64)][cin in chunk (8)]; bias (64, may be NULL); relu 0/1.
+ *     [cin chunk c (8)][xi (16)][wn (2)][q (4)][i (16)][j (2)][s (2)], cout = 32 wn + 16 j + i, cin = 8 c + 2 q + s
+ *     (the kernel's MFMA lane order); bias (64, may be NULL); relu 0/1.
  *     The middle layers of FFDNet (networks/ffdnet/models.py:53-58, BatchNorm folded) and SimpleCNN. */
 int deqsci_conv3x3_c64_winograd_f32(const float* x, const float* u_packed, const float* bias, float* y,
                                     int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream);

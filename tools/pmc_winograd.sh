@@ -13,7 +13,7 @@ import csv, collections, glob
 for f in sorted(glob.glob('gpurun_out/pmc_wg/p*/k_counter_collection.csv')):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'winograd' in r['Kernel_Name'] and r['Grid_Size'] == str(8*8*64*256):
+        if "winograd" in r["Kernel_Name"] and r["Grid_Size"] == str(8*16*64*256):
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items():
         print(f.split('/')[2], k, sorted(v)[len(v)//2], len(v))
