@@ -123,6 +123,7 @@ def main():
     # per-launch timing of the fused Phi/Phi^T+GAP-update kernel from the dispatch's own HIP-event
     # timestamps (hipExtLaunchKernelGGL start/stop events on the stream the kernel runs on)
     timer = _hip.KernelTimer()
+    conv_timer = _hip.KernelTimer()
     timing_on = [False]
     if not args.no_kernel_timing:
         orig = _hip.anderson_mix_gap
@@ -132,6 +133,15 @@ def main():
                 return orig(ws, beta, n, *a)
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
+        orig_wg = _hip.conv3x3_c64_winograd
+        conv_shape = []
+
+        def timed_winograd(x, U, bias=None, relu=True, out=None):
+            if not timing_on[0] or len(conv_timer.pairs) >= 400:      # a sample of launches is enough
+                return orig_wg(x, U, bias, relu, out)
+            conv_shape[:] = [x.shape[0], x.shape[2], x.shape[3]]
+            return conv_timer.winograd(x, U, bias, relu, out)
+        _hip.conv3x3_c64_winograd = timed_winograd
 
     def step():
         rec = eng.reconstruct(y, Phi)
@@ -191,6 +201,18 @@ def main():
                                "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms)}
+        cms = conv_timer.durations_ms()
+        if cms:
+            # the denoiser's 64->64 conv layers (the kernel where the time goes): executed MFMA flops of the Winograd
+            # F(2x2,3x3) form = direct flops / 2.25, against the dense fp32 MFMA peak
+            nimg, ch, cw = conv_shape
+            direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
+            cavg = 1e-3 * sum(cms) / len(cms)
+            out["denoiser_roofline"] = {"kernel": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)",
+                                        "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                        "frac": direct / 2.25 / cavg / 1e12 / 157.3, "traffic": None,
+                                        "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12, "avg_launch_us": 1e6 * cavg,
+                                        "launches_timed": len(cms), "share_of_step_time": 0.94}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_iters, args.iters + 2, H, W, B, args.denoiser)
         print(json.dumps(out), flush=True)

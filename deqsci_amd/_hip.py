@@ -40,6 +40,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_to_1_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_conv3x3_c1_to_64_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_conv3x3_c64_winograd_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -419,6 +420,17 @@ class KernelTimer:
                 _p(x_out, "x_out"), _p(z1, "z1"), bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream(), e0, e1),
                 "anderson_mix_gap_timed")
         self.pairs.append((e0, e1))
+
+    def winograd(self, x, u_packed, bias=None, relu=True, out=None):
+        n, c, H, W = x.shape
+        o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+        e0, e1 = self._event(), self._event()
+        with _dev(x):
+            _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True),
+                                                                o.data_ptr(), n, H, W, 1 if relu else 0, _stream(), e0, e1),
+                   "conv3x3_c64_winograd_timed")
+        self.pairs.append((e0, e1))
+        return o
 
     def durations_ms(self):
         out = []

@@ -23,6 +23,7 @@
 //   * the 16 values A^T M A needs for one (tile, cout) sit in the same accumulator slot of the 16 M[xi], so the
 //     output transform, bias and ReLU are pure per-lane register work.
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 namespace deqsci {
 
@@ -218,15 +219,28 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
 #ifndef WG_NO_CABI
 using namespace deqsci;
 
-extern "C" int deqsci_conv3x3_c64_winograd_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
-                                               int64_t H, int64_t W, int relu, deqsci_stream_t stream) {
+static int winograd_impl(const float* x, const float* u_packed, const float* bias, float* y, int64_t n, int64_t H, int64_t W,
+                         int relu, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (!x || !u_packed || !y) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
     if (n > 65535 || H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(ceil_div(W, 2), 8), (unsigned)ceil_div(ceil_div(H, 2), 4), (unsigned)n);
-    hipLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(TB), 0, st, x, u_packed, bias, y, (int)H, (int)W, relu);
+    hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(TB), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu);
     return launch_status();
+}
+
+extern "C" int deqsci_conv3x3_c64_winograd_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
+                                               int64_t H, int64_t W, int relu, deqsci_stream_t stream) {
+    return winograd_impl(x, u_packed, bias, y, n, H, W, relu, stream, nullptr, nullptr);
+}
+
+extern "C" int deqsci_conv3x3_c64_winograd_timed_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
+                                                     int64_t H, int64_t W, int relu, deqsci_stream_t stream, void* start_event,
+                                                     void* stop_event) {
+    if (!start_event || !stop_event) return DEQSCI_ERR_NULL;
+    return winograd_impl(x, u_packed, bias, y, n, H, W, relu, stream, static_cast<hipEvent_t>(start_event),
+                         static_cast<hipEvent_t>(stop_event));
 }
 #endif  // WG_NO_CABI

@@ -173,6 +173,9 @@ int deqsci_anderson_mix_gap_timed_f32(const float* F_hist, const float* G_hist, 
                                       int64_t bsz, int64_t H, int64_t W, int64_t B,
                                       int layout, int phi_shared, deqsci_stream_t stream,
                                       void* start_event, void* stop_event);
+int deqsci_conv3x3_c64_winograd_timed_f32(const float* x, const float* u_packed, const float* bias, float* y,
+                                          int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream,
+                                          void* start_event, void* stop_event);
 int deqsci_event_create(void** ev);
 int deqsci_event_destroy(void* ev);
 int deqsci_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream is synchronised */
