@@ -42,24 +42,27 @@ constexpr int WG_NCHUNK = 64 / WG_CK;
 // [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
 // v_mfma_f32_16x16x4_f32 (128 registers), and holds every value the output transform of its (tile, cout) needs.
 //
-// Data movement (the first versions were bound by narrow global loads, not by the matrix pipe):
-//   * the RAW input tile (10 x 18 pixels) is staged in LDS one 32-channel half at a time with full-line
-//     (128 B per pixel) coalesced loads; pixel stride 34 floats / row stride 624 floats make the per-lane patch
-//     reads conflict-free;
+// Data movement (the first versions were bound by LDS traffic and barriers, not by the matrix pipe):
+//   * the RAW input tile (10 x 18 pixels) is staged in LDS one 16-channel quarter at a time (64 B per pixel,
+//     coalesced); pixel stride 18 floats, and pixel rows 2,3,6,7 shifted right by one pixel, make the per-lane
+//     patch reads (ds_read2_b64, 32 banks) conflict-free;
 //   * each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch for its 2 channels of
-//     the chunk (16 ds_read_b64) and computes V = B^T d B in registers: the A operands of all 16 xi never touch
-//     LDS again (no V buffer, no transform threads, no second barrier for V);
-//   * the pre-transformed weights of a chunk go through LDS in MFMA-lane order (host-packed), so staging is a
-//     linear 32 KB copy and each lane's B operands for one xi are ONE conflict-free ds_read_b128.
-constexpr int WG_RAW_PS = 34;                 // floats per staged pixel (32 channels + 2)
-constexpr int WG_RAW_RS = 624;                // floats per staged pixel row (18 * 34 = 612, +12: 2 rows == 32 banks apart)
-constexpr int WG_RAW_ROWS = 10, WG_RAW_COLS = 18;
+//     the chunk and computes V = B^T d B in registers: the A operands of all 16 xi never touch LDS again;
+//   * the pre-transformed weights of a chunk go through LDS in MFMA-lane order (host-packed): staging is a linear
+//     32 KB copy, a lane's B operands for one xi are ONE conflict-free ds_read_b128, and the chunk buffers are
+//     double-buffered so a chunk costs one barrier.
+constexpr int WG_RAW_PS = 18;                 // floats per staged pixel (16 channels + 2)
+constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 10;
+constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 342 floats per staged pixel row (one spare pixel for the shift)
+constexpr int WG_U_CHUNK = 16 * 2 * 64 * 4;   // floats of one weight chunk in LDS (32 KB)
+
+__device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
 
 __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int H, int W, int relu) {
-    __shared__ __attribute__((aligned(16))) float Raw[WG_RAW_ROWS * WG_RAW_RS];   // 24.4 KB
-    __shared__ __attribute__((aligned(16))) float Us[16 * 2 * 64 * 4];           // U[xi][cout half][MFMA lane][j][2]   32 KB
+    __shared__ __attribute__((aligned(16))) float Raw[WG_RAW_ROWS * WG_RAW_RS];   // 13.4 KB
+    __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave >> 1, wn = wave & 1;
     const int n = blockIdx.z;
@@ -67,20 +70,20 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     const float* xn = x + (int64_t)n * H * W * 64;
     const int py0 = 2 * ty0 - 1, px0 = 2 * tx0 - 1;                // image coordinates of staged pixel (0,0)
 
-    // ---- staging roles: raw half = 180 pixels x 8 float4 (6 per thread, last partly idle); U chunk = 8 float4 per thread
-    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 8;          // 1440
-    constexpr int RAW_PER_THREAD = (RAW_F4 + TB - 1) / TB;         // 6
+    // ---- staging roles: raw quarter = 180 pixels x 4 float4 (3 per thread, last partly idle); U chunk = 8 float4 per thread
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 4;          // 720
+    constexpr int RAW_PER_THREAD = (RAW_F4 + TB - 1) / TB;         // 3
     float4 rawv[RAW_PER_THREAD];
-    auto fetch_raw = [&](int half) {
+    auto fetch_raw = [&](int quarter) {
 #pragma unroll
         for (int k = 0; k < RAW_PER_THREAD; ++k) {
             const int e = k * TB + tid;
-            const int pix = e >> 3, q4 = e & 7;
+            const int pix = e >> 2, q4 = e & 3;
             const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
             const int iy = py0 + pr, ix = px0 + pc;
             const bool ok = e < RAW_F4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
             const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            float4 v = ld4(xn + ((int64_t)cy * W + cx) * 64 + half * 32 + 4 * q4);      // clamped address, zero-select
+            float4 v = ld4(xn + ((int64_t)cy * W + cx) * 64 + quarter * 16 + 4 * q4);   // clamped address, zero-select
             if (!ok) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             rawv[k] = v;
         }
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
         for (int k = 0; k < RAW_PER_THREAD; ++k) {
             const int e = k * TB + tid;
             if (e < RAW_F4) {
-                const int pix = e >> 3, q4 = e & 7;
+                const int pix = e >> 2, q4 = e & 3;
                 const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
-                float* dst = Raw + pr * WG_RAW_RS + pc * WG_RAW_PS + 4 * q4;           // 8-B aligned (34 floats = 136 B)
+                float* dst = Raw + pr * WG_RAW_RS + (pc + wg_row_shift(pr)) * WG_RAW_PS + 4 * q4;   // 8-B aligned
                 *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
                 *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
             }
@@ -101,7 +104,11 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     float4 u[8];
     auto fetch_u = [&](int c) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = ld4(Ug + (int64_t)c * (16 * 64 * WG_CK) + (j * TB + tid) * 4);
+        for (int j = 0; j < 8; ++j) u[j] = ld4(Ug + (int64_t)c * WG_U_CHUNK + (j * TB + tid) * 4);
+    };
+    auto store_u = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(Us + buf * WG_U_CHUNK + (j * TB + tid) * 4) = u[j];
     };
 
     f32x4 acc[16][2];
@@ -113,33 +120,38 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16*wt + i and channels {2q, 2q+1} of the chunk
     const int mi = lane & 15, mq = lane >> 4;
     const int tl_a = 16 * wt + mi;
-    const float* patch = Raw + (2 * (tl_a >> 3)) * WG_RAW_RS + (2 * (tl_a & 7)) * WG_RAW_PS + 2 * mq;
-    const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's B operands {j=0: cin 2q,2q+1; j=1: ...}: 16 B
+    int prow[4];                                             // this lane's 4 patch rows (with their shift) in Raw
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+        const int r = 2 * (tl_a >> 3) + pr;
+        prow[pr] = r * WG_RAW_RS + (2 * (tl_a & 7) + wg_row_shift(r)) * WG_RAW_PS + 2 * mq;
+    }
+    const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's B operands of xi = 0 in buffer 0
 
     fetch_raw(0);
     fetch_u(0);
+    store_raw();
+    store_u(0);
+    __syncthreads();
 #pragma unroll 1
     for (int c = 0; c < WG_NCHUNK; ++c) {
-        const int cc = c & 3;
-        __syncthreads();                                      // every wave is done with the previous chunk's LDS reads
-        if (cc == 0) store_raw();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(Us + (j * TB + tid) * 4) = u[j];   // linear 32 KB copy
-        __syncthreads();
-        if (c + 1 < WG_NCHUNK) fetch_u(c + 1);                // next chunk's global loads fly under this chunk's MFMAs
-        if (c == 3) fetch_raw(1);
+        // entry: Us[c&1] = U(c) and Raw = quarter c>>1 are visible to every wave
+#if WG_ABLATE < 3
+        if (c + 1 < WG_NCHUNK) fetch_u(c + 1);                // next chunk's / quarter's global loads fly under the MFMAs
+        if ((c & 1) == 0 && c + 2 < WG_NCHUNK) fetch_raw((c >> 1) + 1);
+#endif
 
         // ---- input transform in registers: V = B^T d B for (tile, 2 channels); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
         float2 v[16];
         {
             float2 w[16];
-            const float* pp = patch + 8 * cc;
+            const float* pp = Raw + 8 * (c & 1);
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) {                  // rows: w = B^T d (column pc of the patch)
-                const float2 d0 = *reinterpret_cast<const float2*>(pp + pc * WG_RAW_PS);
-                const float2 d1 = *reinterpret_cast<const float2*>(pp + WG_RAW_RS + pc * WG_RAW_PS);
-                const float2 d2 = *reinterpret_cast<const float2*>(pp + 2 * WG_RAW_RS + pc * WG_RAW_PS);
-                const float2 d3 = *reinterpret_cast<const float2*>(pp + 3 * WG_RAW_RS + pc * WG_RAW_PS);
+                const float2 d0 = *reinterpret_cast<const float2*>(pp + prow[0] + pc * WG_RAW_PS);
+                const float2 d1 = *reinterpret_cast<const float2*>(pp + prow[1] + pc * WG_RAW_PS);
+                const float2 d2 = *reinterpret_cast<const float2*>(pp + prow[2] + pc * WG_RAW_PS);
+                const float2 d3 = *reinterpret_cast<const float2*>(pp + prow[3] + pc * WG_RAW_PS);
                 w[pc] = make_float2(d0.x - d2.x, d0.y - d2.y);
                 w[4 + pc] = make_float2(d1.x + d2.x, d1.y + d2.y);
                 w[8 + pc] = make_float2(d2.x - d1.x, d2.y - d1.y);
@@ -158,12 +170,15 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
         // ---- MFMA phase: per xi ONE ds_read_b128 (this lane's B operands for both cout tiles and both k-steps, stored
         // in lane order so a wavefront reads 1 KiB contiguous) feeds four MFMAs; the read of xi+1 is issued before the
         // MFMAs of xi; consecutive MFMAs alternate accumulators (40-cycle dependent latency)
-        float4 b = *reinterpret_cast<const float4*>(ub);
+        const float* ubc = ub + (c & 1) * WG_U_CHUNK;
+        float4 b = *reinterpret_cast<const float4*>(ubc);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             float4 bn = b;
-            if (xi + 1 < 16) bn = *reinterpret_cast<const float4*>(ub + (xi + 1) * (2 * 64 * 4));
+#if WG_ABLATE != 4
+            if (xi + 1 < 16) bn = *reinterpret_cast<const float4*>(ubc + (xi + 1) * (2 * 64 * 4));
+#endif
 #if WG_ABLATE == 1
             acc[xi][0][0] += v[xi].x * b.x + v[xi].y * b.y;
             acc[xi][1][0] += v[xi].x * b.z + v[xi].y * b.w;
@@ -178,6 +193,14 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then the four MFMAs of xi
         }
         __builtin_amdgcn_sched_barrier(0);
+#if WG_ABLATE < 3
+        if (c + 1 < WG_NCHUNK) store_u((c + 1) & 1);          // the other buffer: nobody reads it before the barrier
+        __syncthreads();                                      // U(c+1) visible; every wave is done with Us[c&1] (and Raw if c is odd)
+        if ((c & 1) == 1 && c + 1 < WG_NCHUNK) {              // quarter boundary: one extra barrier per two chunks
+            store_raw();
+            __syncthreads();
+        }
+#endif
     }
 
     // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; bias; ReLU; store
