@@ -142,3 +142,39 @@ def test_golden_metadata_present():
         with open(os.path.join(GOLDEN, f"e2e_{tag}.json")) as fh:
             meta = json.load(fh)
         assert meta["measurements"] and all("psnr" in m and "sha16_clip" in m for m in meta["measurements"])
+
+
+def test_weight_packing_layouts_on_cpu():
+    """The host-side weight re-orderings the HIP conv kernels consume, checked without a GPU: unpack every packed
+    layout back by its documented index formula and (for Winograd) run the F(2x2,3x3) algebra in torch."""
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(21)
+    w = torch.randn(64, 64, 3, 3, generator=g)
+    U = _hip.pack_winograd_weights(w)                     # [c][xi][wn][q][i][j][s]
+    assert tuple(U.shape) == (8, 16, 2, 4, 16, 2, 2)
+    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]])
+    Uref = G @ w @ G.t()                                  # (cout, cin, 4, 4)
+    for (c, xi, wn, q, i, j, s_) in [(0, 0, 0, 0, 0, 0, 0), (3, 7, 1, 2, 5, 1, 1), (7, 15, 1, 3, 15, 1, 0), (5, 9, 0, 1, 8, 0, 1)]:
+        cout, cin = 32 * wn + 16 * j + i, 8 * c + 2 * q + s_
+        assert abs(float(U[c, xi, wn, q, i, j, s_]) - float(Uref[cout, cin, xi // 4, xi % 4])) < 1e-6
+    # Winograd algebra with the packed weights == conv2d (one 4x4 patch -> 2x2 outputs)
+    x = torch.randn(1, 64, 4, 4, generator=g)
+    Bt = torch.tensor([[1.0, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+    At = torch.tensor([[1.0, 1, 1, 0], [0, 1, -1, -1]])
+    V = Bt @ x[0] @ Bt.t()                                # (cin, 4, 4)
+    M = torch.einsum("oiab,iab->oab", Uref, V)
+    Y = At @ M @ At.t()                                   # (cout, 2, 2)
+    want = Fn.conv2d(x, w)[0]                             # valid conv of the 4x4 patch = the 2x2 outputs
+    assert rel_l2(Y.numpy(), want.numpy()) < 1e-5
+    wt = torch.randn(4, 64, 3, 3, generator=g)
+    pt = _hip.pack_tail_weights(wt)                       # [half][tap][cin32][cout]
+    assert tuple(pt.shape) == (2, 9, 32, 4) and float(pt[1, 5, 7, 2]) == float(wt[2, 32 + 7, 1, 2])
+    wh = torch.randn(64, 5, 3, 3, generator=g)
+    ph = _hip.pack_head_weights(wh)                       # [ch*9+tap][cout//4][cout%4]
+    assert tuple(ph.shape) == (45, 16, 4) and float(ph[2 * 9 + 4, 3, 1]) == float(wh[13, 2, 1, 1])
+    w1 = torch.randn(64, 1, 3, 3, generator=g)
+    assert float(_hip.pack_c1_to_64_weights(w1)[7, 10, 2]) == float(w1[42, 0, 2, 1])
+    w2 = torch.randn(1, 64, 3, 3, generator=g)
+    assert float(_hip.pack_c64_to_1_weights(w2)[1, 3, 9]) == float(w2[0, 41, 1, 0])
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.pack_winograd_weights(torch.zeros(64, 32, 3, 3))
