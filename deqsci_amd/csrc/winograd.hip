@@ -37,23 +37,25 @@ constexpr int WG_NCHUNK = 64 / WG_CK;
 #define WG_ABLATE 0
 #endif
 
-// Block = 32 tiles x all 64 output channels, 4 wavefronts, TWO blocks resident per CU (<= 80 KB LDS, <= 256 registers)
-// so one block's staging / barriers / epilogue run under the other block's MFMAs.  Wave w owns tiles
-// [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
+// Block = 32 tiles x all 64 output channels, 4 wavefronts, TWO blocks resident per CU (<= 80 KB LDS, <= 256 registers).
+// Wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
 // v_mfma_f32_16x16x4_f32 (128 registers), and holds every value the output transform of its (tile, cout) needs.
 //
-// Data movement (the first versions were bound by LDS traffic and barriers, not by the matrix pipe):
-//   * the RAW input tile (10 x 18 pixels) is staged in LDS one 16-channel quarter at a time (64 B per pixel,
-//     coalesced); pixel stride 18 floats, and pixel rows 2,3,6,7 shifted right by one pixel, make the per-lane
-//     patch reads (ds_read2_b64, 32 banks) conflict-free;
-//   * each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch for its 2 channels of
-//     the chunk and computes V = B^T d B in registers: the A operands of all 16 xi never touch LDS again;
-//   * the pre-transformed weights of a chunk go through LDS in MFMA-lane order (host-packed): staging is a linear
-//     32 KB copy, a lane's B operands for one xi are ONE conflict-free ds_read_b128, and the chunk buffers are
-//     double-buffered so a chunk costs one barrier.
-constexpr int WG_RAW_PS = 18;                 // floats per staged pixel (16 channels + 2)
+// The 64 input channels are consumed in 8 chunks of 8.  A chunk is one software-pipeline stage with ONE barrier:
+//   * weights U(c+1): host-packed in MFMA-lane order, copied global -> LDS by the DMA path (global_load_lds_dwordx4,
+//     no registers, no ds_write) into the other of two 32 KB buffers; a lane's B operands for one xi are then ONE
+//     conflict-free ds_read_b128 feeding 4 MFMAs;
+//   * raw input of chunk c+2 (10 x 18 pixels x 8 channels): two coalesced float4 per lane into registers at the top of
+//     the stage, written to the other of two 7.6 KB LDS tiles after the MFMAs (pixel stride 10 floats, pixel rows
+//     2,3,6,7 shifted by one pixel: the per-lane patch reads hit 32 distinct banks);
+//   * each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch of chunk c+1 while the
+//     MFMAs of chunk c run, and turns it into V = B^T d B (its A operands for all 16 xi) in registers afterwards:
+//     the A operands never go back to LDS, and no LDS read latency is exposed (measured: the un-pipelined input
+//     transform was 24 % of a block's lifetime).
+constexpr int WG_RAW_PS = 10;                 // floats per staged pixel (8 channels + 2)
 constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 10;
-constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 342 floats per staged pixel row (one spare pixel for the shift)
+constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 190 floats per staged pixel row (one spare pixel for the shift)
+constexpr int WG_RAW_BUF = WG_RAW_ROWS * WG_RAW_RS;           // 1900 floats = 7.6 KB
 constexpr int WG_U_CHUNK = 16 * 2 * 64 * 4;   // floats of one weight chunk in LDS (32 KB)
 
 __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
@@ -61,8 +63,8 @@ __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
 __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int H, int W, int relu) {
-    __shared__ __attribute__((aligned(16))) float Raw[WG_RAW_ROWS * WG_RAW_RS];   // 13.4 KB
     __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
+    __shared__ __attribute__((aligned(16))) float Raw[2 * WG_RAW_BUF];            // 2 x raw chunk tile                    15.2 KB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave >> 1, wn = wave & 1;
     const int n = blockIdx.z;
@@ -70,45 +72,49 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     const float* xn = x + (int64_t)n * H * W * 64;
     const int py0 = 2 * ty0 - 1, px0 = 2 * tx0 - 1;                // image coordinates of staged pixel (0,0)
 
-    // ---- staging roles: raw quarter = 180 pixels x 4 float4 (3 per thread, last partly idle); U chunk = 8 float4 per thread
-    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 4;          // 720
-    constexpr int RAW_PER_THREAD = (RAW_F4 + TB - 1) / TB;         // 3
-    float4 rawv[RAW_PER_THREAD];
-    auto fetch_raw = [&](int quarter) {
+    // ---- raw staging role: chunk tile = 180 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 256
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 360
+    int roff[2], rdst[2];                                          // global element offset (clamped) / LDS float offset, -1 = idle
+    bool rok[2];
 #pragma unroll
-        for (int k = 0; k < RAW_PER_THREAD; ++k) {
-            const int e = k * TB + tid;
-            const int pix = e >> 2, q4 = e & 3;
-            const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
-            const int iy = py0 + pr, ix = px0 + pc;
-            const bool ok = e < RAW_F4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            float4 v = ld4(xn + ((int64_t)cy * W + cx) * 64 + quarter * 16 + 4 * q4);   // clamped address, zero-select
-            if (!ok) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int k = 0; k < 2; ++k) {
+        const int e = k * TB + tid;
+        const int pix = e >> 1, q4 = e & 1;
+        const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
+        const int iy = py0 + pr, ix = px0 + pc;
+        rok[k] = e < RAW_F4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        roff[k] = (cy * W + cx) * 64 + 4 * q4;
+        rdst[k] = e < RAW_F4 ? pr * WG_RAW_RS + (pc + wg_row_shift(pr)) * WG_RAW_PS + 4 * q4 : -1;
+    }
+    float4 rawv[2];
+    auto fetch_raw = [&](int c) {                                  // clamped address + zero-select: no branches
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float4 v = ld4(xn + roff[k] + c * WG_CK);
+            if (!rok[k]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             rawv[k] = v;
         }
     };
-    auto store_raw = [&]() {
+    auto store_raw = [&](int buf) {
 #pragma unroll
-        for (int k = 0; k < RAW_PER_THREAD; ++k) {
-            const int e = k * TB + tid;
-            if (e < RAW_F4) {
-                const int pix = e >> 2, q4 = e & 3;
-                const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
-                float* dst = Raw + pr * WG_RAW_RS + (pc + wg_row_shift(pr)) * WG_RAW_PS + 4 * q4;   // 8-B aligned
+        for (int k = 0; k < 2; ++k)
+            if (rdst[k] >= 0) {
+                float* dst = Raw + buf * WG_RAW_BUF + rdst[k];                          // 8-B aligned (pixel stride 40 B)
                 *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
                 *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
             }
-        }
     };
-    float4 u[8];
-    auto fetch_u = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) u[j] = ld4(Ug + (int64_t)c * WG_U_CHUNK + (j * TB + tid) * 4);
+    // ---- weight chunk: DMA global -> LDS, 8 x 1 KiB per wavefront, linear
+    auto dma_u_piece = [&](int c, int buf, int j) {
+        const int blk = j * 4 + wave;                                                   // 1 KiB block of the 32 KB chunk
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(Ug + (int64_t)c * WG_U_CHUNK + (blk * 64 + lane) * 4),
+            (__attribute__((address_space(3))) void*)(Us + buf * WG_U_CHUNK + blk * 256), 16, 0, 0);
     };
-    auto store_u = [&](int buf) {
+    auto dma_u = [&](int c, int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(Us + buf * WG_U_CHUNK + (j * TB + tid) * 4) = u[j];
+        for (int j = 0; j < 8; ++j) dma_u_piece(c, buf, j);
     };
 
     f32x4 acc[16][2];
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16*wt + i and channels {2q, 2q+1} of the chunk
     const int mi = lane & 15, mq = lane >> 4;
     const int tl_a = 16 * wt + mi;
-    int prow[4];                                             // this lane's 4 patch rows (with their shift) in Raw
+    int prow[4];                                             // this lane's 4 patch rows (with their shift) in a raw tile
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
         const int r = 2 * (tl_a >> 3) + pr;
@@ -128,49 +134,64 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     }
     const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's B operands of xi = 0 in buffer 0
 
+    // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  V = B^T d B
+    float2 dn[16], v[16];
+    auto read_patch = [&](int buf) {
+        const float* pp = Raw + buf * WG_RAW_BUF;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) dn[pr * 4 + pc] = *reinterpret_cast<const float2*>(pp + prow[pr] + pc * WG_RAW_PS);
+    };
+    auto transform = [&]() {
+        float2 w[16];
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {                      // rows: w = B^T d (column pc of the patch)
+            const float2 d0 = dn[pc], d1 = dn[4 + pc], d2 = dn[8 + pc], d3 = dn[12 + pc];
+            w[pc] = make_float2(d0.x - d2.x, d0.y - d2.y);
+            w[4 + pc] = make_float2(d1.x + d2.x, d1.y + d2.y);
+            w[8 + pc] = make_float2(d2.x - d1.x, d2.y - d1.y);
+            w[12 + pc] = make_float2(d1.x - d3.x, d1.y - d3.y);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {                      // columns: V = w B
+            const float2 w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
+            v[pr * 4] = make_float2(w0.x - w2.x, w0.y - w2.y);
+            v[pr * 4 + 1] = make_float2(w1.x + w2.x, w1.y + w2.y);
+            v[pr * 4 + 2] = make_float2(w2.x - w1.x, w2.y - w1.y);
+            v[pr * 4 + 3] = make_float2(w1.x - w3.x, w1.y - w3.y);
+        }
+    };
+
+#ifdef WG_STAMP
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias)) +
+                                    (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 40;
+    int stamp_i = 0;
+#define WG_MARK() do { if (tid == 0) stamp_out[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#else
+#define WG_MARK() do { } while (0)
+#endif
+    WG_MARK();                                                // 0: kernel entry
+    // ---- prologue: U(0), raw(0), raw(1) staged; V(0) computed
+    dma_u(0, 0);
     fetch_raw(0);
-    fetch_u(0);
-    store_raw();
-    store_u(0);
+    store_raw(0);
+    fetch_raw(1);
+    store_raw(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    read_patch(0);
+    transform();
+    WG_MARK();                                                // 1: prologue done
 #pragma unroll 1
     for (int c = 0; c < WG_NCHUNK; ++c) {
-        // entry: Us[c&1] = U(c) and Raw = quarter c>>1 are visible to every wave
-#if WG_ABLATE < 3
-        if (c + 1 < WG_NCHUNK) fetch_u(c + 1);                // next chunk's / quarter's global loads fly under the MFMAs
-        if ((c & 1) == 0 && c + 2 < WG_NCHUNK) fetch_raw((c >> 1) + 1);
-#endif
-
-        // ---- input transform in registers: V = B^T d B for (tile, 2 channels); B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        float2 v[16];
-        {
-            float2 w[16];
-            const float* pp = Raw + 8 * (c & 1);
-#pragma unroll
-            for (int pc = 0; pc < 4; ++pc) {                  // rows: w = B^T d (column pc of the patch)
-                const float2 d0 = *reinterpret_cast<const float2*>(pp + prow[0] + pc * WG_RAW_PS);
-                const float2 d1 = *reinterpret_cast<const float2*>(pp + prow[1] + pc * WG_RAW_PS);
-                const float2 d2 = *reinterpret_cast<const float2*>(pp + prow[2] + pc * WG_RAW_PS);
-                const float2 d3 = *reinterpret_cast<const float2*>(pp + prow[3] + pc * WG_RAW_PS);
-                w[pc] = make_float2(d0.x - d2.x, d0.y - d2.y);
-                w[4 + pc] = make_float2(d1.x + d2.x, d1.y + d2.y);
-                w[8 + pc] = make_float2(d2.x - d1.x, d2.y - d1.y);
-                w[12 + pc] = make_float2(d1.x - d3.x, d1.y - d3.y);
-            }
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr) {                  // columns: V = w B
-                const float2 w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
-                v[pr * 4] = make_float2(w0.x - w2.x, w0.y - w2.y);
-                v[pr * 4 + 1] = make_float2(w1.x + w2.x, w1.y + w2.y);
-                v[pr * 4 + 2] = make_float2(w2.x - w1.x, w2.y - w1.y);
-                v[pr * 4 + 3] = make_float2(w1.x - w3.x, w1.y - w3.y);
-            }
-        }
+        // entry: Us[c&1] = U(c), Raw[(c+1)&1] = raw(c+1) visible; v = V(c) in registers
         __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA phase: per xi ONE ds_read_b128 (this lane's B operands for both cout tiles and both k-steps, stored
-        // in lane order so a wavefront reads 1 KiB contiguous) feeds four MFMAs; the read of xi+1 is issued before the
-        // MFMAs of xi; consecutive MFMAs alternate accumulators (40-cycle dependent latency)
+        WG_MARK();
+        // ---- MFMA phase: per xi ONE ds_read_b128 (B operands) and ONE ds_read_b64 (a patch element of the next chunk)
+        // are issued ahead of the four MFMAs of xi; consecutive MFMAs alternate accumulators (40-cycle dependent latency)
         const float* ubc = ub + (c & 1) * WG_U_CHUNK;
+        const float* ppn = Raw + ((c + 1) & 1) * WG_RAW_BUF;
         float4 b = *reinterpret_cast<const float4*>(ubc);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
@@ -178,6 +199,13 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
             float4 bn = b;
 #if WG_ABLATE != 4
             if (xi + 1 < 16) bn = *reinterpret_cast<const float4*>(ubc + (xi + 1) * (2 * 64 * 4));
+#endif
+            dn[xi] = *reinterpret_cast<const float2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
+#if WG_ABLATE < 3
+            // the next chunk's weights (8 DMA pieces) and the raw tile after next (2 loads) are issued one per xi, so the
+            // vector-memory queue never makes the wave wait in front of its MFMAs
+            if (xi < 8) { if (c + 1 < WG_NCHUNK) dma_u_piece(c + 1, (c + 1) & 1, xi); }
+            else if (xi == 8) { if (c + 2 < WG_NCHUNK) fetch_raw(c + 2); }
 #endif
 #if WG_ABLATE == 1
             acc[xi][0][0] += v[xi].x * b.x + v[xi].y * b.y;
@@ -189,18 +217,20 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.w, acc[xi][1], 0, 0, 0);
 #endif
             b = bn;
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of xi+1 ...
+            if (xi < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // one DMA piece ...
+            else if (xi == 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // ... or the two raw loads
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the B read of xi+1 and one patch read ...
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then the four MFMAs of xi
         }
         __builtin_amdgcn_sched_barrier(0);
+        WG_MARK();
 #if WG_ABLATE < 3
-        if (c + 1 < WG_NCHUNK) store_u((c + 1) & 1);          // the other buffer: nobody reads it before the barrier
-        __syncthreads();                                      // U(c+1) visible; every wave is done with Us[c&1] (and Raw if c is odd)
-        if ((c & 1) == 1 && c + 1 < WG_NCHUNK) {              // quarter boundary: one extra barrier per two chunks
-            store_raw();
-            __syncthreads();
-        }
+        if (c + 1 < WG_NCHUNK) transform();                   // V(c+1) from the patch read during the MFMAs
+        if (c + 2 < WG_NCHUNK) store_raw(c & 1);              // raw(c+2) into the tile V(c) came from
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of U(c+1) has landed in LDS
+        __syncthreads();                                      // U(c+1), raw(c+2) visible; every wave is done with Us[c&1]
 #endif
+        WG_MARK();
     }
 
     // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; bias; ReLU; store
@@ -235,6 +265,7 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
             }
         }
     }
+    WG_MARK();                                                // last: epilogue issued
 }
 
 }  // namespace deqsci
