@@ -37,7 +37,9 @@ constexpr int WG_NCHUNK = 64 / WG_CK;
 #define WG_ABLATE 0
 #endif
 
-// Block = 32 tiles x all 64 output channels, 4 wavefronts, TWO blocks resident per CU (<= 80 KB LDS, <= 256 registers).
+// Block = 64 tiles (8 x 8) x all 64 output channels, 8 wavefronts (512 threads), ONE block per CU at 2 waves per SIMD:
+// per-CU weight traffic is what bounds this kernel (the global -> LDS path sustains ~25 GB/s per CU), and a 64-tile block
+// streams each 32 KB weight chunk once for twice the outputs of the earlier 32-tile / two-blocks-per-CU version.
 // Wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
 // v_mfma_f32_16x16x4_f32 (128 registers), and holds every value the output transform of its (tile, cout) needs.
 //
@@ -53,14 +55,15 @@ constexpr int WG_NCHUNK = 64 / WG_CK;
 //     the A operands never go back to LDS, and no LDS read latency is exposed (measured: the un-pipelined input
 //     transform was 24 % of a block's lifetime).
 constexpr int WG_RAW_PS = 10;                 // floats per staged pixel (8 channels + 2)
-constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 10;
+constexpr int WG_THREADS = 512;               // 8 wavefronts: wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32)
+constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 18;  // 8 x 8 tiles = 16 x 16 output pixels (+ halo)
 constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 190 floats per staged pixel row (one spare pixel for the shift)
 constexpr int WG_RAW_BUF = WG_RAW_ROWS * WG_RAW_RS;           // 1900 floats = 7.6 KB
 constexpr int WG_U_CHUNK = 16 * 2 * 64 * 4;   // floats of one weight chunk in LDS (32 KB)
 
 __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
 
-__global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
+__global__ __launch_bounds__(WG_THREADS, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                 const float* __restrict__ bias, float* __restrict__ y,
                                                                 int H, int W, int relu) {
     __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
@@ -68,17 +71,17 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wt = wave >> 1, wn = wave & 1;
     const int n = blockIdx.z;
-    const int ty0 = blockIdx.y * 4, tx0 = blockIdx.x * 8;          // tile coordinates of the block
+    const int ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 8;          // tile coordinates of the block
     const float* xn = x + (int64_t)n * H * W * 64;
     const int py0 = 2 * ty0 - 1, px0 = 2 * tx0 - 1;                // image coordinates of staged pixel (0,0)
 
-    // ---- raw staging role: chunk tile = 180 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 256
-    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 360
+    // ---- raw staging role: chunk tile = 324 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 512
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 648
     int roff[2], rdst[2];                                          // global element offset (clamped) / LDS float offset, -1 = idle
     bool rok[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int e = k * TB + tid;
+        const int e = k * WG_THREADS + tid;
         const int pix = e >> 1, q4 = e & 1;
         const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
         const int iy = py0 + pr, ix = px0 + pc;
@@ -107,14 +110,14 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
     };
     // ---- weight chunk: DMA global -> LDS, 8 x 1 KiB per wavefront, linear
     auto dma_u_piece = [&](int c, int buf, int j) {
-        const int blk = j * 4 + wave;                                                   // 1 KiB block of the 32 KB chunk
+        const int blk = j * 8 + wave;                                                   // 1 KiB block of the 32 KB chunk
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(Ug + (int64_t)c * WG_U_CHUNK + (blk * 64 + lane) * 4),
             (__attribute__((address_space(3))) void*)(Us + buf * WG_U_CHUNK + blk * 256), 16, 0, 0);
     };
     auto dma_u = [&](int c, int buf) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dma_u_piece(c, buf, j);
+        for (int j = 0; j < 4; ++j) dma_u_piece(c, buf, j);
     };
 
     f32x4 acc[16][2];
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
 #if WG_ABLATE < 3
             // the next chunk's weights (8 DMA pieces) and the raw tile after next (2 loads) are issued one per xi, so the
             // vector-memory queue never makes the wave wait in front of its MFMAs
-            if (xi < 8) { if (c + 1 < WG_NCHUNK) dma_u_piece(c + 1, (c + 1) & 1, xi); }
+            if (xi < 8 && (xi & 1) == 0) { if (c + 1 < WG_NCHUNK) dma_u_piece(c + 1, (c + 1) & 1, xi >> 1); }
             else if (xi == 8) { if (c + 2 < WG_NCHUNK) fetch_raw(c + 2); }
 #endif
 #if WG_ABLATE == 1
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(TB, 2) void winograd_conv64_kernel(const float* __r
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.w, acc[xi][1], 0, 0, 0);
 #endif
             b = bn;
-            if (xi < 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // one DMA piece ...
-            else if (xi == 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);  // ... or the two raw loads
+            if (xi < 8 && (xi & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA piece ...
+            else if (xi == 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);              // ... or the two raw loads
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the B read of xi+1 and one patch read ...
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then the four MFMAs of xi
         }
@@ -280,8 +283,8 @@ static int winograd_impl(const float* x, const float* u_packed, const float* bia
     if (n > 65535 || H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)ceil_div(ceil_div(W, 2), 8), (unsigned)ceil_div(ceil_div(H, 2), 4), (unsigned)n);
-    hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(TB), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu);
+    const dim3 grid((unsigned)ceil_div(ceil_div(W, 2), 8), (unsigned)ceil_div(ceil_div(H, 2), 8), (unsigned)n);
+    hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(WG_THREADS), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu);
     return launch_status();
 }
 

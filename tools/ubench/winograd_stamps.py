@@ -6,7 +6,7 @@ from deqsci_amd import _hip
 N, H, W = 64, 128, 128
 x = torch.randn(N, 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
 U = _hip.pack_winograd_weights(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
-nblk = (W // 16) * (H // 8) * N
+nblk = (W // 16) * (H // 16) * N
 stamps = torch.zeros(nblk * 40, dtype=torch.int64, device="cuda")
 out = torch.empty_like(x)
 for _ in range(3):
