@@ -86,6 +86,19 @@ __device__ __forceinline__ double wave_sum(double v) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Compute units of the current device (cached per device; a plain attribute query: no allocation, no synchronisation).
+inline int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cached[dev] = v;
+    }
+    return cached[dev];
+}
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : static_cast<int>(e);

@@ -8,123 +8,154 @@
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      F(2x2,3x3): 4x4 input patch d (stride 2) -> 2x2 outputs
 //
-// One block = 4 x 8 Winograd tiles (8 x 16 output pixels) x all 64 output channels.  The 16 transform positions
-// xi are 16 independent GEMMs  M[xi] (32 tiles x 64 cout) += V[xi] (32 x cin) U[xi] (cin x 64):
-//   * 4 wavefronts, each owning 16 tiles x 32 couts of every M[xi]: 32 accumulators of v_mfma_f32_16x16x4_f32
-//     (128 registers), two blocks per CU so that transform / barrier / epilogue time of one block is MFMA time
-//     of the other (a first version with 64-tile blocks, 32x32x2 MFMAs and one block per CU spent 57 % of its
-//     time outside the matrix pipe: tools/ubench/winograd_ablate.sh);
-//   * cin is consumed in chunks of 8: V[xi][tile][8] and U[xi][cout][8] live in LDS with a 12-float row
-//     stride (a 32-lane ds_read_b64 touches 64 distinct banks); lane quarter q = lane>>4 reads its cin
-//     {2q, 2q+1} with ONE ds_read_b64 per operand and feeds 2 MFMAs (the K index of an MFMA is free to mean
-//     "cin 2q+s" as long as A and B agree);
-//   * the next chunk's 4x4 input patches (one channel per lane) and pre-transformed weights are fetched into
-//     registers BEFORE the MFMA phase of the current chunk, so global latency hides under the MFMAs;
-//   * the 16 values A^T M A needs for one (tile, cout) sit in the same accumulator slot of the 16 M[xi], so the
-//     output transform, bias and ReLU are pure per-lane register work.
+// Work unit ("block tile") = 4 x 8 Winograd tiles (8 x 16 output pixels) x all 64 output channels.  The 16 transform
+// positions xi are 16 independent GEMMs  M[xi] (64 cout x 32 tiles) += U[xi] (64 x cin) V[xi] (cin x 32):
+//   * PERSISTENT workgroups of 4 wavefronts, two per CU (<= 80 KB LDS, <= 256 registers), each walking a contiguous run
+//     of block tiles of "its" XCD (neighbouring tiles share halo pixels in that XCD's L2).  Wave w owns tiles
+//     [16*(w>>1), +16) x couts [32*(w&1), +32) of every M[xi]: 16 x 2 accumulators of v_mfma_f32_16x16x4_f32 (128
+//     registers) that hold every value the output transform of its (tile, cout) needs.
+//   * the 64 input channels are consumed in chunks of 8, and the chunk pipeline runs ACROSS block tiles (chunk g of
+//     the workgroup = chunk g&7 of its (g>>3)-th tile): one stage = MFMA phase + input transform + ONE barrier, with
+//       - weights U((g+1)&7): host-packed in MFMA-lane order, copied global -> LDS by the DMA path
+//         (global_load_lds_dwordx4: no registers, no ds_write) into the other of two 32 KB buffers; a lane's weight
+//         operands for one xi are ONE conflict-free ds_read_b128 feeding 4 MFMAs;
+//       - raw input of chunk g+2 (10 x 18 pixels x 8 channels, possibly of the NEXT block tile): two coalesced float4 per
+//         lane into registers, written to the other of two 7.6 KB LDS tiles after the MFMAs (pixel stride 10 floats,
+//         pixel rows 2,3,6,7 shifted by one pixel: the per-lane patch reads hit 32 distinct banks);
+//       - each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch of chunk g+1 while the
+//         MFMAs of chunk g run and turns it into V = B^T d B (its operands for all 16 xi) in registers afterwards;
+//     so a block tile has no prologue of its own: its first two raw chunks and first weight chunk are in flight while the
+//     previous tile finishes, and only the output transform sits between two tiles' MFMAs (the co-resident workgroup's
+//     MFMAs fill that gap).
+//   * the matrix core gets the WEIGHTS as its A operand: D rows (4 per lane, consecutive registers) are 4 consecutive
+//     couts of one tile, so the epilogue (Y = A^T M A, bias, ReLU) is per-lane register work ending in 16-byte stores.
+//
+// Three things the compiler must not be allowed to do here, all measured (tools/ubench/winograd_stamps.py):
+//   * __syncthreads() is a fence + s_barrier and the fence becomes `s_waitcnt vmcnt(0)`: it would drain the loads and
+//     DMA pieces deliberately left in flight across the barrier -> wg_lds_barrier() (lgkmcnt only);
+//   * after __builtin_amdgcn_global_load_lds hipcc cannot tell which LDS bytes the DMA writes and puts vmcnt(0) in front
+//     of the next ds_read of ANY LDS array -> the DMA is inline asm and its wait is placed by hand;
+//   * a register load hipcc believes pending on some path makes it wait before the registers' next use - and with it for
+//     every younger DMA piece -> raw_landed() tells it, on every path, that the raw loads are complete.
 #include "common.hpp"
 #include <hip/hip_ext.h>
+#include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is named as a clobber of the LDS-DMA asm below, on purpose
 
 namespace deqsci {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int WG_CK = 8;            // input channels per chunk
-
+constexpr int WG_CK = 8;                      // input channels per chunk
 constexpr int WG_NCHUNK = 64 / WG_CK;
-
-#ifndef WG_ABLATE        // tuning harness only (tools/ubench/winograd_ablate.sh): 1 = no MFMA, 2 = no global loads/transform
-#define WG_ABLATE 0
-#endif
-
-// Block = 64 tiles (8 x 8) x all 64 output channels, 8 wavefronts (512 threads), ONE block per CU at 2 waves per SIMD:
-// per-CU weight traffic is what bounds this kernel (the global -> LDS path sustains ~25 GB/s per CU), and a 64-tile block
-// streams each 32 KB weight chunk once for twice the outputs of the earlier 32-tile / two-blocks-per-CU version.
-// Wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32) for all 16 transform positions: 16 x 2 accumulators of
-// v_mfma_f32_16x16x4_f32 (128 registers), and holds every value the output transform of its (tile, cout) needs.
-//
-// The 64 input channels are consumed in 8 chunks of 8.  A chunk is one software-pipeline stage with ONE barrier:
-//   * weights U(c+1): host-packed in MFMA-lane order, copied global -> LDS by the DMA path (global_load_lds_dwordx4,
-//     no registers, no ds_write) into the other of two 32 KB buffers; a lane's B operands for one xi are then ONE
-//     conflict-free ds_read_b128 feeding 4 MFMAs;
-//   * raw input of chunk c+2 (10 x 18 pixels x 8 channels): two coalesced float4 per lane into registers at the top of
-//     the stage, written to the other of two 7.6 KB LDS tiles after the MFMAs (pixel stride 10 floats, pixel rows
-//     2,3,6,7 shifted by one pixel: the per-lane patch reads hit 32 distinct banks);
-//   * each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch of chunk c+1 while the
-//     MFMAs of chunk c run, and turns it into V = B^T d B (its A operands for all 16 xi) in registers afterwards:
-//     the A operands never go back to LDS, and no LDS read latency is exposed (measured: the un-pipelined input
-//     transform was 24 % of a block's lifetime).
+constexpr int WG_TB = 256;                    // 4 wavefronts
 constexpr int WG_RAW_PS = 10;                 // floats per staged pixel (8 channels + 2)
-constexpr int WG_THREADS = 512;               // 8 wavefronts: wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32)
-constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 18;  // 8 x 8 tiles = 16 x 16 output pixels (+ halo)
+constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 10;
 constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 190 floats per staged pixel row (one spare pixel for the shift)
 constexpr int WG_RAW_BUF = WG_RAW_ROWS * WG_RAW_RS;           // 1900 floats = 7.6 KB
 constexpr int WG_U_CHUNK = 16 * 2 * 64 * 4;   // floats of one weight chunk in LDS (32 KB)
 
 __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
 
-__global__ __launch_bounds__(WG_THREADS, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
-                                                                const float* __restrict__ bias, float* __restrict__ y,
-                                                                int H, int W, int relu) {
+// Workgroup barrier that orders LDS traffic only (see the header).
+__device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ uint32_t wg_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// tiles_x / tiles_y: block tiles per image row / column; n_tiles = images * tiles_x * tiles_y
+__global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
+                                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                                   int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
     __shared__ __attribute__((aligned(16))) float Raw[2 * WG_RAW_BUF];            // 2 x raw chunk tile                    15.2 KB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)wg_uniform((uint32_t)(tid >> 6));          // in an SGPR: the DMA bookkeeping is scalar code
     const int wt = wave >> 1, wn = wave & 1;
-    const int n = blockIdx.z;
-    const int ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 8;          // tile coordinates of the block
-    const float* xn = x + (int64_t)n * H * W * 64;
-    const int py0 = 2 * ty0 - 1, px0 = 2 * tx0 - 1;                // image coordinates of staged pixel (0,0)
 
-    // ---- raw staging role: chunk tile = 324 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 512
-    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 648
-    int roff[2], rdst[2];                                          // global element offset (clamped) / LDS float offset, -1 = idle
-    bool rok[2];
+    // ---- the run of block tiles of this workgroup: XCD k (workgroups k, k+8, ...) owns tiles [k*per_xcd, (k+1)*per_xcd)
+    int t_first, t_step, t_end;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((nb & 7) == 0) {
+            const int per_xcd = (n_tiles + 7) >> 3;
+            t_first = (b & 7) * per_xcd + (b >> 3);
+            t_step = nb >> 3;
+            t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
+        } else { t_first = b; t_step = nb; t_end = n_tiles; }
+    }
+    if (t_first >= t_end) return;
+
+    // ---- raw staging role: chunk tile = 180 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 256
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 360
+    int rdst[2], rpr[2], rpc[2];                                   // LDS float offset (-1 = idle), staged pixel row / column
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int e = k * WG_THREADS + tid;
+        const int e = k * WG_TB + tid;
         const int pix = e >> 1, q4 = e & 1;
-        const int pr = pix / WG_RAW_COLS, pc = pix - pr * WG_RAW_COLS;
-        const int iy = py0 + pr, ix = px0 + pc;
-        rok[k] = e < RAW_F4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-        roff[k] = (cy * W + cx) * 64 + 4 * q4;
-        rdst[k] = e < RAW_F4 ? pr * WG_RAW_RS + (pc + wg_row_shift(pr)) * WG_RAW_PS + 4 * q4 : -1;
+        rpr[k] = pix / WG_RAW_COLS;
+        rpc[k] = pix - rpr[k] * WG_RAW_COLS;
+        rdst[k] = e < RAW_F4 ? rpr[k] * WG_RAW_RS + (rpc[k] + wg_row_shift(rpr[k])) * WG_RAW_PS + 4 * q4 : -1;
     }
-    float4 rawv[2];
-    auto fetch_raw = [&](int c) {                                  // clamped address + zero-select: no branches
+    // fetch stream state: addresses of the block tile that chunk g+2 belongs to
+    uint32_t roff[2];                                              // global byte offset (clamped into the image)
+    bool rok[2];                                                   // pixel inside the image (else zero)
+    bool border = true;                                            // (uniform) some staged pixel of the tile is outside the image
+    const float* xf = x;                                           // image base of the fetch stream
+    auto set_fetch_tile = [&](int t) {
+        const int per_img = tiles_x * tiles_y;
+        const int n = t / per_img, r = t - n * per_img;
+        const int by = r / tiles_x, bx = r - by * tiles_x;
+        xf = x + (int64_t)n * H * W * 64;
+        const int py0 = 8 * by - 1, px0 = 16 * bx - 1;             // image coordinates of staged pixel (0,0)
+        border = py0 < 0 || px0 < 0 || py0 + WG_RAW_ROWS > H || px0 + WG_RAW_COLS > W;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            float4 v = ld4(xn + roff[k] + c * WG_CK);
-            if (!rok[k]) v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            rawv[k] = v;
+            const int iy = py0 + rpr[k], ix = px0 + rpc[k];
+            rok[k] = rdst[k] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            roff[k] = (uint32_t)(((cy * W + cx) * 64 + 4 * (tid & 1)) * 4);
         }
     };
+    float4 rawv[2];
+    // clamped address, no branches; NOTHING here may consume the loaded value (that would park the wave on the memory
+    // latency): out-of-image pixels are zeroed in store_raw
+    auto fetch_raw_k = [&](int c, int k) {
+        rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * WG_CK) + roff[k]);
+    };
     auto store_raw = [&](int buf) {
+        if (border) {                                              // uniform branch: interior tiles skip the selects
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-            if (rdst[k] >= 0) {
-                float* dst = Raw + buf * WG_RAW_BUF + rdst[k];                          // 8-B aligned (pixel stride 40 B)
-                *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
-                *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
-            }
-    };
-    // ---- weight chunk: DMA global -> LDS, 8 x 1 KiB per wavefront, linear
-    auto dma_u_piece = [&](int c, int buf, int j) {
-        const int blk = j * 8 + wave;                                                   // 1 KiB block of the 32 KB chunk
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(Ug + (int64_t)c * WG_U_CHUNK + (blk * 64 + lane) * 4),
-            (__attribute__((address_space(3))) void*)(Us + buf * WG_U_CHUNK + blk * 256), 16, 0, 0);
-    };
-    auto dma_u = [&](int c, int buf) {
+            for (int k = 0; k < 2; ++k)
+                if (rdst[k] >= 0) {
+                    float* dst = Raw + buf * WG_RAW_BUF + rdst[k];                      // 8-B aligned (pixel stride 40 B)
+                    const float4 val = rok[k] ? rawv[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    *reinterpret_cast<float2*>(dst) = make_float2(val.x, val.y);
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(val.z, val.w);
+                }
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma_u_piece(c, buf, j);
+            for (int k = 0; k < 2; ++k)
+                if (rdst[k] >= 0) {
+                    float* dst = Raw + buf * WG_RAW_BUF + rdst[k];
+                    *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
+                }
+        }
+    };
+    auto raw_landed = [&]() { asm volatile("" ::"v"(rawv[0].x), "v"(rawv[1].x)); };
+    // ---- weight chunk: DMA global -> LDS, 8 x 1 KiB per wavefront, linear; scalar base + per-lane offset
+    const uint32_t us_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
+    const uint32_t dma_voff = (uint32_t)((wave * 64 + lane) * 16);                      // bytes
+    auto dma_u_piece = [&](int c, int buf, int j) {                                     // 1 KiB block j*4 + wave of chunk c
+        const uint64_t g = (uint64_t)(Ug + (int64_t)c * WG_U_CHUNK + j * (4 * 256));
+        const uint64_t gs = ((uint64_t)wg_uniform((uint32_t)(g >> 32)) << 32) | wg_uniform((uint32_t)g);
+        const uint32_t ldst = wg_uniform(us_lds + (uint32_t)((buf * WG_U_CHUNK + (j * 4 + wave) * 256) * 4));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst), "v"(dma_voff), "s"(gs) : "memory", "m0");
     };
 
-    f32x4 acc[16][2];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[xi][j] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 acc[16][2];                                        // written, not accumulated, by the first chunk of every tile
 
     // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16*wt + i and channels {2q, 2q+1} of the chunk
     const int mi = lane & 15, mq = lane >> 4;
@@ -135,7 +166,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void winograd_conv64_kernel(const fl
         const int r = 2 * (tl_a >> 3) + pr;
         prow[pr] = r * WG_RAW_RS + (2 * (tl_a & 7) + wg_row_shift(r)) * WG_RAW_PS + 2 * mq;
     }
-    const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's B operands of xi = 0 in buffer 0
+    const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's weight operands of xi = 0 in buffer 0
 
     // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  V = B^T d B
     float2 dn[16], v[16];
@@ -166,109 +197,162 @@ __global__ __launch_bounds__(WG_THREADS, 2) void winograd_conv64_kernel(const fl
         }
     };
 
+    // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; ReLU; 16-byte stores.  The bias is already inside:
+    // the coefficient of M[1][1] (xi = 5) is 1 in all four outputs, so the tile's first MFMA of xi = 5 starts from the
+    // bias instead of zero.  All arithmetic on register PAIRS (v_pk_add_f32): non-MFMA vector instructions are what
+    // bounds this kernel once the matrix pipe is fed (tools/ubench/mfma_valu_mix.hip).
+    // D layout of the 16x16 MFMA with the weights as A operand: col = lane&15 (tile), row = 4*(lane>>4) + reg (cout)
+    auto epilogue = [&](int t) {
+        const int per_img = tiles_x * tiles_y;
+        const int n = t / per_img, r = t - n * per_img;
+        const int by = r / tiles_x, bx = r - by * tiles_x;
+        float* yn = y + (int64_t)n * H * W * 64;
+        const int tl = 16 * wt + (lane & 15);
+        const int oy = 2 * (4 * by + (tl >> 3)), ox = 2 * (8 * bx + (tl & 7));
+        float* o = yn + ((int64_t)oy * W + ox) * 64 + 32 * wn + 4 * (lane >> 4);
+        const bool in0 = oy < H && ox < W, inx = ox + 1 < W, iny = oy + 1 < H;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x2 o00[2], o01[2], o10[2], o11[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const f32x2 m0 = {acc[b][j][2 * h], acc[b][j][2 * h + 1]};
+                    const f32x2 m1 = {acc[4 + b][j][2 * h], acc[4 + b][j][2 * h + 1]};
+                    const f32x2 m2 = {acc[8 + b][j][2 * h], acc[8 + b][j][2 * h + 1]};
+                    const f32x2 m3 = {acc[12 + b][j][2 * h], acc[12 + b][j][2 * h + 1]};
+                    s0[b] = (m0 + m1) + m2;
+                    s1[b] = (m1 - m2) - m3;
+                }
+                o00[h] = (s0[0] + s0[1]) + s0[2];
+                o01[h] = (s0[1] - s0[2]) - s0[3];
+                o10[h] = (s1[0] + s1[1]) + s1[2];
+                o11[h] = (s1[1] - s1[2]) - s1[3];
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        o00[h][e] = fmaxf(o00[h][e], 0.0f); o01[h][e] = fmaxf(o01[h][e], 0.0f);
+                        o10[h][e] = fmaxf(o10[h][e], 0.0f); o11[h][e] = fmaxf(o11[h][e], 0.0f);
+                    }
+                }
+            }
+            if (in0) {
+                float* oj = o + 16 * j;
+                st4(oj, make_float4(o00[0][0], o00[0][1], o00[1][0], o00[1][1]));
+                if (inx) st4(oj + 64, make_float4(o01[0][0], o01[0][1], o01[1][0], o01[1][1]));
+                if (iny) {
+                    st4(oj + (int64_t)W * 64, make_float4(o10[0][0], o10[0][1], o10[1][0], o10[1][1]));
+                    if (inx) st4(oj + (int64_t)W * 64 + 64, make_float4(o11[0][0], o11[0][1], o11[1][0], o11[1][1]));
+                }
+            }
+        }
+    };
+
 #ifdef WG_STAMP
-    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias)) +
-                                    (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 40;
+#ifndef WG_STAMP_TID
+#define WG_STAMP_TID 0
+#endif
+    unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias)) + (size_t)blockIdx.x * 40;
+    __shared__ unsigned long long stamp_lds[40];              // stamps go to LDS: a global store would count in vmcnt
     int stamp_i = 0;
-#define WG_MARK() do { if (tid == 0) stamp_out[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#define WG_MARK() do { if (stamp_i < 38) { if (tid == WG_STAMP_TID) stamp_lds[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } } while (0)
+    bias = nullptr;
 #else
 #define WG_MARK() do { } while (0)
 #endif
     WG_MARK();                                                // 0: kernel entry
-    // ---- prologue: U(0), raw(0), raw(1) staged; V(0) computed
-    dma_u(0, 0);
-    fetch_raw(0);
+    // ---- prologue (once per workgroup): bias, U(0), raw(0), raw(1) staged; V(0) computed; fetch stream at chunk 2
+    if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.0f;
+    set_fetch_tile(t_first);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_u_piece(0, 0, j);
+    fetch_raw_k(0, 0); fetch_raw_k(0, 1);
     store_raw(0);
-    fetch_raw(1);
+    fetch_raw_k(1, 0); fetch_raw_k(1, 1);
     store_raw(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    raw_landed();
     __syncthreads();
     read_patch(0);
     transform();
     WG_MARK();                                                // 1: prologue done
-#pragma unroll 1
-    for (int c = 0; c < WG_NCHUNK; ++c) {
-        // entry: Us[c&1] = U(c), Raw[(c+1)&1] = raw(c+1) visible; v = V(c) in registers
-        __builtin_amdgcn_sched_barrier(0);
+    int t_fetch = t_first;                                    // tile of the fetch stream
+    // One pipeline stage = chunk c of the current tile.  PAR = c&1 selects the LDS buffers (compile-time: every LDS address
+    // of the stage is an immediate offset), FIRST = chunk 0: the accumulators are written from zero / the bias.
+    auto stage = [&](auto par_c, auto first_c, int c, int t_cur) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        // entry: Us[PAR] = U(c), Raw[PAR^1] = raw(c+1) visible; v = V(c) in registers
         WG_MARK();
-        // ---- MFMA phase: per xi ONE ds_read_b128 (B operands) and ONE ds_read_b64 (a patch element of the next chunk)
-        // are issued ahead of the four MFMAs of xi; consecutive MFMAs alternate accumulators (40-cycle dependent latency)
-        const float* ubc = ub + (c & 1) * WG_U_CHUNK;
-        const float* ppn = Raw + ((c + 1) & 1) * WG_RAW_BUF;
-        float4 b = *reinterpret_cast<const float4*>(ubc);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        // ---- MFMA phase.  Hand-ordered: everything that is not an MFMA sits right behind the FIRST of the four MFMAs of a
+        // transform position.  Chunk indices past the end of the run are clamped instead of branched around (a duplicate
+        // fetch of valid memory nobody reads).
+        const float* ubc = ub + PAR * WG_U_CHUNK;
+        const float* ppn = Raw + (PAR ^ 1) * WG_RAW_BUF;
+        const int cf = (c + 2) & 7;                           // chunk of the fetch stream within its tile
+        const int cu = (c + 1) & 7;                           // weight chunk to stage (into Us[PAR^1])
+        f32x4 init5[2];
+        if (FIRST) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) init5[j] = *reinterpret_cast<const f32x4*>(bias_s + 32 * wn + 16 * j + 4 * (lane >> 4));
+        }
+        float4 bq[3];
+        bq[0] = *reinterpret_cast<const float4*>(ubc);
+        bq[1] = *reinterpret_cast<const float4*>(ubc + 2 * 64 * 4);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            float4 bn = b;
-#if WG_ABLATE != 4
-            if (xi + 1 < 16) bn = *reinterpret_cast<const float4*>(ubc + (xi + 1) * (2 * 64 * 4));
-#endif
+            if (xi + 2 < 16) bq[(xi + 2) % 3] = *reinterpret_cast<const float4*>(ubc + (xi + 2) * (2 * 64 * 4));
             dn[xi] = *reinterpret_cast<const float2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
-#if WG_ABLATE < 3
-            // the next chunk's weights (8 DMA pieces) and the raw tile after next (2 loads) are issued one per xi, so the
-            // vector-memory queue never makes the wave wait in front of its MFMAs
-            if (xi < 8 && (xi & 1) == 0) { if (c + 1 < WG_NCHUNK) dma_u_piece(c + 1, (c + 1) & 1, xi >> 1); }
-            else if (xi == 8) { if (c + 2 < WG_NCHUNK) fetch_raw(c + 2); }
-#endif
-#if WG_ABLATE == 1
-            acc[xi][0][0] += v[xi].x * b.x + v[xi].y * b.y;
-            acc[xi][1][0] += v[xi].x * b.z + v[xi].y * b.w;
-#else
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].x, b.x, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].x, b.z, acc[xi][1], 0, 0, 0);
-            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.y, acc[xi][0], 0, 0, 0);
-            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[xi].y, b.w, acc[xi][1], 0, 0, 0);
-#endif
-            b = bn;
-            if (xi < 8 && (xi & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // one DMA piece ...
-            else if (xi == 8) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);              // ... or the two raw loads
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // the B read of xi+1 and one patch read ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... then the four MFMAs of xi
+            const float4 b = bq[xi % 3];
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[xi].x, FIRST ? (xi == 5 ? init5[0] : zero) : acc[xi][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (xi < 8) dma_u_piece(cu, PAR ^ 1, xi);         // weights first: they are needed one stage from now,
+            else if (xi == 8) fetch_raw_k(cf, 0);             // the raw chunk two stages from now
+            else if (xi == 9) fetch_raw_k(cf, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, v[xi].x, FIRST ? (xi == 5 ? init5[1] : zero) : acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, v[xi].y, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, v[xi].y, acc[xi][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         WG_MARK();
-#if WG_ABLATE < 3
-        if (c + 1 < WG_NCHUNK) transform();                   // V(c+1) from the patch read during the MFMAs
-        if (c + 2 < WG_NCHUNK) store_raw(c & 1);              // raw(c+2) into the tile V(c) came from
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of U(c+1) has landed in LDS
-        __syncthreads();                                      // U(c+1), raw(c+2) visible; every wave is done with Us[c&1]
-#endif
+        transform();                                          // V(c+1) from the patch read during the MFMAs
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // raw(c+2) in registers, this wave's part of U(c+1) in LDS
+        raw_landed();
+        store_raw(PAR);                                       // raw(c+2) into the tile V(c) came from
+        wg_lds_barrier();                                     // U(c+1), raw(c+2) visible; every wave is done with Us[PAR]
         WG_MARK();
-    }
-
-    // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; bias; ReLU; store
-    // C/D layout of the 16x16 MFMA: col = lane&15 (cout), row = 4*(lane>>4) + reg (tile)
-    float* yn = y + (int64_t)n * H * W * 64;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int cout = 32 * wn + 16 * j + (lane & 15);
-        const float bv = bias ? bias[cout] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tl = 16 * wt + 4 * (lane >> 4) + r;
-            const int oy = 2 * (ty0 + (tl >> 3)), ox = 2 * (tx0 + (tl & 7));
-            float s0[4], s1[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float m0 = acc[b][j][r], m1 = acc[4 + b][j][r], m2 = acc[8 + b][j][r], m3 = acc[12 + b][j][r];
-                s0[b] = (m0 + m1) + m2;
-                s1[b] = (m1 - m2) - m3;
-            }
-            float y00 = (s0[0] + s0[1]) + s0[2] + bv, y01 = (s0[1] - s0[2]) - s0[3] + bv;
-            float y10 = (s1[0] + s1[1]) + s1[2] + bv, y11 = (s1[1] - s1[2]) - s1[3] + bv;
-            if (relu) { y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f); y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f); }
-            if (oy < H && ox < W) {
-                float* o = yn + ((int64_t)oy * W + ox) * 64 + cout;
-                o[0] = y00;
-                if (ox + 1 < W) o[64] = y01;
-                if (oy + 1 < H) {
-                    o[(int64_t)W * 64] = y10;
-                    if (ox + 1 < W) o[(int64_t)W * 64 + 64] = y11;
-                }
-            }
+        if (c == 5) {                                         // chunks c+3.. of the fetch stream belong to the next tile
+            if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
+            set_fetch_tile(t_fetch);
+        } else if (c == 7) {
+            epilogue(t_cur);                                  // its stores drain under the next tile's MFMAs
+        }
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+        stage(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
+        stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, 1, t_cur);
+#pragma unroll 1
+        for (int c = 2; c < WG_NCHUNK; c += 2) {
+            stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, c, t_cur);
+            stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c + 1, t_cur);
         }
     }
-    WG_MARK();                                                // last: epilogue issued
+    WG_MARK();
+#ifdef WG_STAMP
+    if (tid == WG_STAMP_TID) {
+        for (int i = 0; i < stamp_i; ++i) stamp_out[i] = stamp_lds[i];
+        stamp_out[38] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        stamp_out[39] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave/simd/cu/sh/se
+    }
+#endif
 }
 
 }  // namespace deqsci
@@ -280,11 +364,16 @@ static int winograd_impl(const float* x, const float* u_packed, const float* bia
                          int relu, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (!x || !u_packed || !y) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
-    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
+    if (H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(ceil_div(W, 2), 8), tiles_y = ceil_div(ceil_div(H, 2), 4);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W > (int64_t)INT32_MAX / 64) return DEQSCI_ERR_UNSUPPORTED;   // 32-bit offsets
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)ceil_div(ceil_div(W, 2), 8), (unsigned)ceil_div(ceil_div(H, 2), 8), (unsigned)n);
-    hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(WG_THREADS), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu);
+    const int64_t resident = 2 * (int64_t)num_cus();          // two workgroups per CU, persistent
+    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(WG_TB), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu,
+                          (int)tiles_x, (int)tiles_y, (int)n_tiles);
     return launch_status();
 }
 
