@@ -61,12 +61,25 @@ __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
 // Workgroup barrier that orders LDS traffic only (see the header).
 __device__ __forceinline__ void wg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// a - b on a register pair in ONE instruction (hipcc splits the vector subtraction of the epilogue into two v_sub_f32)
+__device__ __forceinline__ f32x2 wg_pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t wg_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// tiles_x / tiles_y: block tiles per image row / column; n_tiles = images * tiles_x * tiles_y
+// Exact t / d for 0 <= t < 2^31 as a multiply and a shift (host: wg_magic): the tile decode is scalar code without the
+// ~40-instruction software division, which matters because an instruction here costs a full MFMA slot of the sibling wave.
+__device__ __forceinline__ int wg_div(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
+
+// tiles_x / tiles_y: block tiles per image row / column; n_tiles = images * tiles_x * tiles_y;
+// (mg_img, sh_img) / (mg_tx, sh_tx): division magic for tiles_x * tiles_y and tiles_x
 __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
-                                                                   int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles) {
+                                                                   int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles,
+                                                                   uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
     __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
     __shared__ __attribute__((aligned(16))) float Raw[2 * WG_RAW_BUF];            // 2 x raw chunk tile                    15.2 KB
     __shared__ __attribute__((aligned(16))) float bias_s[64];
@@ -104,9 +117,8 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     bool border = true;                                            // (uniform) some staged pixel of the tile is outside the image
     const float* xf = x;                                           // image base of the fetch stream
     auto set_fetch_tile = [&](int t) {
-        const int per_img = tiles_x * tiles_y;
-        const int n = t / per_img, r = t - n * per_img;
-        const int by = r / tiles_x, bx = r - by * tiles_x;
+        const int n = wg_div(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = wg_div(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         xf = x + (int64_t)n * H * W * 64;
         const int py0 = 8 * by - 1, px0 = 16 * bx - 1;             // image coordinates of staged pixel (0,0)
         border = py0 < 0 || px0 < 0 || py0 + WG_RAW_ROWS > H || px0 + WG_RAW_COLS > W;
@@ -145,14 +157,31 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
         }
     };
     auto raw_landed = [&]() { asm volatile("" ::"v"(rawv[0].x), "v"(rawv[1].x)); };
-    // ---- weight chunk: DMA global -> LDS, 8 x 1 KiB per wavefront, linear; scalar base + per-lane offset
+    // ---- weight chunk: DMA global -> LDS.  The chunk is host-packed in LDS order, so it is a linear 32 KB copy: wave w
+    // moves bytes [8 KiB * w, +8 KiB) in 8 instructions that differ only in their immediate offset (which the hardware adds
+    // to the global AND the LDS address): one scalar base and one M0 value per chunk, no address arithmetic per piece.
     const uint32_t us_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
-    const uint32_t dma_voff = (uint32_t)((wave * 64 + lane) * 16);                      // bytes
-    auto dma_u_piece = [&](int c, int buf, int j) {                                     // 1 KiB block j*4 + wave of chunk c
-        const uint64_t g = (uint64_t)(Ug + (int64_t)c * WG_U_CHUNK + j * (4 * 256));
-        const uint64_t gs = ((uint64_t)wg_uniform((uint32_t)(g >> 32)) << 32) | wg_uniform((uint32_t)g);
-        const uint32_t ldst = wg_uniform(us_lds + (uint32_t)((buf * WG_U_CHUNK + (j * 4 + wave) * 256) * 4));
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldst), "v"(dma_voff), "s"(gs) : "memory", "m0");
+    const uint32_t dma_voff = (uint32_t)(wave * 8192 + lane * 16);                      // bytes
+    uint64_t dma_g = 0;                                                                 // global base of the chunk + 4096
+    uint32_t dma_m0 = 0;                                                                // LDS base of this wave's 8 KiB + 4096
+    auto dma_u_setup = [&](int c, int buf) {
+        const uint64_t g = (uint64_t)(Ug + (int64_t)c * WG_U_CHUNK) + 4096;
+        dma_g = ((uint64_t)wg_uniform((uint32_t)(g >> 32)) << 32) | wg_uniform((uint32_t)g);
+        dma_m0 = wg_uniform(us_lds + (uint32_t)(buf * WG_U_CHUNK * 4 + wave * 8192 + 4096));
+        asm volatile("s_mov_b32 m0, %0" ::"s"(dma_m0) : "m0");                         // nothing else in this kernel uses M0
+    };
+#define WG_DMA_PIECE(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF ::"v"(dma_voff), "s"(dma_g) : "memory")
+    auto dma_u_piece = [&](int j) {                                                     // KiB j of this wave's 8
+        switch (j) {
+            case 0: WG_DMA_PIECE(-4096); break;
+            case 1: WG_DMA_PIECE(-3072); break;
+            case 2: WG_DMA_PIECE(-2048); break;
+            case 3: WG_DMA_PIECE(-1024); break;
+            case 4: WG_DMA_PIECE(0); break;
+            case 5: WG_DMA_PIECE(1024); break;
+            case 6: WG_DMA_PIECE(2048); break;
+            default: WG_DMA_PIECE(3072); break;
+        }
     };
 
     f32x4 acc[16][2];                                        // written, not accumulated, by the first chunk of every tile
@@ -169,31 +198,31 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     const float* ub = Us + (wn * 64 + lane) * 4;             // this lane's weight operands of xi = 0 in buffer 0
 
     // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]:  V = B^T d B
-    float2 dn[16], v[16];
+    f32x2 dn[16], v[16];                                     // register pairs: every transform step is ONE v_pk_add_f32
     auto read_patch = [&](int buf) {
         const float* pp = Raw + buf * WG_RAW_BUF;
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr)
 #pragma unroll
-            for (int pc = 0; pc < 4; ++pc) dn[pr * 4 + pc] = *reinterpret_cast<const float2*>(pp + prow[pr] + pc * WG_RAW_PS);
+            for (int pc = 0; pc < 4; ++pc) dn[pr * 4 + pc] = *reinterpret_cast<const f32x2*>(pp + prow[pr] + pc * WG_RAW_PS);
     };
     auto transform = [&]() {
-        float2 w[16];
+        f32x2 w[16];
 #pragma unroll
         for (int pc = 0; pc < 4; ++pc) {                      // rows: w = B^T d (column pc of the patch)
-            const float2 d0 = dn[pc], d1 = dn[4 + pc], d2 = dn[8 + pc], d3 = dn[12 + pc];
-            w[pc] = make_float2(d0.x - d2.x, d0.y - d2.y);
-            w[4 + pc] = make_float2(d1.x + d2.x, d1.y + d2.y);
-            w[8 + pc] = make_float2(d2.x - d1.x, d2.y - d1.y);
-            w[12 + pc] = make_float2(d1.x - d3.x, d1.y - d3.y);
+            const f32x2 d0 = dn[pc], d1 = dn[4 + pc], d2 = dn[8 + pc], d3 = dn[12 + pc];
+            w[pc] = d0 - d2;
+            w[4 + pc] = d1 + d2;
+            w[8 + pc] = d2 - d1;
+            w[12 + pc] = d1 - d3;
         }
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {                      // columns: V = w B
-            const float2 w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
-            v[pr * 4] = make_float2(w0.x - w2.x, w0.y - w2.y);
-            v[pr * 4 + 1] = make_float2(w1.x + w2.x, w1.y + w2.y);
-            v[pr * 4 + 2] = make_float2(w2.x - w1.x, w2.y - w1.y);
-            v[pr * 4 + 3] = make_float2(w1.x - w3.x, w1.y - w3.y);
+            const f32x2 w0 = w[pr * 4], w1 = w[pr * 4 + 1], w2 = w[pr * 4 + 2], w3 = w[pr * 4 + 3];
+            v[pr * 4] = w0 - w2;
+            v[pr * 4 + 1] = w1 + w2;
+            v[pr * 4 + 2] = w2 - w1;
+            v[pr * 4 + 3] = w1 - w3;
         }
     };
 
@@ -203,9 +232,8 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // bounds this kernel once the matrix pipe is fed (tools/ubench/mfma_valu_mix.hip).
     // D layout of the 16x16 MFMA with the weights as A operand: col = lane&15 (tile), row = 4*(lane>>4) + reg (cout)
     auto epilogue = [&](int t) {
-        const int per_img = tiles_x * tiles_y;
-        const int n = t / per_img, r = t - n * per_img;
-        const int by = r / tiles_x, bx = r - by * tiles_x;
+        const int n = wg_div(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = wg_div(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         float* yn = y + (int64_t)n * H * W * 64;
         const int tl = 16 * wt + (lane & 15);
         const int oy = 2 * (4 * by + (tl >> 3)), ox = 2 * (8 * bx + (tl & 7));
@@ -224,12 +252,12 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
                     const f32x2 m2 = {acc[8 + b][j][2 * h], acc[8 + b][j][2 * h + 1]};
                     const f32x2 m3 = {acc[12 + b][j][2 * h], acc[12 + b][j][2 * h + 1]};
                     s0[b] = (m0 + m1) + m2;
-                    s1[b] = (m1 - m2) - m3;
+                    s1[b] = wg_pk_sub(wg_pk_sub(m1, m2), m3);
                 }
                 o00[h] = (s0[0] + s0[1]) + s0[2];
-                o01[h] = (s0[1] - s0[2]) - s0[3];
+                o01[h] = wg_pk_sub(wg_pk_sub(s0[1], s0[2]), s0[3]);
                 o10[h] = (s1[0] + s1[1]) + s1[2];
-                o11[h] = (s1[1] - s1[2]) - s1[3];
+                o11[h] = wg_pk_sub(wg_pk_sub(s1[1], s1[2]), s1[3]);
                 if (relu) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
@@ -266,8 +294,9 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // ---- prologue (once per workgroup): bias, U(0), raw(0), raw(1) staged; V(0) computed; fetch stream at chunk 2
     if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.0f;
     set_fetch_tile(t_first);
+    dma_u_setup(0, 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_u_piece(0, 0, j);
+    for (int j = 0; j < 8; ++j) dma_u_piece(j);
     fetch_raw_k(0, 0); fetch_raw_k(0, 1);
     store_raw(0);
     fetch_raw_k(1, 0); fetch_raw_k(1, 1);
@@ -298,6 +327,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #pragma unroll
             for (int j = 0; j < 2; ++j) init5[j] = *reinterpret_cast<const f32x4*>(bias_s + 32 * wn + 16 * j + 4 * (lane >> 4));
         }
+        dma_u_setup(cu, PAR ^ 1);
         float4 bq[3];
         bq[0] = *reinterpret_cast<const float4*>(ubc);
         bq[1] = *reinterpret_cast<const float4*>(ubc + 2 * 64 * 4);
@@ -305,13 +335,16 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             if (xi + 2 < 16) bq[(xi + 2) % 3] = *reinterpret_cast<const float4*>(ubc + (xi + 2) * (2 * 64 * 4));
-            dn[xi] = *reinterpret_cast<const float2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
+            if ((xi & 1) == 0) {                              // two patch elements per instruction (ds_read2_b64)
+                dn[xi] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
+                dn[xi + 1] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + ((xi & 3) + 1) * WG_RAW_PS);
+            }
             const float4 b = bq[xi % 3];
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             __builtin_amdgcn_sched_barrier(0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[xi].x, FIRST ? (xi == 5 ? init5[0] : zero) : acc[xi][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (xi < 8) dma_u_piece(cu, PAR ^ 1, xi);         // weights first: they are needed one stage from now,
+            if (xi < 8) dma_u_piece(xi);                      // weights first: they are needed one stage from now,
             else if (xi == 8) fetch_raw_k(cf, 0);             // the raw chunk two stages from now
             else if (xi == 9) fetch_raw_k(cf, 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -360,6 +393,14 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #ifndef WG_NO_CABI
 using namespace deqsci;
 
+// t / d == (t * mg) >> sh for every 0 <= t < 2^31:  sh = 31 + ceil(log2 d), mg = ceil(2^sh / d) < 2^32
+static void wg_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = 31 + s;
+    *mg = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+}
+
 static int winograd_impl(const float* x, const float* u_packed, const float* bias, float* y, int64_t n, int64_t H, int64_t W,
                          int relu, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (!x || !u_packed || !y) return DEQSCI_ERR_NULL;
@@ -372,8 +413,11 @@ static int winograd_impl(const float* x, const float* u_packed, const float* bia
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t resident = 2 * (int64_t)num_cus();          // two workgroups per CU, persistent
     const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    wg_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    wg_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
     hipExtLaunchKernelGGL(winograd_conv64_kernel, grid, dim3(WG_TB), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu,
-                          (int)tiles_x, (int)tiles_y, (int)n_tiles);
+                          (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);
     return launch_status();
 }
 

@@ -23,7 +23,12 @@ def timeit(fn, n=30, warm=5):
     return (time.perf_counter() - t0) / n * 1e6
 
 
-for (N, H, W) in ((64, 128, 128), (8, 128, 128), (64, 256, 256)):
+# `--shape N H W` runs one shape only (what the PMC script profiles)
+SHAPES = ((64, 128, 128), (8, 128, 128), (64, 256, 256))
+if "--shape" in sys.argv:
+    i = sys.argv.index("--shape")
+    SHAPES = (tuple(int(v) for v in sys.argv[i + 1:i + 4]),)
+for (N, H, W) in SHAPES:
     x = torch.randn(N, 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     w = (torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
     wcl = w.contiguous(memory_format=torch.channels_last)

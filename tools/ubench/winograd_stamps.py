@@ -34,6 +34,8 @@ if "--timeline" in sys.argv:
     t0 = blk[0, 0]
     for b in blk[:8]:
         print("simd/wave %d/%d" % ((b[39] >> 4) & 3, b[39] & 0xF), [int(v - t0) for v in b[:nz]])
+        ph = b[2:nz - 1]
+        print("   phases (mfma, other+barrier, gap):", [(int(ph[i + 1] - ph[i]), int(ph[i + 2] - ph[i + 1]), int(ph[i + 3] - ph[i + 2])) for i in range(0, len(ph) - 3, 3)])
 mf0 = int(os.environ.get("WG_MF0", 2)); per = int(os.environ.get("WG_PER", 3))
 tot = np.zeros(3); span = 0
 for k0 in keys:
