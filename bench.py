@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - headline metric of BASELINE.json on MI355X: reconstructed frames/s at 256x256x8,
-180 DEQ (Anderson) iterations, FFDNet denoiser, plus the HBM roofline of the fused
-Phi/Phi^T + GAP-update kernel and the reference algorithm timed on the host CPU.
+180 DEQ (Anderson) iterations, FFDNet denoiser, plus the MFMA roofline of the dominant kernel (the
+Winograd 64->64 conv of the denoiser), the HBM roofline of the fused Phi/Phi^T + GAP-update kernel and the
+reference algorithm timed on the host CPU.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -197,22 +198,34 @@ def main():
                         k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
                         if rec["bsz"] == bsz and rec["size"] == args.size and k:
                             traffic = k["hbm_bytes_per_launch"]
-            out["roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}, 3> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update)",
+            out["hbm_roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}, 3> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update)",
                                "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms)}
         cms = conv_timer.durations_ms()
         if cms:
-            # the denoiser's 64->64 conv layers (the kernel where the time goes): executed MFMA flops of the Winograd
-            # F(2x2,3x3) form = direct flops / 2.25, against the dense fp32 MFMA peak
+            # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call).
+            # Algorithmic flops per launch = the MFMA flops of the Winograd F(2x2,3x3) form = direct flops / 2.25,
+            # against the dense fp32 MFMA peak; "hbm_roofline" is the fused streaming kernel of the DEQ loop itself.
             nimg, ch, cw = conv_shape
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
             cavg = 1e-3 * sum(cms) / len(cms)
-            out["denoiser_roofline"] = {"kernel": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)",
-                                        "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                                        "frac": direct / 2.25 / cavg / 1e12 / 157.3, "traffic": None,
-                                        "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12, "avg_launch_us": 1e6 * cavg,
-                                        "launches_timed": len(cms), "share_of_step_time": 0.94}
+            n_conv = 13 if args.denoiser == "ffdnet" else 2       # 64->64 layers per denoiser call (models.py:53-58 / SimpleCNN_models.py:47-53)
+            share = cavg * n_conv * eng.last_info["f_calls"] / (elapsed / args.steps)
+            wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
+            wfile = os.path.join(ROOT, "profiles", "r01_pmc_winograd.json")
+            if os.path.exists(wfile):
+                with open(wfile) as fh:
+                    rec = json.load(fh)
+                if rec.get("shape") == [nimg, 64, ch, cw]:
+                    wtraffic = rec["hbm_bytes_per_launch"]
+            out["roofline"] = {"kernel": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)",
+                               "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                               "frac": direct / 2.25 / cavg / 1e12 / 157.3, "traffic": wtraffic,
+                               "algorithmic_flops_per_launch": direct / 2.25, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
+                               "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3)}
+        if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
+            out["roofline"] = out["hbm_roofline"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_iters, args.iters + 2, H, W, B, args.denoiser)
         print(json.dumps(out), flush=True)

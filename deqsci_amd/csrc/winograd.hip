@@ -8,35 +8,45 @@
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      F(2x2,3x3): 4x4 input patch d (stride 2) -> 2x2 outputs
 //
-// Work unit ("block tile") = 4 x 8 Winograd tiles (8 x 16 output pixels) x all 64 output channels.  The 16 transform
-// positions xi are 16 independent GEMMs  M[xi] (64 cout x 32 tiles) += U[xi] (64 x cin) V[xi] (cin x 32):
-//   * PERSISTENT workgroups of 4 wavefronts, two per CU (<= 80 KB LDS, <= 256 registers), each walking a contiguous run
-//     of block tiles of "its" XCD (neighbouring tiles share halo pixels in that XCD's L2).  Wave w owns tiles
-//     [16*(w>>1), +16) x couts [32*(w&1), +32) of every M[xi]: 16 x 2 accumulators of v_mfma_f32_16x16x4_f32 (128
-//     registers) that hold every value the output transform of its (tile, cout) needs.
-//   * the 64 input channels are consumed in chunks of 8, and the chunk pipeline runs ACROSS block tiles (chunk g of
-//     the workgroup = chunk g&7 of its (g>>3)-th tile): one stage = MFMA phase + input transform + ONE barrier, with
-//       - weights U((g+1)&7): host-packed in MFMA-lane order, copied global -> LDS by the DMA path
-//         (global_load_lds_dwordx4: no registers, no ds_write) into the other of two 32 KB buffers; a lane's weight
-//         operands for one xi are ONE conflict-free ds_read_b128 feeding 4 MFMAs;
-//       - raw input of chunk g+2 (10 x 18 pixels x 8 channels, possibly of the NEXT block tile): two coalesced float4 per
-//         lane into registers, written to the other of two 7.6 KB LDS tiles after the MFMAs (pixel stride 10 floats,
-//         pixel rows 2,3,6,7 shifted by one pixel: the per-lane patch reads hit 32 distinct banks);
-//       - each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch of chunk g+1 while the
-//         MFMAs of chunk g run and turns it into V = B^T d B (its operands for all 16 xi) in registers afterwards;
+// Work unit ("block tile") = 8 x 8 Winograd tiles (16 x 16 output pixels) x all 64 output channels.  The 16 transform
+// positions xi are 16 independent GEMMs  M[xi] (64 cout x 64 tiles) += U[xi] (64 x cin) V[xi] (cin x 64):
+//   * ONE PERSISTENT workgroup of 8 wavefronts per CU (two per SIMD, <= 256 registers, 92 KB LDS), walking a contiguous
+//     run of block tiles of "its" XCD (neighbouring tiles share halo pixels in that XCD's L2).  64 tiles per CU is the
+//     most the register file holds accumulators for (256 KB), and it is what one pass over the 256 KB of transformed
+//     weights is amortised over.  Wave w owns tiles [16*(w>>1), +16) x couts [32*(w&1), +32) of every M[xi]: 16 x 2
+//     accumulators of v_mfma_f32_16x16x4_f32 (128 registers) that hold every value the output transform of its
+//     (tile, cout) needs.
+//   * the 64 input channels are consumed in chunks of 8, and the chunk pipeline runs ACROSS block tiles: one stage =
+//     MFMA phase + input transform + ONE barrier, with
+//       - weights U(c+1): host-packed in LDS order, so the 32 KB chunk is a LINEAR copy global -> LDS by the DMA path
+//         (global_load_lds_dwordx4: no registers, no ds_write): every wave moves 4 KB in 4 instructions that differ only
+//         in their immediate offset; a lane's weight operands for one xi are ONE conflict-free ds_read_b128 feeding 4 MFMAs;
+//       - raw input of chunk c+2 (18 x 18 pixels x 8 channels, possibly of the NEXT block tile): two coalesced float4 per
+//         lane into registers, written to the other of two 13.7 KB LDS tiles after the MFMAs (pixel stride 10 floats,
+//         pixel rows 2,3,6,7,.. shifted by one pixel: the per-lane patch reads hit 32 distinct banks);
+//       - each MFMA lane (tile i = lane&15, channel pair q = lane>>4) reads ITS OWN 4x4 patch of chunk c+1 while the
+//         MFMAs of chunk c run and turns it into V = B^T d B (its operands for all 16 xi) in registers afterwards;
 //     so a block tile has no prologue of its own: its first two raw chunks and first weight chunk are in flight while the
-//     previous tile finishes, and only the output transform sits between two tiles' MFMAs (the co-resident workgroup's
-//     MFMAs fill that gap).
+//     previous tile finishes, and only the output transform sits between two tiles' MFMAs.
 //   * the matrix core gets the WEIGHTS as its A operand: D rows (4 per lane, consecutive registers) are 4 consecutive
-//     couts of one tile, so the epilogue (Y = A^T M A, bias, ReLU) is per-lane register work ending in 16-byte stores.
+//     couts of one tile, so the epilogue (Y = A^T M A, ReLU) is per-lane register work ending in 16-byte stores; the bias
+//     is the initial value of the xi = 5 accumulator (its coefficient in all four outputs is 1).
 //
-// Three things the compiler must not be allowed to do here, all measured (tools/ubench/winograd_stamps.py):
-//   * __syncthreads() is a fence + s_barrier and the fence becomes `s_waitcnt vmcnt(0)`: it would drain the loads and
-//     DMA pieces deliberately left in flight across the barrier -> wg_lds_barrier() (lgkmcnt only);
-//   * after __builtin_amdgcn_global_load_lds hipcc cannot tell which LDS bytes the DMA writes and puts vmcnt(0) in front
-//     of the next ds_read of ANY LDS array -> the DMA is inline asm and its wait is placed by hand;
-//   * a register load hipcc believes pending on some path makes it wait before the registers' next use - and with it for
-//     every younger DMA piece -> raw_landed() tells it, on every path, that the raw loads are complete.
+// What bounds it (tools/ubench/mfma_valu_mix.hip, cu_fill_rate.hip, winograd_stamps.py; DESIGN.md has the numbers):
+//   * the two waves of a SIMD do not overlap their MFMA streams with each other's other work for free: while one wave
+//     issues MFMAs back to back, its sibling gets ONE instruction of any kind per MFMA, and two MFMA streams are simply
+//     serialised.  A chunk therefore costs a SIMD 2 x (64 MFMAs + the ~60 LDS/DMA/wait instructions inside the MFMA
+//     phase) plus whatever is left outside; every instruction that is not an MFMA was counted and cut: packed
+//     (v_pk_add_f32) transforms, bias folded into the accumulator, multiply-shift tile decode, immediate-offset DMA,
+//     compile-time LDS buffer parity;
+//   * three things the compiler must not be allowed to do, all measured:
+//       - __syncthreads() is a fence + s_barrier and the fence becomes `s_waitcnt vmcnt(0)`: it would drain the loads and
+//         DMA pieces deliberately left in flight across the barrier -> wg_lds_barrier() (lgkmcnt only);
+//       - after __builtin_amdgcn_global_load_lds hipcc cannot tell which LDS bytes the DMA writes and puts vmcnt(0) in
+//         front of the next ds_read of ANY LDS array -> the DMA is inline asm and its wait is placed by hand;
+//       - a register load hipcc believes pending on some path makes it wait before the registers' next use - and with it
+//         for every younger DMA piece -> raw_landed() tells it, on every path, that the raw loads are complete.
+//   (WG_WAVES=4 builds the 32-tile variant with two independent workgroups per CU; it measures 2-3 % slower.)
 #include "common.hpp"
 #include <hip/hip_ext.h>
 #include <type_traits>
@@ -49,11 +59,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WG_CK = 8;                      // input channels per chunk
 constexpr int WG_NCHUNK = 64 / WG_CK;
-constexpr int WG_TB = 256;                    // 4 wavefronts
+#ifndef WG_WAVES
+#define WG_WAVES 8                            // wavefronts per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
+#endif
+constexpr int WG_TB = 64 * WG_WAVES;
+constexpr int WG_TROWS = WG_WAVES;            // Winograd tile rows of a block tile (8 tiles per row, 16 tiles per wave pair)
 constexpr int WG_RAW_PS = 10;                 // floats per staged pixel (8 channels + 2)
-constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 10;
+constexpr int WG_RAW_COLS = 18, WG_RAW_ROWS = 2 * WG_TROWS + 2;
 constexpr int WG_RAW_RS = (WG_RAW_COLS + 1) * WG_RAW_PS;      // 190 floats per staged pixel row (one spare pixel for the shift)
-constexpr int WG_RAW_BUF = WG_RAW_ROWS * WG_RAW_RS;           // 1900 floats = 7.6 KB
+constexpr int WG_RAW_BUF = WG_RAW_ROWS * WG_RAW_RS;           // 3420 floats = 13.7 KB
 constexpr int WG_U_CHUNK = 16 * 2 * 64 * 4;   // floats of one weight chunk in LDS (32 KB)
 
 __device__ __forceinline__ int wg_row_shift(int r) { return (r >> 1) & 1; }
@@ -81,7 +95,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
                                                                    int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles,
                                                                    uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
     __shared__ __attribute__((aligned(16))) float Us[2 * WG_U_CHUNK];             // 2 x U[xi][cout half][MFMA lane][j][2]   64 KB
-    __shared__ __attribute__((aligned(16))) float Raw[2 * WG_RAW_BUF];            // 2 x raw chunk tile                    15.2 KB
+    __shared__ __attribute__((aligned(16))) float Raw[2 * WG_RAW_BUF];            // 2 x raw chunk tile                    27.4 KB
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = (int)wg_uniform((uint32_t)(tid >> 6));          // in an SGPR: the DMA bookkeeping is scalar code
@@ -101,7 +115,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     if (t_first >= t_end) return;
 
     // ---- raw staging role: chunk tile = 180 pixels x 2 float4; lane e handles (pixel e>>1, half e&1), e = tid, tid + 256
-    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 360
+    constexpr int RAW_F4 = WG_RAW_ROWS * WG_RAW_COLS * 2;          // 648 <= 2 * WG_TB
     int rdst[2], rpr[2], rpc[2];                                   // LDS float offset (-1 = idle), staged pixel row / column
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
         const int n = wg_div(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = wg_div(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         xf = x + (int64_t)n * H * W * 64;
-        const int py0 = 8 * by - 1, px0 = 16 * bx - 1;             // image coordinates of staged pixel (0,0)
+        const int py0 = 2 * WG_TROWS * by - 1, px0 = 16 * bx - 1;  // image coordinates of staged pixel (0,0)
         border = py0 < 0 || px0 < 0 || py0 + WG_RAW_ROWS > H || px0 + WG_RAW_COLS > W;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -161,25 +175,27 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // moves bytes [8 KiB * w, +8 KiB) in 8 instructions that differ only in their immediate offset (which the hardware adds
     // to the global AND the LDS address): one scalar base and one M0 value per chunk, no address arithmetic per piece.
     const uint32_t us_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
-    const uint32_t dma_voff = (uint32_t)(wave * 8192 + lane * 16);                      // bytes
-    uint64_t dma_g = 0;                                                                 // global base of the chunk + 4096
-    uint32_t dma_m0 = 0;                                                                // LDS base of this wave's 8 KiB + 4096
-    auto dma_u_setup = [&](int c, int buf) {
-        const uint64_t g = (uint64_t)(Ug + (int64_t)c * WG_U_CHUNK) + 4096;
-        dma_g = ((uint64_t)wg_uniform((uint32_t)(g >> 32)) << 32) | wg_uniform((uint32_t)g);
-        dma_m0 = wg_uniform(us_lds + (uint32_t)(buf * WG_U_CHUNK * 4 + wave * 8192 + 4096));
+    constexpr int DMA_WAVE_BYTES = WG_U_CHUNK * 4 / WG_WAVES;                          // 4 KiB (8 waves) or 8 KiB (4 waves)
+    const uint32_t dma_voff = (uint32_t)(wave * DMA_WAVE_BYTES + lane * 16);            // bytes
+    // returns the scalar global base of the chunk (+ half a wave share); sets M0 = LDS base of this wave's share (+ half).
+    // The base is handed to the pieces as a VALUE: kept in a by-reference variable it ended up in vector registers.
+    auto dma_u_setup = [&](int c, int buf) -> uint64_t {
+        const uint64_t g = (uint64_t)(Ug + (int64_t)c * WG_U_CHUNK) + DMA_WAVE_BYTES / 2;
+        const uint32_t dma_m0 = wg_uniform(us_lds + (uint32_t)(buf * WG_U_CHUNK * 4 + wave * DMA_WAVE_BYTES + DMA_WAVE_BYTES / 2));
         asm volatile("s_mov_b32 m0, %0" ::"s"(dma_m0) : "m0");                         // nothing else in this kernel uses M0
+        return ((uint64_t)wg_uniform((uint32_t)(g >> 32)) << 32) | wg_uniform((uint32_t)g);
     };
-#define WG_DMA_PIECE(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF ::"v"(dma_voff), "s"(dma_g) : "memory")
-    auto dma_u_piece = [&](int j) {                                                     // KiB j of this wave's 8
-        switch (j) {
-            case 0: WG_DMA_PIECE(-4096); break;
-            case 1: WG_DMA_PIECE(-3072); break;
-            case 2: WG_DMA_PIECE(-2048); break;
-            case 3: WG_DMA_PIECE(-1024); break;
-            case 4: WG_DMA_PIECE(0); break;
-            case 5: WG_DMA_PIECE(1024); break;
-            case 6: WG_DMA_PIECE(2048); break;
+#define WG_DMA_PIECE(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF ::"v"(dma_voff), "s"(dg) : "memory")
+    constexpr int DMA_PIECES = DMA_WAVE_BYTES / 1024;
+    auto dma_u_piece = [&](uint64_t dg, int j) {                                                     // KiB j of this wave's share
+        switch (j - DMA_PIECES / 2) {
+            case -4: WG_DMA_PIECE(-4096); break;
+            case -3: WG_DMA_PIECE(-3072); break;
+            case -2: WG_DMA_PIECE(-2048); break;
+            case -1: WG_DMA_PIECE(-1024); break;
+            case 0: WG_DMA_PIECE(0); break;
+            case 1: WG_DMA_PIECE(1024); break;
+            case 2: WG_DMA_PIECE(2048); break;
             default: WG_DMA_PIECE(3072); break;
         }
     };
@@ -231,12 +247,12 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // bias instead of zero.  All arithmetic on register PAIRS (v_pk_add_f32): non-MFMA vector instructions are what
     // bounds this kernel once the matrix pipe is fed (tools/ubench/mfma_valu_mix.hip).
     // D layout of the 16x16 MFMA with the weights as A operand: col = lane&15 (tile), row = 4*(lane>>4) + reg (cout)
-    auto epilogue = [&](int t) {
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int n = wg_div(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = wg_div(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         float* yn = y + (int64_t)n * H * W * 64;
         const int tl = 16 * wt + (lane & 15);
-        const int oy = 2 * (4 * by + (tl >> 3)), ox = 2 * (8 * bx + (tl & 7));
+        const int oy = 2 * (WG_TROWS * by + (tl >> 3)), ox = 2 * (8 * bx + (tl & 7));
         float* o = yn + ((int64_t)oy * W + ox) * 64 + 32 * wn + 4 * (lane >> 4);
         const bool in0 = oy < H && ox < W, inx = ox + 1 < W, iny = oy + 1 < H;
 #pragma unroll
@@ -294,9 +310,11 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // ---- prologue (once per workgroup): bias, U(0), raw(0), raw(1) staged; V(0) computed; fetch stream at chunk 2
     if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.0f;
     set_fetch_tile(t_first);
-    dma_u_setup(0, 0);
+    {
+        const uint64_t dg = dma_u_setup(0, 0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_u_piece(j);
+        for (int j = 0; j < DMA_PIECES; ++j) dma_u_piece(dg, j);
+    }
     fetch_raw_k(0, 0); fetch_raw_k(0, 1);
     store_raw(0);
     fetch_raw_k(1, 0); fetch_raw_k(1, 1);
@@ -310,43 +328,44 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     int t_fetch = t_first;                                    // tile of the fetch stream
     // One pipeline stage = chunk c of the current tile.  PAR = c&1 selects the LDS buffers (compile-time: every LDS address
     // of the stage is an immediate offset), FIRST = chunk 0: the accumulators are written from zero / the bias.
-    auto stage = [&](auto par_c, auto first_c, int c, int t_cur) {
+    // (always_inline: called as a function, the by-reference captures - accumulators included - live in scratch memory.)
+    auto stage = [&](auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         // entry: Us[PAR] = U(c), Raw[PAR^1] = raw(c+1) visible; v = V(c) in registers
         WG_MARK();
-        // ---- MFMA phase.  Hand-ordered: everything that is not an MFMA sits right behind the FIRST of the four MFMAs of a
-        // transform position.  Chunk indices past the end of the run are clamped instead of branched around (a duplicate
-        // fetch of valid memory nobody reads).
+        // ---- MFMA phase.  Hand-ordered: everything that is not an MFMA sits right behind the FIRST of the four MFMAs of
+        // a transform position.  Chunk indices past the end of the run are clamped instead of branched around (a
+        // duplicate fetch of valid memory nobody reads).
         const float* ubc = ub + PAR * WG_U_CHUNK;
         const float* ppn = Raw + (PAR ^ 1) * WG_RAW_BUF;
         const int cf = (c + 2) & 7;                           // chunk of the fetch stream within its tile
-        const int cu = (c + 1) & 7;                           // weight chunk to stage (into Us[PAR^1])
         f32x4 init5[2];
         if (FIRST) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) init5[j] = *reinterpret_cast<const f32x4*>(bias_s + 32 * wn + 16 * j + 4 * (lane >> 4));
         }
-        dma_u_setup(cu, PAR ^ 1);
-        float4 bq[3];
-        bq[0] = *reinterpret_cast<const float4*>(ubc);
-        bq[1] = *reinterpret_cast<const float4*>(ubc + 2 * 64 * 4);
+        const uint64_t dg = dma_u_setup((c + 1) & 7, PAR ^ 1);   // weight chunk to stage, into the buffer M(c-1) released
+        constexpr int PF = 2;                                 // weight operands are read PF transform positions ahead
+        float4 bq[PF + 1];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bq[i] = *reinterpret_cast<const float4*>(ubc + i * (2 * 64 * 4));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
-            if (xi + 2 < 16) bq[(xi + 2) % 3] = *reinterpret_cast<const float4*>(ubc + (xi + 2) * (2 * 64 * 4));
+            if (xi + PF < 16) bq[(xi + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ubc + (xi + PF) * (2 * 64 * 4));
             if ((xi & 1) == 0) {                              // two patch elements per instruction (ds_read2_b64)
                 dn[xi] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
                 dn[xi + 1] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + ((xi & 3) + 1) * WG_RAW_PS);
             }
-            const float4 b = bq[xi % 3];
+            const float4 b = bq[xi % (PF + 1)];
             const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
             __builtin_amdgcn_sched_barrier(0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[xi].x, FIRST ? (xi == 5 ? init5[0] : zero) : acc[xi][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (xi < 8) dma_u_piece(xi);                      // weights first: they are needed one stage from now,
-            else if (xi == 8) fetch_raw_k(cf, 0);             // the raw chunk two stages from now
-            else if (xi == 9) fetch_raw_k(cf, 1);
+            if (xi < DMA_PIECES) dma_u_piece(dg, xi);         // weights first: they are needed one stage from now,
+            else if (xi == DMA_PIECES) fetch_raw_k(cf, 0);    // the raw chunk two stages from now
+            else if (xi == DMA_PIECES + 1) fetch_raw_k(cf, 1);
             __builtin_amdgcn_sched_barrier(0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, v[xi].x, FIRST ? (xi == 5 ? init5[1] : zero) : acc[xi][1], 0, 0, 0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, v[xi].y, acc[xi][0], 0, 0, 0);
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c + 1, t_cur);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing may still be landing in LDS when the workgroup retires
     WG_MARK();
 #ifdef WG_STAMP
     if (tid == WG_STAMP_TID) {
@@ -407,11 +427,11 @@ static int winograd_impl(const float* x, const float* u_packed, const float* bia
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
     if (H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
-    const int64_t tiles_x = ceil_div(ceil_div(W, 2), 8), tiles_y = ceil_div(ceil_div(H, 2), 4);
+    const int64_t tiles_x = ceil_div(ceil_div(W, 2), 8), tiles_y = ceil_div(ceil_div(H, 2), WG_TROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
     if (n_tiles > (int64_t)INT32_MAX / 16 || H * W > (int64_t)INT32_MAX / 64) return DEQSCI_ERR_UNSUPPORTED;   // 32-bit offsets
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t resident = 2 * (int64_t)num_cus();          // two workgroups per CU, persistent
+    const int64_t resident = (8 / WG_WAVES) * (int64_t)num_cus(); // persistent workgroups: 16 wavefronts (2 per SIMD) on every CU
     const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
     uint32_t mg_img, sh_img, mg_tx, sh_tx;
     wg_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);

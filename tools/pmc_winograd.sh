@@ -1,21 +1,36 @@
 #!/bin/bash
-# SQ counters for the Winograd conv kernel (one pass, 8 SQ slots; no trace domains)
+# Hardware counters of the Winograd conv kernel on 64 images of 64 x 128 x 128 (the FFDNet layer shape of the bench workload):
+# SQ counters, cache counters, and HBM bytes (FETCH_SIZE / WRITE_SIZE, separate passes, no trace domains; corrected as
+# tools/pmc_summarize.py calibrates them in the same image: FETCH_SIZE x 2, WRITE_SIZE x 1, both in KiB).
 mkdir -p gpurun_out/pmc_wg
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $R/gpurun_out/pmc_wg/p1 -o k -- python3 $R/tools/conv_bench.py --shape 64 128 128 > $R/gpurun_out/pmc_wg/p1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/pmc_wg/p2 -o k -- python3 $R/tools/conv_bench.py --shape 64 128 128 > $R/gpurun_out/pmc_wg/p2.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc_wg/p3 -o k -- python3 $R/tools/conv_bench.py --shape 64 128 128 > $R/gpurun_out/pmc_wg/p3.log 2>&1
+i=0
+for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc_wg/p$i -o k -- python3 $R/tools/conv_bench.py --shape 64 128 128 > $R/gpurun_out/pmc_wg/p$i.log 2>&1
+done
 cd $R
-python - <<'PY'
-import csv, collections, glob
+python - <<'PY' > gpurun_out/pmc_winograd.json
+import csv, collections, glob, json
+agg = collections.defaultdict(list)
 for f in sorted(glob.glob('gpurun_out/pmc_wg/p*/k_counter_collection.csv')):
-    agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "winograd" in r["Kernel_Name"]:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
-    for k, v in agg.items():
-        print(f.split('/')[2], k, sorted(v)[len(v)//2], len(v))
+med = {k: sorted(v)[len(v) // 2] for k, v in agg.items()}
+n, H, W = 64, 128, 128
+alg = 2 * n * H * W * 64 * 4 + 16 * 64 * 64 * 4
+rd, wr = med.get("FETCH_SIZE", 0) * 1024 * 2.0, med.get("WRITE_SIZE", 0) * 1024 * 1.0
+mfma = n * (H // 2) * (W // 2) * 16 * 64 * 64 * 2 / 2048
+out = {"kernel": "deqsci::winograd_conv64_kernel", "shape": [n, 64, H, W], "launches": len(agg.get("FETCH_SIZE", [])), "counters_median": med,
+       "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "hbm_bytes_per_launch": int(rd + wr),
+       "algorithmic_hbm_bytes": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 3),
+       "mfma_instructions": int(mfma), "non_mfma_valu_per_mfma": round((med.get("SQ_INSTS_VALU", 0) - mfma) / mfma, 3),
+       "mfma_busy_fraction": round(med.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * med.get("GRBM_GUI_ACTIVE", 1) / 8), 3)}
+print(json.dumps(out, indent=1))
 PY
-tail -2 gpurun_out/pmc_wg/p3.log | cut -c1-200
+cat gpurun_out/pmc_winograd.json
