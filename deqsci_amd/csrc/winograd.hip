@@ -59,6 +59,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int WG_CK = 8;                      // input channels per chunk
 constexpr int WG_NCHUNK = 64 / WG_CK;
+#ifndef WG_ABL
+#define WG_ABL 0                              // timing ablations only (tools/ubench): 1 = no patch reads, 2 = no DMA / raw fetch
+#endif
 #ifndef WG_WAVES
 #define WG_WAVES 8                            // wavefronts per workgroup: 8 (one workgroup per CU) or 4 (two per CU)
 #endif
@@ -144,19 +147,25 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             roff[k] = (uint32_t)(((cy * W + cx) * 64 + 4 * (tid & 1)) * 4);
         }
     };
-    float4 rawv[2];
+    // Two register sets: the chunk fetched during stage c is stored to LDS at the end of stage c+1, a whole stage (about
+    // 5000 cycles, more than an HBM round trip under load) later - the first touch of a 128-byte line (chunks 0 and 4 of a
+    // tile) would otherwise be waited for twice per tile.  Each set carries the in-image flags of the tile it was fetched from.
+    float4 rawv[2][2];
+    bool rawok[2][2], rawbd[2] = {true, true};
     // clamped address, no branches; NOTHING here may consume the loaded value (that would park the wave on the memory
     // latency): out-of-image pixels are zeroed in store_raw
-    auto fetch_raw_k = [&](int c, int k) {
-        rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * WG_CK) + roff[k]);
+    auto fetch_raw_k = [&](int set, int c, int k) {
+        rawv[set][k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * WG_CK) + roff[k]);
+        rawok[set][k] = rok[k];
+        rawbd[set] = border;
     };
-    auto store_raw = [&](int buf) {
-        if (border) {                                              // uniform branch: interior tiles skip the selects
+    auto store_raw = [&](int set, int buf) {
+        if (rawbd[set]) {                                          // uniform branch: interior tiles skip the selects
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (rdst[k] >= 0) {
                     float* dst = Raw + buf * WG_RAW_BUF + rdst[k];                      // 8-B aligned (pixel stride 40 B)
-                    const float4 val = rok[k] ? rawv[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    const float4 val = rawok[set][k] ? rawv[set][k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     *reinterpret_cast<float2*>(dst) = make_float2(val.x, val.y);
                     *reinterpret_cast<float2*>(dst + 2) = make_float2(val.z, val.w);
                 }
@@ -165,12 +174,14 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             for (int k = 0; k < 2; ++k)
                 if (rdst[k] >= 0) {
                     float* dst = Raw + buf * WG_RAW_BUF + rdst[k];
-                    *reinterpret_cast<float2*>(dst) = make_float2(rawv[k].x, rawv[k].y);
-                    *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[k].z, rawv[k].w);
+                    *reinterpret_cast<float2*>(dst) = make_float2(rawv[set][k].x, rawv[set][k].y);
+                    *reinterpret_cast<float2*>(dst + 2) = make_float2(rawv[set][k].z, rawv[set][k].w);
                 }
         }
     };
-    auto raw_landed = [&]() { asm volatile("" ::"v"(rawv[0].x), "v"(rawv[1].x)); };
+    // Unconditional "use" of the raw registers: tells hipcc's wait-count pass that the loads have landed on every path
+    // (the stores above are predicated, and a load it believes pending makes it wait - for younger DMA pieces too).
+    auto raw_landed = [&](int set) { asm volatile("" ::"v"(rawv[set][0].x), "v"(rawv[set][1].x)); };
     // ---- weight chunk: DMA global -> LDS.  The chunk is host-packed in LDS order, so it is a linear 32 KB copy: wave w
     // moves bytes [8 KiB * w, +8 KiB) in 8 instructions that differ only in their immediate offset (which the hardware adds
     // to the global AND the LDS address): one scalar base and one M0 value per chunk, no address arithmetic per piece.
@@ -298,10 +309,13 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #ifndef WG_STAMP_TID
 #define WG_STAMP_TID 0
 #endif
+#ifndef WG_STAMP_SKIP
+#define WG_STAMP_SKIP 0                         // marks to skip before recording 38 of them
+#endif
     unsigned long long* stamp_out = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias)) + (size_t)blockIdx.x * 40;
     __shared__ unsigned long long stamp_lds[40];              // stamps go to LDS: a global store would count in vmcnt
     int stamp_i = 0;
-#define WG_MARK() do { if (stamp_i < 38) { if (tid == WG_STAMP_TID) stamp_lds[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } } while (0)
+#define WG_MARK() do { if (stamp_i >= WG_STAMP_SKIP && stamp_i < WG_STAMP_SKIP + 38) { if (tid == WG_STAMP_TID) stamp_lds[stamp_i - WG_STAMP_SKIP] = __builtin_readcyclecounter(); } ++stamp_i; } while (0)
     bias = nullptr;
 #else
 #define WG_MARK() do { } while (0)
@@ -315,15 +329,17 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < DMA_PIECES; ++j) dma_u_piece(dg, j);
     }
-    fetch_raw_k(0, 0); fetch_raw_k(0, 1);
-    store_raw(0);
-    fetch_raw_k(1, 0); fetch_raw_k(1, 1);
-    store_raw(1);
+    fetch_raw_k(0, 0, 0); fetch_raw_k(0, 0, 1);
+    store_raw(0, 0);
+    fetch_raw_k(0, 1, 0); fetch_raw_k(0, 1, 1);
+    store_raw(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    raw_landed();
+    raw_landed(0);
+    fetch_raw_k(1, 2, 0); fetch_raw_k(1, 2, 1);               // raw(2): stored at the end of stage 0
     __syncthreads();
     read_patch(0);
     transform();
+    __syncthreads();                                          // every wave has read its patch of raw(0): stage 0 overwrites it
     WG_MARK();                                                // 1: prologue done
     int t_fetch = t_first;                                    // tile of the fetch stream
     // One pipeline stage = chunk c of the current tile.  PAR = c&1 selects the LDS buffers (compile-time: every LDS address
@@ -332,14 +348,19 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     auto stage = [&](auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
-        // entry: Us[PAR] = U(c), Raw[PAR^1] = raw(c+1) visible; v = V(c) in registers
+        // entry: Us[PAR] = U(c), Raw[PAR^1] = raw(c+1) visible; v = V(c) in registers; everyone is done with raw(c) in Raw[PAR]
         WG_MARK();
+        // raw(c+2), requested a stage ago, goes to LDS BEFORE the MFMA phase: the second wave of a SIMD does it while it
+        // waits for its turn on the matrix pipe, and nothing but the input transform is left between the MFMAs and the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_landed(PAR ^ 1);
+        store_raw(PAR ^ 1, PAR);
         // ---- MFMA phase.  Hand-ordered: everything that is not an MFMA sits right behind the FIRST of the four MFMAs of
         // a transform position.  Chunk indices past the end of the run are clamped instead of branched around (a
         // duplicate fetch of valid memory nobody reads).
         const float* ubc = ub + PAR * WG_U_CHUNK;
         const float* ppn = Raw + (PAR ^ 1) * WG_RAW_BUF;
-        const int cf = (c + 2) & 7;                           // chunk of the fetch stream within its tile
+        const int cf = (c + 3) & 7;                           // chunk of the fetch stream within its tile
         f32x4 init5[2];
         if (FIRST) {
 #pragma unroll
@@ -354,7 +375,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             if (xi + PF < 16) bq[(xi + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ubc + (xi + PF) * (2 * 64 * 4));
-            if ((xi & 1) == 0) {                              // two patch elements per instruction (ds_read2_b64)
+            if ((xi & 1) == 0 && !(WG_ABL & 1)) {             // two patch elements per instruction (ds_read2_b64)
                 dn[xi] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + (xi & 3) * WG_RAW_PS);
                 dn[xi + 1] = *reinterpret_cast<const f32x2*>(ppn + prow[xi >> 2] + ((xi & 3) + 1) * WG_RAW_PS);
             }
@@ -363,9 +384,10 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             __builtin_amdgcn_sched_barrier(0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[xi].x, FIRST ? (xi == 5 ? init5[0] : zero) : acc[xi][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (xi < DMA_PIECES) dma_u_piece(dg, xi);         // weights first: they are needed one stage from now,
-            else if (xi == DMA_PIECES) fetch_raw_k(cf, 0);    // the raw chunk two stages from now
-            else if (xi == DMA_PIECES + 1) fetch_raw_k(cf, 1);
+            if (WG_ABL & 2) { }
+            else if (xi < DMA_PIECES) dma_u_piece(dg, xi);    // weights first: they are needed one stage from now,
+            else if (xi == DMA_PIECES) fetch_raw_k(PAR, cf, 0);   // the raw chunk three stages from now, into the set
+            else if (xi == DMA_PIECES + 1) fetch_raw_k(PAR, cf, 1);   // stage c-1 stored from
             __builtin_amdgcn_sched_barrier(0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, v[xi].x, FIRST ? (xi == 5 ? init5[1] : zero) : acc[xi][1], 0, 0, 0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, v[xi].y, acc[xi][0], 0, 0, 0);
@@ -374,12 +396,11 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
         }
         WG_MARK();
         transform();                                          // V(c+1) from the patch read during the MFMAs
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // raw(c+2) in registers, this wave's part of U(c+1) in LDS
-        raw_landed();
-        store_raw(PAR);                                       // raw(c+2) into the tile V(c) came from
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");      // this wave's part of U(c+1) is in LDS (the two raw loads of this
+                                                              // stage stay in flight)
         wg_lds_barrier();                                     // U(c+1), raw(c+2) visible; every wave is done with Us[PAR]
         WG_MARK();
-        if (c == 5) {                                         // chunks c+3.. of the fetch stream belong to the next tile
+        if (c == 4) {                                         // chunks c+4.. of the fetch stream belong to the next tile
             if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
             set_fetch_tile(t_fetch);
         } else if (c == 7) {
@@ -401,7 +422,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     WG_MARK();
 #ifdef WG_STAMP
     if (tid == WG_STAMP_TID) {
-        for (int i = 0; i < stamp_i; ++i) stamp_out[i] = stamp_lds[i];
+        for (int i = 0; i < 38 && i < stamp_i - WG_STAMP_SKIP; ++i) stamp_out[i] = stamp_lds[i];
         stamp_out[38] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
         stamp_out[39] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID: wave/simd/cu/sh/se
     }
