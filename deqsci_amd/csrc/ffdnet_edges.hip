@@ -15,6 +15,16 @@
 
 namespace deqsci {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// acc += s.x * w  /  acc += s.y * w  on a register pair, fused (one rounding per lane, exactly fmaf): ONE v_pk_fma_f32, the
+// broadcast of s.x / s.y is an operand modifier (op_sel) of the instruction
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 s, f32x2 w) {
+    acc = __builtin_elementwise_fma(__builtin_shufflevector(s, s, 0, 0), w, acc);
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 s, f32x2 w) {
+    acc = __builtin_elementwise_fma(__builtin_shufflevector(s, s, 1, 1), w, acc);
+}
+
 constexpr int TT_H = 8, TT_W = 32;                 // output tile (half-res positions)
 constexpr int TT_IW = TT_W + 2, TT_IH = TT_H + 2;  // input tile with halo
 constexpr int TT_CH = 32;                          // channels per LDS pass
@@ -31,24 +41,43 @@ __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
+    // staging: [TT_IH][TT_IW][32] per half (zero outside the image), 8 float4 per pixel, NST float4 per lane.  All loads of a
+    // half are issued back to back into registers, and the second half is requested BEFORE the first is computed on.
+    constexpr int NE = TT_IH * TT_IW * (TT_CH / 4), NST = (NE + TB - 1) / TB;
+    float4 stg[NST];
+    int sdst[NST];                                            // LDS float offset, -1 = no element
+    int64_t soff[NST];                                        // global element offset, -1 = outside the image (zero)
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int e = threadIdx.x + i * TB;
+        const int pix = e / (TT_CH / 4), q = e % (TT_CH / 4);
+        const int pr = pix / TT_IW, pc = pix % TT_IW;
+        const int gr = r0 + pr - 1, gc = c0 + pc - 1;
+        sdst[i] = e < NE ? pix * TT_PS + 4 * q : -1;
+        soff[i] = (e < NE && gr >= 0 && gr < H && gc >= 0 && gc < W) ? ((int64_t)gr * W + gc) * 64 + 4 * q : -1;
+    }
+    auto fetch_half = [&](int half) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i)
+            stg[i] = soff[i] >= 0 ? ld4(hn + soff[i] + half * TT_CH) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    auto store_half = [&](int half) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            float4 v = stg[i];
+            if (bias && soff[i] >= 0) {   // the previous layer's folded-BN bias + ReLU applied on the way in (padding stays 0)
+                const float4 b = ld4(bias + half * TT_CH + (sdst[i] % TT_PS));
+                v.x = fmaxf(v.x + b.x, 0.0f); v.y = fmaxf(v.y + b.y, 0.0f); v.z = fmaxf(v.z + b.z, 0.0f); v.w = fmaxf(v.w + b.w, 0.0f);
+            }
+            if (sdst[i] >= 0) *reinterpret_cast<float4*>(tile + sdst[i]) = v;
+        }
+    };
+    fetch_half(0);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        // stage [TT_IH][TT_IW][32] (zero outside the image): 8 float4 per pixel
-        for (int e = threadIdx.x; e < TT_IH * TT_IW * (TT_CH / 4); e += TB) {
-            const int pix = e / (TT_CH / 4), q = e % (TT_CH / 4);
-            const int pr = pix / TT_IW, pc = pix % TT_IW;
-            const int gr = r0 + pr - 1, gc = c0 + pc - 1;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (gr >= 0 && gr < H && gc >= 0 && gc < W) {
-                v = ld4(hn + ((int64_t)gr * W + gc) * 64 + half * TT_CH + 4 * q);
-                if (bias) {      // the previous layer's folded-BN bias + ReLU applied on the way in (padding stays 0)
-                    const float4 b = ld4(bias + half * TT_CH + 4 * q);
-                    v.x = fmaxf(v.x + b.x, 0.0f); v.y = fmaxf(v.y + b.y, 0.0f); v.z = fmaxf(v.z + b.z, 0.0f); v.w = fmaxf(v.w + b.w, 0.0f);
-                }
-            }
-            *reinterpret_cast<float4*>(tile + pix * TT_PS + 4 * q) = v;
-        }
+        store_half(half);
         __syncthreads();
+        if (half == 0) fetch_half(1);                         // in flight under the FMAs of the first half
         const float* wh = wp + half * 9 * TT_CH * COUT;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -125,11 +154,13 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
 constexpr int HD_T = 32;                      // tile side in half-res positions
 constexpr int HD_P = 2 * HD_T + 4;            // patch side in full-res pixels
 constexpr int HD_PS = HD_P + 2;               // LDS row stride (even: float2 reads stay 8-B aligned)
+constexpr int HD_SS = HD_T + 3;               // row stride of the sigma plane (HD_T + 2 columns)
 
 __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                          const float* __restrict__ sigma, int sigma_stride,
                                                          float* __restrict__ h, int H, int W) {
     __shared__ __attribute__((aligned(16))) float patch[HD_P * HD_PS];
+    __shared__ float sgm[(HD_T + 2) * HD_SS];
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * HD_T, c0 = blockIdx.x * HD_T;
     const int H2 = 2 * H, W2 = 2 * W;
@@ -139,11 +170,25 @@ __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict
         const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
         patch[pr * HD_PS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
     }
-    const int cq = threadIdx.x % 16, slot = threadIdx.x / 16;
-    float4 wr[45];                                  // [ch*9 + tap] -> 4 output channels 4cq..4cq+3
-#pragma unroll
-    for (int k = 0; k < 45; ++k) wr[k] = ld4(wq + (k * 16 + cq) * 4);
+    // the sigma plane of the tile with its ring: sigma inside the image, 0 in the conv's zero padding (9 compares and
+    // selects per position otherwise - the loop below is bound by instruction count, not by its FMAs)
     const float sig = sigma[(int64_t)n * sigma_stride];
+    for (int e = threadIdx.x; e < (HD_T + 2) * (HD_T + 2); e += TB) {
+        const int pr = e / (HD_T + 2), pc = e % (HD_T + 2);
+        const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
+        sgm[pr * HD_SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+    }
+    const int cq = threadIdx.x % 16, slot = threadIdx.x / 16;
+    // [ch*9 + tap] -> output channels 4cq..4cq+3 as two register pairs: every multiply-add below is ONE v_pk_fma_f32 on a
+    // pair of output channels (2 x the scalar FMA rate), its input picked from the low / high half of the float2 the LDS
+    // read delivered (op_sel), so no broadcast moves are needed
+    f32x2 wl[45], wh[45];
+#pragma unroll
+    for (int k = 0; k < 45; ++k) {
+        const float4 t = ld4(wq + (k * 16 + cq) * 4);
+        wl[k] = (f32x2){t.x, t.y};
+        wh[k] = (f32x2){t.z, t.w};
+    }
     __syncthreads();
     float* hn = h + (int64_t)n * H * W * 64;
 #pragma unroll 1
@@ -151,31 +196,31 @@ __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict
         const int q = it * 16 + slot;
         const int lr = q / HD_T, lc = q % HD_T;
         const int r = r0 + lr, c = c0 + lc;
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        f32x2 al = {0.0f, 0.0f}, ah = {0.0f, 0.0f};
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {         // channel 0: the sigma map, zero in the conv's padding ring
-            const int rr = r + tap / 3 - 1, cc = c + tap % 3 - 1;
-            const float sv = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
-            acc = fma4(sv, wr[tap], acc);
+        for (int dr = 0; dr < 3; ++dr) {            // channel 0: the sigma map (zero in the conv's padding ring), from LDS
+            const float* sp = sgm + (lr + dr) * HD_SS + lc;
+            const f32x2 s01 = {sp[0], sp[1]}, s2x = {sp[2], sp[2]};
+            pk_fma_lo(al, s01, wl[dr * 3]);     pk_fma_lo(ah, s01, wh[dr * 3]);
+            pk_fma_hi(al, s01, wl[dr * 3 + 1]); pk_fma_hi(ah, s01, wh[dr * 3 + 1]);
+            pk_fma_lo(al, s2x, wl[dr * 3 + 2]); pk_fma_lo(ah, s2x, wh[dr * 3 + 2]);
         }
 #pragma unroll
         for (int prow = 0; prow < 6; ++prow) {      // full-res rows 2r-2 .. 2r+3: dr = prow/2 - 1, i = prow%2
             const float* pp = patch + (2 * lr + prow) * HD_PS + 2 * lc;
-            const float2 a = *reinterpret_cast<const float2*>(pp);
-            const float2 b = *reinterpret_cast<const float2*>(pp + 2);
-            const float2 d = *reinterpret_cast<const float2*>(pp + 4);
-            const float v[6] = {a.x, a.y, b.x, b.y, d.x, d.y};
+            f32x2 v[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const f32x2*>(pp + 2 * j);
 #pragma unroll
             for (int pcol = 0; pcol < 6; ++pcol) {  // dc = pcol/2 - 1, j = pcol%2
                 const int ch = 1 + 2 * (prow % 2) + (pcol % 2);
                 const int tap = (prow / 2) * 3 + (pcol / 2);
-                acc = fma4(v[pcol], wr[ch * 9 + tap], acc);
+                if (pcol % 2 == 0) { pk_fma_lo(al, v[pcol / 2], wl[ch * 9 + tap]); pk_fma_lo(ah, v[pcol / 2], wh[ch * 9 + tap]); }
+                else { pk_fma_hi(al, v[pcol / 2], wl[ch * 9 + tap]); pk_fma_hi(ah, v[pcol / 2], wh[ch * 9 + tap]); }
             }
         }
-        if (r < H && c < W) {
-            acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f);
-            st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
-        }
+        if (r < H && c < W)
+            st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, make_float4(fmaxf(al[0], 0.0f), fmaxf(al[1], 0.0f), fmaxf(ah[0], 0.0f), fmaxf(ah[1], 0.0f)));
     }
 }
 
