@@ -11,16 +11,20 @@ Tensors are (bsz,H,W,B) / (bsz,H,W) fp32 on the GPU, exactly as the reference pa
 """
 import torch
 
-from . import _hip
+from . import _hip, autograd as _ag
 
 
 def A_torch_(x, Phi):
     """Forward model of snapshot compressive imaging: y = sum_b x_b * Phi_b."""
+    if _ag.taping(x):
+        return _ag.sci_forward(x, Phi)
     return _hip.sci_forward(_hip.f32c(x), _hip.f32c(Phi), _hip.LAYOUT_HWB)
 
 
 def At_torch_(y, Phi):
     """Transpose of the forward model: x_b = y * Phi_b."""
+    if _ag.taping(y):
+        return _ag.sci_adjoint(y, Phi)
     return _hip.sci_adjoint(_hip.f32c(y), _hip.f32c(Phi), _hip.LAYOUT_HWB)
 
 

@@ -6,7 +6,7 @@
                                    solvers/new_equilibrium_utils_yaping.py:153-189
     forward_iteration(f, x0, max_iter, tol) -> (z, [res])            ibid. :213-222
     DEQFixedPoint(f, solver, **kwargs).forward(y, Phi, Phi_sum, initial_point, train_flag)
-                                   ibid. :241-281 (inference part)
+                                   ibid. :241-281 (inference; with a tape: the training forward + backward hook)
 
 Same names, argument meaning and error behaviour, tensors in the reference's (bsz,H,W,B) layout.
 `andersonexp` / `forward_iteration` accept ANY callable f (kernels K4-K7 on flat (bsz,N) views, one
@@ -17,7 +17,7 @@ whole loop to deqsci_amd.engine.DEQSCIEngine (planar state, fused kernels, no pe
 import torch
 import torch.nn as nn
 
-from . import _hip
+from . import _hip, autograd as _ag
 from ._hip import LAYOUT_BHW, LAYOUT_HWB
 from .engine import SIGMA0, SIGMA_DECAY, DEQSCIEngine
 from .operators import A_torch_, At_torch_
@@ -53,10 +53,39 @@ class EquilibriumProxGradSCI(nn.Module):
             self.noise_sigma = self.noise_sigma * SIGMA_DECAY
         return self.noise_sigma
 
+    def _forward_taped(self, z, y, Phi, Phi_sum):
+        """The same map with autograd recording (training: :268-272 of the DEQ wrapper call f with the tape on): the GAP
+        projection is the HIP kernel behind an autograd.Function, the denoiser is the PyTorch module itself and the
+        layout shuffles are torch views, exactly the operations of :399-420."""
+        bsz, w, h, c = z.shape
+        op = self.nonlinear_op
+        tag = getattr(op, "tag", None)
+        if self.A is A_torch_ and self.At is At_torch_:
+            z1 = _ag.gap_update(z, y, Phi, Phi_sum)
+        else:
+            z1 = z + self.At((y - self.A(z, Phi)) / Phi_sum, Phi)
+        zp = z1.permute(0, 3, 1, 2).contiguous()
+        if tag == 'conv2d':
+            return op(zp.view(bsz * c, 1, w, h)).view(bsz, c, w, h).permute(0, 2, 3, 1)
+        if tag == 'conv3d':
+            return op(zp.view(bsz, 1, c, w, h)).view(bsz, c, w, h).permute(0, 2, 3, 1)
+        if tag == 'ffdnet':
+            noise = op(zp.view(bsz * c, 1, w, h), self._sigma(y, bsz * c))
+        elif tag == 'denoiser':
+            noise = op(zp.view(bsz * c, 1, w, h))
+        elif tag == '3d_denoiser':
+            noise = op(zp.view(bsz, 1, c, w, h))
+        else:
+            print('unknown nonlinear_op tag!')
+            raise UnboundLocalError("local variable 'z_tplus1' referenced before assignment")
+        return z1 - noise.view(bsz, c, w, h).permute(0, 2, 3, 1)
+
     def forward(self, z, y, Phi, Phi_sum):
         bsz, w, h, c = z.shape
         op = self.nonlinear_op
         tag = getattr(op, "tag", None)
+        if torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in op.parameters())):
+            return self._forward_taped(z, y, Phi, Phi_sum)
         if self.A is A_torch_ and self.At is At_torch_:
             # K3 fused with the permute(0,3,1,2).contiguous() of :415/:419
             z1 = _hip.gap_update(_hip.f32c(z), _hip.f32c(Phi), _hip.f32c(y), _hip.f32c(Phi_sum), LAYOUT_HWB, LAYOUT_BHW)
@@ -164,9 +193,25 @@ class DEQFixedPoint(nn.Module):
         return self._engine[1]
 
     def forward(self, x, Phi, Phi_sum, initial_point=None, train_flag=True):
-        """x is the measurement y.  Inference only: the reference's implicit-differentiation backward
-        hook (:274-280, training) is outside this build's scope; `train_flag` is ignored as in the reference."""
+        """x is the measurement y.  Without a tape (torch.no_grad(), or no parameter of f requiring a gradient) this is the
+        inference path; with one it is the reference's training forward (:249-281): solve without tape, one taped f call,
+        and the implicit-differentiation hook that solves  g = J_f^T g + grad  with the same solver and settings
+        (`self.backward_res`).  `train_flag=False` skips the tape even when one could be recorded (the reference has that
+        switch commented out, :277-279, and always records)."""
         init_point = torch.zeros_like(x) if initial_point is None else initial_point
+        if train_flag and torch.is_grad_enabled() and any(p.requires_grad for p in self.f.parameters()):
+            with torch.no_grad():
+                z, self.forward_res = self.solver(lambda z: self.f(z, x, Phi, Phi_sum), init_point, **self.kwargs)
+            z = self.f(z, x, Phi, Phi_sum)                                     # re-engage the tape (:268)
+            z0 = z.clone().detach().requires_grad_()
+            f0 = self.f(z0, x, Phi, Phi_sum)                                   # Jacobian-vector products come from this graph
+
+            def backward_hook(grad):
+                g, self.backward_res = self.solver(
+                    lambda v: torch.autograd.grad(f0, z0, v, retain_graph=True)[0] + grad, grad, **self.kwargs)
+                return g
+            z.register_hook(backward_hook)
+            return z
         eng = self._engine_for()
         if eng is not None:
             z = eng.reconstruct(x, Phi, Phi_sum, initial_point=init_point)

@@ -133,6 +133,10 @@ class ProxGradSCI:
 
     @torch.no_grad()
     def __call__(self, z, y, Phi, Phi_sum):
+        return self.taped(z, y, Phi, Phi_sum)
+
+    def taped(self, z, y, Phi, Phi_sum):
+        """the same map without torch.no_grad(): autograd records it when z or the weights require a gradient"""
         bsz, H, Wd, B = z.shape
         z1 = gap_update(z, y, Phi, Phi_sum)
         planar = z1.permute(0, 3, 1, 2).contiguous().view(bsz * B, 1, H, Wd)
@@ -213,6 +217,25 @@ def deq_forward(fmap, iterator, y, Phi, Phi_sum, x0, **kw):
     z = fmap(zs, y, Phi, Phi_sum)
     fmap(z, y, Phi, Phi_sum)
     return z, res
+
+
+def deq_forward_train(fmap, iterator, y, Phi, Phi_sum, x0, **kw):
+    """DEQFixedPoint.forward with a tape (training; solvers/new_equilibrium_utils_yaping.py:249-281): the solve runs without
+    tape, z = f(z*) re-engages it, and a backward hook on z solves g = J^T g + grad with the same iterator and settings, J
+    being the Jacobian of a second taped call f0 = f(z0) at the detached z0 = z (:270-280).  Returns (z, info) with
+    info['forward_res'] and, after backward, info['backward_res']."""
+    with torch.no_grad():
+        zs, fres = iterator(lambda z: fmap(z, y, Phi, Phi_sum), x0, **kw)
+    z = fmap.taped(zs, y, Phi, Phi_sum)
+    z0 = z.clone().detach().requires_grad_()
+    f0 = fmap.taped(z0, y, Phi, Phi_sum)
+    info = {"forward_res": fres}
+
+    def hook(grad):
+        g, info["backward_res"] = iterator(lambda v: torch.autograd.grad(f0, z0, v, retain_graph=True)[0] + grad, grad, **kw)
+        return g
+    z.register_hook(hook)
+    return z, info
 
 
 # ----------------------------------------------------------------------------- ADMM variant (SURVEY 8(f-3))

@@ -17,6 +17,8 @@ Groups:
   g4  trace_*.npz        teacher-forced f trace, traffic m0 64x64 crop, and_maxiters=10
   g5  e2e_*.npz/.json    the reference's real test_solver_sci over data/test_gray
   g6  sigma.npz          FFDNet sigma sequence (repeated fp32 multiply)
+  g7  admm_toy.npz       ADMM variant on a toy denoiser
+  g8  backward.npz       training-mode DEQFixedPoint: implicit-differentiation gradients (SimpleCNN, cnn.ckpt)
 """
 import hashlib
 import json
@@ -369,6 +371,37 @@ def g7():
         out[f"it{it}_res"] = torch.tensor(deq.forward_res, dtype=torch.float64)
     np.savez_compressed(HERE + "/admm_toy.npz", **{k: v.numpy() for k, v in out.items()})
     print("g7 ->", HERE + "/admm_toy.npz")
+
+
+def g8():
+    """Training-mode DEQFixedPoint (new_equilibrium_utils_yaping.py:241-281): forward solve without tape, one taped f call,
+    implicit-differentiation backward hook solved with the same Anderson settings; MSE loss as in
+    training/sci_equilibrium_training.py:69; gradients of every denoiser parameter."""
+    g = torch.Generator().manual_seed(2024)
+    bsz, H, W, B = 2, 24, 20, 4
+    Phi = (torch.rand(bsz, H, W, B, generator=g) < 0.5).float()
+    Phi[:, 0, :2, :] = 0
+    gt = torch.rand(bsz, H, W, B, generator=g)
+    y = A_torch_(gt, Phi)
+    Phi_sum = torch.sum(Phi, axis=3)
+    Phi_sum[Phi_sum == 0] = 1
+    solver = build_solver("SimpleCNN")
+    for p in solver.parameters():
+        p.requires_grad_(True)
+    deq = eq_utils.DEQFixedPoint(solver, eq_utils.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
+    init = initial_point(y, Phi, Phi_sum, gt)
+    rec = deq(y, Phi, Phi_sum, initial_point=init)
+    loss = torch.nn.MSELoss()(rec, gt)
+    solver.zero_grad()
+    loss.backward()
+    out = {"Phi": Phi, "gt": gt, "y": y, "Phi_sum": Phi_sum, "rec": rec.detach(), "loss": loss.detach().double(),
+           "forward_res": torch.tensor(deq.forward_res, dtype=torch.float64),
+           "backward_res": torch.tensor(deq.backward_res, dtype=torch.float64)}
+    for name, p in solver.named_parameters():
+        out["grad." + name] = p.grad.detach()
+    np.savez_compressed(HERE + "/backward.npz", **{k: v.numpy() for k, v in out.items()})
+    print("g8 ->", HERE + "/backward.npz", "loss", float(loss), "fwd res", deq.forward_res, "bwd res", deq.backward_res,
+          {k: float(v.norm()) for k, v in out.items() if k.startswith("grad.")})
 
 
 if __name__ == "__main__":

@@ -578,3 +578,52 @@ def test_plain_edge_kernels_vs_torch(shape):
     want3 = Fn.conv2d(torch.relu(h.double() + b.double().view(1, -1, 1, 1)), w2.double(), padding=1)
     got3 = _hip.conv3x3_c64_to_1(h, _hip.pack_c64_to_1_weights(w2), in_bias=b)
     assert float((got3.double() - want3).norm() / want3.norm()) < 1e-6
+
+
+def test_training_backward_vs_reference_golden():
+    """DEQFixedPoint with a tape = the reference's training forward + implicit-differentiation backward hook
+    (solve without tape, taped f, g = J^T g + grad solved with the same Anderson settings).  Reconstruction, loss, both
+    residuals and the gradient of every SimpleCNN weight against the reference's own run (tests/golden/backward.npz);
+    the linear operators' backward passes are the HIP kernels (deqsci_amd/autograd.py)."""
+    g = np.load(os.path.join(GOLDEN, "backward.npz"))
+    solver, _ = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 12)
+    deq = deqsci_amd.DEQFixedPoint(solver, deqsci_amd.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
+    Phi, y, Ps, gt = G(g["Phi"]), G(g["y"]), G(g["Phi_sum"]), G(g["gt"])
+    rec = deq(y, Phi, Ps, initial_point=deqsci_amd.initial_point(y, Phi, Ps, gt))
+    assert rec.requires_grad
+    loss = torch.nn.functional.mse_loss(rec, gt)
+    solver.zero_grad()
+    loss.backward()
+    assert rel_l2(rec.detach().cpu().numpy(), g["rec"]) < 1e-4
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * float(g["loss"])
+    assert abs(deq.forward_res - float(g["forward_res"])) < 1e-2 * float(g["forward_res"])
+    assert abs(deq.backward_res - float(g["backward_res"])) < 1e-2 * float(g["backward_res"])
+    for name, p in solver.named_parameters():
+        assert rel_l2(p.grad.cpu().numpy(), g["grad." + name]) < 1e-4, name
+    # the inference switch: no tape, engine path, same reconstruction
+    rec2 = deq(y, Phi, Ps, initial_point=deqsci_amd.initial_point(y, Phi, Ps, gt), train_flag=False)
+    assert not rec2.requires_grad and rel_l2(rec2.cpu().numpy(), g["rec"]) < 1e-4
+
+
+def test_autograd_ops_are_adjoint_consistent():
+    """backward of A is At, of At is A, of the GAP projection is the projection with y = 0 (autograd.gradcheck-style dot test)."""
+    from deqsci_amd import autograd as ag
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    Phi = (torch.rand(2, 20, 12, 8, device=DEV, generator=gen) < 0.5).float()
+    Ps = deqsci_amd.phi_sum(Phi)
+    x = torch.randn(2, 20, 12, 8, device=DEV, generator=gen, requires_grad=True)
+    yv = torch.randn(2, 20, 12, device=DEV, generator=gen, requires_grad=True)
+    u = torch.randn(2, 20, 12, device=DEV, generator=gen)
+    v = torch.randn(2, 20, 12, 8, device=DEV, generator=gen)
+    (gx,) = torch.autograd.grad(deqsci_amd.A_torch_(x, Phi), x, u)
+    assert rel_l2(gx.cpu().numpy(), (u[..., None] * Phi).cpu().numpy()) < 1e-6
+    (gy,) = torch.autograd.grad(deqsci_amd.At_torch_(yv, Phi), yv, v)
+    assert rel_l2(gy.cpu().numpy(), (v * Phi).sum(3).cpu().numpy()) < 1e-6
+    z1 = ag.gap_update(x, yv, Phi, Ps)
+    gz, gyy = torch.autograd.grad(z1, (x, yv), v)
+    xr = x.detach().clone().requires_grad_()
+    yr = yv.detach().clone().requires_grad_()
+    ref = xr + ((yr - (xr * Phi).sum(3)) / Ps)[..., None] * Phi
+    rz, ry = torch.autograd.grad(ref, (xr, yr), v)
+    assert rel_l2(z1.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-6
+    assert rel_l2(gz.cpu().numpy(), rz.cpu().numpy()) < 1e-5 and rel_l2(gyy.cpu().numpy(), ry.cpu().numpy()) < 1e-5

@@ -171,3 +171,25 @@ def test_admm_variant_golden():
     for it, tol in ((8, 1e-9), (40, 5e-2)):
         z, u, res = orc.admmexp(lambda a, b: orc.admm_step(den, a, b, y, Phi, Ps), [x0, u0], max_iter=it, tol=tol)
         assert torch.equal(z, T(g[f"it{it}_z"])) and res == float(g[f"it{it}_res"])
+
+
+def test_oracle_training_backward_matches_reference():
+    """g8: training-mode DEQFixedPoint of the reference (tape re-engaged after the solve, implicit-differentiation hook solved
+    with Anderson) - reconstruction, loss, both residuals and the gradient of every denoiser weight."""
+    g = np.load(os.path.join(GOLDEN, "backward.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    W = orc.load_weights("cnn")
+    for v in W.values():
+        v.requires_grad_(True)
+    f = orc.ProxGradSCI("SimpleCNN", W)
+    z, info = orc.deq_forward_train(f, orc.andersonexp, T("y"), T("Phi"), T("Phi_sum"), orc.initial_point(T("y"), T("Phi")),
+                                    m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
+    loss = torch.nn.functional.mse_loss(z, T("gt"))
+    loss.backward()
+    assert rel_l2(z.detach().numpy(), g["rec"]) < 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-7
+    assert abs(info["forward_res"] - float(g["forward_res"])) < 1e-6 * float(g["forward_res"])
+    assert abs(info["backward_res"] - float(g["backward_res"])) < 1e-5 * float(g["backward_res"])
+    for k in g.files:
+        if k.startswith("grad."):
+            assert rel_l2(W[k[len("grad.nonlinear_op."):]].grad.numpy(), g[k]) < 1e-5, k

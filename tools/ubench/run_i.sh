@@ -1,12 +1,5 @@
-export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -q -x -k "head or tail or edge or ffdnet or conv" 2>&1 | tail -2
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_tmp -o bench -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/prof_tmp.log 2>&1
-cd $R
-python - <<'PY'
-import csv
-for r in list(csv.DictReader(open('gpurun_out/prof_tmp/bench_kernel_stats.csv')))[:6]:
-    print(r['Name'][:50], r['Calls'], round(float(r['AverageNs'])/1e3,1), r['Percentage'])
-PY
-grep "^{" gpurun_out/prof_tmp.log | cut -c1-120
+for P in 0 32; do
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -DWG_RAW_PAD=$P -shared -o deqsci_amd/lib/libdeqsci_hip.so deqsci_amd/csrc/*.hip || exit 1
+echo "PAD=$P"; for r in 1 2; do python tools/conv_bench.py 2>&1 | grep "^{" | python -c "import sys,json; print([json.loads(l)['winograd_mfma_fused_us'] for l in sys.stdin])"; done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -DWG_RAW_PAD=$P -DWG_STAMP -DWG_STAMP_TID=0 -DWG_STAMP_SKIP=194 -shared -o deqsci_amd/lib/libdeqsci_hip.so deqsci_amd/csrc/*.hip && python tools/ubench/winograd_stamps.py --timeline 2>&1 | grep -E "phases"
+done
