@@ -83,6 +83,7 @@ def ffdnet_forward(W, x, sigma):
     networks/ffdnet/models.py:46-64,98-108; functions.py:16-53 (2x2 unshuffle, channel
     2i+j, sigma map first) and :62-81 (inverse shuffle)."""
     N, _, H, Wd = x.shape
+    x = x.detach()            # models.py:102-103 feeds `x.data`: the tape never sees the denoiser's dependence on its input
     down = F.pixel_unshuffle(x, 2)
     nmap = sigma.reshape(N, 1, 1, 1).expand(N, 1, H // 2, Wd // 2)
     h = torch.cat([nmap, down], dim=1)

@@ -373,7 +373,7 @@ def g7():
     print("g7 ->", HERE + "/admm_toy.npz")
 
 
-def g8():
+def g8(kind="SimpleCNN"):
     """Training-mode DEQFixedPoint (new_equilibrium_utils_yaping.py:241-281): forward solve without tape, one taped f call,
     implicit-differentiation backward hook solved with the same Anderson settings; MSE loss as in
     training/sci_equilibrium_training.py:69; gradients of every denoiser parameter."""
@@ -385,7 +385,7 @@ def g8():
     y = A_torch_(gt, Phi)
     Phi_sum = torch.sum(Phi, axis=3)
     Phi_sum[Phi_sum == 0] = 1
-    solver = build_solver("SimpleCNN")
+    solver = build_solver(kind)
     for p in solver.parameters():
         p.requires_grad_(True)
     deq = eq_utils.DEQFixedPoint(solver, eq_utils.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
@@ -399,15 +399,20 @@ def g8():
            "backward_res": torch.tensor(deq.backward_res, dtype=torch.float64)}
     for name, p in solver.named_parameters():
         out["grad." + name] = p.grad.detach()
-    np.savez_compressed(HERE + "/backward.npz", **{k: v.numpy() for k, v in out.items()})
-    print("g8 ->", HERE + "/backward.npz", "loss", float(loss), "fwd res", deq.forward_res, "bwd res", deq.backward_res,
+    if kind == "ffdnet":
+        out["sigma_after"] = solver.noise_sigma.detach().clone()
+    fn = HERE + ("/backward.npz" if kind == "SimpleCNN" else f"/backward_{kind}.npz")
+    np.savez_compressed(fn, **{k: v.numpy() for k, v in out.items()})
+    print("g8 ->", fn, "loss", float(loss), "fwd res", deq.forward_res, "bwd res", deq.backward_res,
           {k: float(v.norm()) for k, v in out.items() if k.startswith("grad.")})
 
 
 if __name__ == "__main__":
     torch.manual_seed(0)
     for arg in sys.argv[1:]:
-        if arg.startswith("g5"):
+        if arg.startswith("g8:"):
+            g8(arg.split(":")[1])
+        elif arg.startswith("g5"):
             parts = arg.split(":")
             g5(parts[1], parts[2], int(parts[3]), only_first=(len(parts) > 4 and parts[4] == "first"))
         else:

@@ -580,13 +580,15 @@ def test_plain_edge_kernels_vs_torch(shape):
     assert float((got3.double() - want3).norm() / want3.norm()) < 1e-6
 
 
-def test_training_backward_vs_reference_golden():
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+def test_training_backward_vs_reference_golden(kind):
     """DEQFixedPoint with a tape = the reference's training forward + implicit-differentiation backward hook
     (solve without tape, taped f, g = J^T g + grad solved with the same Anderson settings).  Reconstruction, loss, both
-    residuals and the gradient of every SimpleCNN weight against the reference's own run (tests/golden/backward.npz);
+    residuals, the FFDNet sigma state and the gradient of every denoiser weight against the reference's own run
+    (tests/golden/backward*.npz);
     the linear operators' backward passes are the HIP kernels (deqsci_amd/autograd.py)."""
-    g = np.load(os.path.join(GOLDEN, "backward.npz"))
-    solver, _ = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 12)
+    g = np.load(os.path.join(GOLDEN, "backward.npz" if kind == "SimpleCNN" else "backward_ffdnet.npz"))
+    solver, _ = build_pipeline(kind, checkpoint.shipped("cnn" if kind == "SimpleCNN" else "ffdnet_gray"), 12)
     deq = deqsci_amd.DEQFixedPoint(solver, deqsci_amd.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
     Phi, y, Ps, gt = G(g["Phi"]), G(g["y"]), G(g["Phi_sum"]), G(g["gt"])
     rec = deq(y, Phi, Ps, initial_point=deqsci_amd.initial_point(y, Phi, Ps, gt))
@@ -599,7 +601,9 @@ def test_training_backward_vs_reference_golden():
     assert abs(deq.forward_res - float(g["forward_res"])) < 1e-2 * float(g["forward_res"])
     assert abs(deq.backward_res - float(g["backward_res"])) < 1e-2 * float(g["backward_res"])
     for name, p in solver.named_parameters():
-        assert rel_l2(p.grad.cpu().numpy(), g["grad." + name]) < 1e-4, name
+        assert rel_l2(p.grad.cpu().numpy(), g["grad." + name]) < (1e-4 if kind == "SimpleCNN" else 5e-4), name
+    if kind == "ffdnet":
+        assert np.array_equal(solver.noise_sigma.cpu().numpy(), g["sigma_after"])
     # the inference switch: no tape, engine path, same reconstruction
     rec2 = deq(y, Phi, Ps, initial_point=deqsci_amd.initial_point(y, Phi, Ps, gt), train_flag=False)
     assert not rec2.requires_grad and rel_l2(rec2.cpu().numpy(), g["rec"]) < 1e-4

@@ -173,15 +173,17 @@ def test_admm_variant_golden():
         assert torch.equal(z, T(g[f"it{it}_z"])) and res == float(g[f"it{it}_res"])
 
 
-def test_oracle_training_backward_matches_reference():
+@pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
+def test_oracle_training_backward_matches_reference(kind):
     """g8: training-mode DEQFixedPoint of the reference (tape re-engaged after the solve, implicit-differentiation hook solved
-    with Anderson) - reconstruction, loss, both residuals and the gradient of every denoiser weight."""
-    g = np.load(os.path.join(GOLDEN, "backward.npz"))
+    with Anderson) - reconstruction, loss, both residuals, the sigma state and the gradient of every denoiser weight."""
+    g = np.load(os.path.join(GOLDEN, "backward.npz" if kind == "SimpleCNN" else "backward_ffdnet.npz"))
     T = lambda k: torch.from_numpy(g[k])
-    W = orc.load_weights("cnn")
-    for v in W.values():
-        v.requires_grad_(True)
-    f = orc.ProxGradSCI("SimpleCNN", W)
+    W = orc.load_weights("cnn" if kind == "SimpleCNN" else "ffdnet_gray")
+    for k, v in W.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    f = orc.ProxGradSCI(kind, W)
     z, info = orc.deq_forward_train(f, orc.andersonexp, T("y"), T("Phi"), T("Phi_sum"), orc.initial_point(T("y"), T("Phi")),
                                     m=5, beta=1.0, lam=1e-2, max_iter=12, tol=1e-9)
     loss = torch.nn.functional.mse_loss(z, T("gt"))
@@ -190,6 +192,11 @@ def test_oracle_training_backward_matches_reference():
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-7
     assert abs(info["forward_res"] - float(g["forward_res"])) < 1e-6 * float(g["forward_res"])
     assert abs(info["backward_res"] - float(g["backward_res"])) < 1e-5 * float(g["backward_res"])
+    if kind == "ffdnet":
+        assert np.array_equal(f.noise_sigma.numpy(), g["sigma_after"])
+    n = 0
     for k in g.files:
         if k.startswith("grad."):
             assert rel_l2(W[k[len("grad.nonlinear_op."):]].grad.numpy(), g[k]) < 1e-5, k
+            n += 1
+    assert n == (4 if kind == "SimpleCNN" else 41)
