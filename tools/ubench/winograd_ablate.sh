@@ -1,13 +1,15 @@
 #!/bin/bash
-# builds three variants of the library (full / no MFMA / no loads+transform after chunk 0) and times the conv
+# Where do the cycles of a Winograd pipeline stage go?  Builds the library with s_memtime stamps (-DWG_STAMP) and prints the
+# per-phase timeline of one CU (tools/ubench/winograd_stamps.py), once as shipped and once per timing ablation
+# (WG_ABL 1 = no patch reads, 2 = no weight DMA / raw fetch inside the MFMA phase, 3 = both; results are wrong then).
+# WG_STAMP_SKIP skips that many marks first (3 per stage), WG_STAMP_TID picks the stamping lane (0 = wave 0, 256 = wave 4).
 set -e
 cd $GRAFT_REPO_ROOT
-for v in 0 1 3 4; do
-  mkdir -p /tmp/wgv$v/deqsci_amd/lib
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -DWG_ABLATE=$v -shared -o /tmp/wgv$v/libdeqsci_hip.so deqsci_amd/csrc/*.hip
+SKIP=${WG_STAMP_SKIP:-194}
+for A in 0 1 2 3; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -DWG_STAMP -DWG_STAMP_TID=${WG_STAMP_TID:-0} \
+        -DWG_STAMP_SKIP=$SKIP -DWG_ABL=$A -shared -o deqsci_amd/lib/libdeqsci_hip.so deqsci_amd/csrc/*.hip
+  echo "WG_ABL=$A"
+  python tools/ubench/winograd_stamps.py --timeline 2>&1 | grep -E "phases|lifetime"
 done
-for v in 0 1 3 4; do
-  cp /tmp/wgv$v/libdeqsci_hip.so deqsci_amd/lib/libdeqsci_hip.so
-  echo "WG_ABLATE=$v: $(python tools/conv_bench.py 2>&1 | grep '^{' | head -1 | cut -c1-140)"
-done
-cp /tmp/wgv0/libdeqsci_hip.so deqsci_amd/lib/libdeqsci_hip.so
+make -B deqsci_amd/lib/libdeqsci_hip.so > /dev/null     # back to the product build
