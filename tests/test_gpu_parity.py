@@ -529,7 +529,7 @@ def test_admm_variant_vs_reference_golden():
         assert abs(deq.forward_res - float(g[f"it{it}_res"])) < 1e-3 * float(g[f"it{it}_res"]) + 1e-6   # 4.5e-8 at it=8: round-off level
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 128, 128), (3, 20, 36), (1, 18, 14), (70, 64, 80), (33, 50, 46), (300, 16, 16)])
+@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 128, 128), (3, 20, 36), (1, 18, 14), (2, 17, 23), (1, 1, 1), (70, 64, 80), (33, 50, 46), (300, 16, 16)])
 def test_winograd_conv64_vs_torch(shape):
     """Winograd F(2x2,3x3) MFMA conv 64->64 (+bias+ReLU) vs conv2d in fp64: transpose-detecting (random asymmetric
     weights), ragged tile edges, with and without the fused epilogue.  The last three shapes have more block tiles than
