@@ -1,6 +1,8 @@
 """Evaluation harness with the reference's behaviour.
 
     load_test_data / SCITestDataset   utils/sci_dataloader.py:241-274 (v5 .mat, sorted file order)
+    load_mat / SCITrainingDatasetSubset   ibid. :163-239 (training pairs gt/ + measurement/ + mask.mat)
+    train_solver_sci                  training/sci_equilibrium_training.py:28-150 (implemented in training.py)
     test_solver_sci                   training/sci_equilibrium_training.py:152-205
     psnr                              skimage.metrics.peak_signal_noise_ratio for float input, range 1
     tensor_to_np                      ibid. :19-21 (PNG payload: clip(0,1)*255)
@@ -29,6 +31,50 @@ def load_test_data(matfile):
             mask = np.float32(f['mask']).transpose()
             orig = np.float32(f['orig']).transpose()
     return {'gt': orig / 255, 'mask': mask, 'meas': meas / 255}
+
+
+def load_mat(location, key):
+    """utils/sci_dataloader.py:163-214: one array of the TRAINING set.  key 'gt' (variable patch_save | p1 | p2 | p3, /255),
+    'meas' (/255) or 'mask'; MATLAB v5 files through scipy, v7.3 (HDF5, column-major: transposed back) through h5py."""
+    import scipy.io as sio
+
+    def pick(f):
+        if key == 'gt':
+            for name in ('patch_save', 'p1', 'p2', 'p3'):
+                if name in f:
+                    return np.asarray(f[name]) / 255
+            raise KeyError(f"{location}: none of patch_save/p1/p2/p3")
+        if key == 'meas':
+            return np.asarray(f['meas']) / 255
+        if key == 'mask':
+            return np.asarray(f['mask'])
+        raise KeyError(f"unknown key {key!r}")
+    try:
+        return np.float32(pick(sio.loadmat(location)))
+    except NotImplementedError:
+        try:
+            import h5py
+        except ImportError as e:
+            raise NotImplementedError(f"{location}: MATLAB v7.3 files need h5py, which is not installed") from e
+        with h5py.File(location, 'r') as f:
+            return np.float32(pick(f)).transpose()
+
+
+class SCITrainingDatasetSubset(torch.utils.data.Dataset):
+    """utils/sci_dataloader.py:218-239: <gt_directory>/<name>.mat and <meas_directory>/<name>.mat pairs, one shared mask."""
+
+    def __init__(self, gt_directory, meas_directory, mask_location):
+        names = directory_filelist(gt_directory)
+        self.full_gt_filelist = [gt_directory + n for n in names]
+        self.full_meas_filelist = [meas_directory + n for n in names]
+        self.mask = load_mat(mask_location, 'mask')
+
+    def __len__(self):
+        return len(self.full_gt_filelist)
+
+    def __getitem__(self, item):
+        return {'gt': load_mat(self.full_gt_filelist[item], 'gt'), 'mask': self.mask,
+                'meas': load_mat(self.full_meas_filelist[item], 'meas')}
 
 
 def directory_filelist(target_directory):
@@ -122,3 +168,10 @@ def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, ve
         for k in all_images:
             write_png(k, all_images[k])
     return avg_psnr, all_images
+
+
+def train_solver_sci(*args, **kwargs):
+    """training/sci_equilibrium_training.py:28-150 - see deqsci_amd/training.py (this module is what the reference's
+    `from training import sci_equilibrium_training` becomes, so the name lives here too)."""
+    from .training import train_solver_sci as _train
+    return _train(*args, **kwargs)

@@ -18,6 +18,7 @@ Groups:
   g5  e2e_*.npz/.json    the reference's real test_solver_sci over data/test_gray
   g6  sigma.npz          FFDNet sigma sequence (repeated fp32 multiply)
   g7  admm_toy.npz       ADMM variant on a toy denoiser
+  g9  training_toy.npz   the reference's train_solver_sci for 2 epochs x 3 steps on seeded toy batches
   g8  backward.npz       training-mode DEQFixedPoint: implicit-differentiation gradients (SimpleCNN, cnn.ckpt)
 """
 import hashlib
@@ -405,6 +406,69 @@ def g8(kind="SimpleCNN"):
     np.savez_compressed(fn, **{k: v.numpy() for k, v in out.items()})
     print("g8 ->", fn, "loss", float(loss), "fwd res", deq.forward_res, "bwd res", deq.backward_res,
           {k: float(v.norm()) for k, v in out.items() if k.startswith("grad.")})
+
+
+def _toy_training_data(seed=77, steps=3, bsz=2, H=24, W=20, B=8):
+    g = torch.Generator().manual_seed(seed)
+    train = []
+    for _ in range(steps):
+        Phi = (torch.rand(bsz, H, W, B, generator=g) < 0.5).float()
+        gt = torch.rand(bsz, H, W, B, generator=g)
+        train.append({"gt": gt, "meas": A_torch_(gt, Phi), "mask": Phi})
+    Phi = (torch.rand(1, H, W, B, generator=g) < 0.5).float()
+    gt = torch.rand(1, H, W, B, generator=g)
+    test = [{"gt": gt, "meas": A_torch_(gt, Phi).unsqueeze(3), "mask": Phi, "file": ["toy"]}]
+    return train, test
+
+
+def g9():
+    """The reference's own training loop (training/sci_equilibrium_training.py:28-150) for 2 epochs of 3 Adam steps on seeded
+    toy batches (SimpleCNN from cnn.ckpt, lr 1e-4, StepLR(1, 0.9), MSE mean, Anderson m=5 max_iter=8): loss of every step,
+    the PSNR the loop prints, the weights after training, what the epoch checkpoint holds."""
+    import tempfile
+
+    class _Writer:                                  # torch.utils.tensorboard is not installed here
+        def __init__(self, *a, **k):
+            pass
+
+        def add_scalar(self, *a, **k):
+            pass
+
+        def flush(self):
+            pass
+    sci_train.tensorboard.SummaryWriter = _Writer
+    train, test = _toy_training_data()
+    solver = build_solver("SimpleCNN")
+    w0 = {k: v.detach().clone() for k, v in solver.state_dict().items()}
+    deq = eq_utils.DEQFixedPoint(solver, eq_utils.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=8, tol=1e-5)
+    opt = torch.optim.Adam(params=solver.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(optimizer=opt, step_size=1, gamma=0.9)
+    losses = []
+    mse = torch.nn.MSELoss(reduction="mean")
+
+    def loss_fn(rec, gt):
+        l = mse(rec, gt)
+        losses.append(float(l.detach()))
+        return l
+    tmp = tempfile.mkdtemp() + "/"
+    ref_shims.PSNR_LOG.clear()
+    sci_train.train_solver_sci(single_iterate_solver=solver, train_dataloader=train, test_dataloader=test, optimizer=opt,
+                               save_model_path=tmp, deep_eq_module=deq, loss_function=loss_fn, n_epochs=2, scheduler=sched,
+                               print_every_n_steps=1, save_every_n_steps=1000, start_epoch=0, train_img_path=tmp,
+                               test_img_path=tmp, best_img_path=tmp, tflog_path=tmp)
+    ck = torch.load(tmp + "epoch_1.ckpt", map_location="cpu", weights_only=False)
+    out = {"losses": np.array(losses, dtype=np.float64), "psnr_log": np.array(ref_shims.PSNR_LOG, dtype=np.float64),
+           "ckpt_epoch": np.array(ck["epoch"]), "lr_after": np.array(opt.param_groups[0]["lr"], dtype=np.float64)}
+    assert sorted(ck.keys()) == ["epoch", "optimizer_state_dict", "scheduler_state_dict", "solver_state_dict"]
+    for i, b in enumerate(train):
+        out[f"train{i}.gt"], out[f"train{i}.mask"] = b["gt"].numpy(), b["mask"].numpy()
+    out["test.gt"], out["test.mask"] = test[0]["gt"].numpy(), test[0]["mask"].numpy()
+    for k, v in solver.state_dict().items():
+        out["w." + k] = v.detach().numpy()
+        out["dw." + k] = (v.detach() - w0[k]).numpy()
+        assert torch.equal(ck["solver_state_dict"][k], v)
+    np.savez_compressed(HERE + "/training_toy.npz", **out)
+    print("g9 ->", HERE + "/training_toy.npz", losses, ref_shims.PSNR_LOG)
 
 
 if __name__ == "__main__":

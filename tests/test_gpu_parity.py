@@ -631,3 +631,69 @@ def test_autograd_ops_are_adjoint_consistent():
     rz, ry = torch.autograd.grad(ref, (xr, yr), v)
     assert rel_l2(z1.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 1e-6
     assert rel_l2(gz.cpu().numpy(), rz.cpu().numpy()) < 1e-5 and rel_l2(gyy.cpu().numpy(), ry.cpu().numpy()) < 1e-5
+
+
+def test_training_loop_vs_reference_golden(tmp_path):
+    """train_solver_sci = the reference's training loop (2 epochs x 3 Adam steps on the seeded toy batches of
+    tests/golden/training_toy.npz): loss of every step, the printed PSNRs, the learning rate, the weight UPDATES and the
+    epoch checkpoint against the reference's own run."""
+    from deqsci_amd import harness
+    g = np.load(os.path.join(GOLDEN, "training_toy.npz"))
+    T = lambda k: torch.from_numpy(g[k])
+    train = []
+    for i in range(3):
+        gt, mask = T(f"train{i}.gt"), T(f"train{i}.mask")
+        train.append({"gt": gt, "meas": (gt * mask).sum(3), "mask": mask})
+    tg, tm = T("test.gt"), T("test.mask")
+    test = [{"gt": tg, "meas": (tg * tm).sum(3).unsqueeze(3), "mask": tm, "file": ["toy"]}]
+    solver, _ = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 8)
+    w0 = {k: v.detach().clone() for k, v in solver.state_dict().items()}
+    deq = deqsci_amd.DEQFixedPoint(solver, deqsci_amd.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=8, tol=1e-5)
+    opt = torch.optim.Adam(params=solver.parameters(), lr=1e-4)
+    sched = torch.optim.lr_scheduler.StepLR(optimizer=opt, step_size=1, gamma=0.9)
+    hist = []
+    out = str(tmp_path) + "/"
+    harness.train_solver_sci(single_iterate_solver=solver, train_dataloader=train, test_dataloader=test, optimizer=opt,
+                             save_model_path=out, deep_eq_module=deq, loss_function=torch.nn.MSELoss(reduction="mean"),
+                             n_epochs=2, scheduler=sched, print_every_n_steps=1, save_every_n_steps=1000, start_epoch=0,
+                             train_img_path=out, test_img_path=out, best_img_path=out, tflog_path=out, history=hist)
+    losses = np.array([h["loss"] for h in hist])
+    assert losses.shape == g["losses"].shape and np.all(np.abs(losses - g["losses"]) < 2e-5 * g["losses"]), (losses, g["losses"])
+    # the reference's PSNR log interleaves: 3 training steps, 1 evaluation, per epoch
+    ref_train_psnr = np.concatenate([g["psnr_log"][0:3], g["psnr_log"][4:7]])
+    assert np.all(np.abs(np.array([h["psnr"] for h in hist]) - ref_train_psnr) < 2e-3)
+    assert abs(opt.param_groups[0]["lr"] - float(g["lr_after"])) < 1e-12
+    for k, v in solver.state_dict().items():
+        dw = (v.detach() - w0[k]).cpu().numpy()
+        assert rel_l2(dw, g["dw." + k]) < 2e-2, (k, rel_l2(dw, g["dw." + k]))
+        assert rel_l2(v.detach().cpu().numpy(), g["w." + k]) < 1e-5
+    ck = torch.load(out + "epoch_1.ckpt", map_location="cpu", weights_only=False)
+    assert sorted(ck.keys()) == ["epoch", "optimizer_state_dict", "scheduler_state_dict", "solver_state_dict"]
+    assert int(ck["epoch"]) == int(g["ckpt_epoch"]) and os.path.exists(out + "epoch_0.ckpt")
+    assert os.path.exists(out + "toy_reconstruction_0.png")
+
+
+def test_cli_training_branch(tmp_path):
+    """`--inference False`: the reference driver's training branch end to end on a toy set written here (MATLAB-v5 files in
+    the reference's directory layout): one epoch of two steps, checkpoint in the reference's format, evaluation PNGs."""
+    import scipy.io as sio
+    from deqsci_amd.cli import main as cli_main
+    rng = np.random.default_rng(9)
+    tr, te, sv = tmp_path / "train", tmp_path / "test", tmp_path / "save"
+    (tr / "gt").mkdir(parents=True)
+    (tr / "measurement").mkdir()
+    te.mkdir()
+    mask = (rng.random((24, 20, 8)) < 0.5).astype(np.float64)
+    sio.savemat(tr / "mask.mat", {"mask": mask})
+    for i in range(4):
+        gt = rng.integers(0, 256, (24, 20, 8)).astype(np.float64)
+        sio.savemat(tr / "gt" / f"{i}.mat", {"patch_save": gt})
+        sio.savemat(tr / "measurement" / f"{i}.mat", {"meas": (gt * mask).sum(2)})
+    orig = rng.integers(0, 256, (24, 20, 8)).astype(np.float64)
+    sio.savemat(te / "toy.mat", {"orig": orig, "mask": mask, "meas": (orig * mask).sum(2)[..., None]})
+    cli_main(["--inference", "False", "--denoiser", "SimpleCNN", "--n_epochs", "1", "--batch_size", "2", "--and_maxiters", "5",
+              "--trainpath", str(tr) + "/", "--testpath", str(te) + "/", "--savepath", str(sv) + "/", "--save_every_n_steps", "2"])
+    ck = torch.load(sv / "model" / "epoch_0.ckpt", map_location="cpu", weights_only=False)
+    assert sorted(ck["solver_state_dict"]) == [f"nonlinear_op.dncnn.{i}.weight" for i in (0, 2, 4, 6)] and ck["epoch"] == 0
+    assert (sv / "model" / "best.ckpt").exists()                       # the mid-epoch evaluation ran and improved on 0 dB
+    assert (sv / "img" / "test" / "toy.mat_reconstruction_7.png").exists()

@@ -114,8 +114,8 @@ def test_shard_bounds_cover_batch_exactly():
 
 
 def test_cli_flags_and_errors():
-    with pytest.raises(NotImplementedError):
-        cli_main(["--inference", "False"])
+    with pytest.raises(SystemExit):
+        cli_main(["--inference", "False"])                               # training branch exists; no GPU here -> refuses
     with pytest.raises(SystemExit):
         cli_main(["--denoiser", "ffdnet", "--and_maxiters", "3"])        # no GPU here -> refuses, no CPU path
     with pytest.raises(SystemExit):
@@ -178,3 +178,31 @@ def test_weight_packing_layouts_on_cpu():
     assert float(_hip.pack_c64_to_1_weights(w2)[1, 3, 9]) == float(w2[0, 41, 1, 0])
     with pytest.raises(_hip.DeqsciHipError):
         _hip.pack_winograd_weights(torch.zeros(64, 32, 3, 3))
+
+
+def test_training_dataset_and_entry_points(tmp_path):
+    """SCITrainingDatasetSubset / load_mat (utils/sci_dataloader.py:163-239) on MATLAB-v5 files written here: gt variable
+    names patch_save/p1..p3, /255 scaling, shared mask, sorted pairing; the training entry points import without a GPU."""
+    import scipy.io as sio
+    from deqsci_amd import harness, training
+    rng = np.random.default_rng(5)
+    (tmp_path / "gt").mkdir()
+    (tmp_path / "measurement").mkdir()
+    mask = (rng.random((6, 5, 8)) < 0.5).astype(np.float64)
+    sio.savemat(tmp_path / "mask.mat", {"mask": mask})
+    want = {}
+    for name, var in (("b.mat", "p2"), ("a.mat", "patch_save")):
+        gt = rng.integers(0, 256, (6, 5, 8)).astype(np.float64)
+        sio.savemat(tmp_path / "gt" / name, {var: gt})
+        sio.savemat(tmp_path / "measurement" / name, {"meas": (gt * mask).sum(2)})
+        want[name] = gt
+    ds = harness.SCITrainingDatasetSubset(str(tmp_path / "gt") + "/", str(tmp_path / "measurement") + "/", str(tmp_path / "mask.mat"))
+    assert len(ds) == 2 and ds.full_gt_filelist[0].endswith("a.mat")
+    item = ds[0]
+    assert item["gt"].dtype == np.float32 and np.allclose(item["gt"], want["a.mat"] / 255)
+    assert np.array_equal(item["mask"], mask.astype(np.float32))
+    assert np.allclose(item["meas"], (want["a.mat"] * mask).sum(2) / 255, rtol=1e-6)
+    assert np.allclose(ds[1]["gt"], want["b.mat"] / 255)
+    with pytest.raises(KeyError):
+        harness.load_mat(str(tmp_path / "mask.mat"), "gt")
+    assert callable(harness.train_solver_sci) and callable(training.train_solver_sci)
