@@ -201,7 +201,9 @@ def main():
             out["hbm_roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}, 3> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update)",
                                "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms)}
+                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
+                                   "note": "the fused Phi/Phi^T + GAP-update kernel BASELINE.json's north_star sets its >= 60 % of HBM "
+                                           "peak target on (bsz 64, working set >> Infinity Cache: profiles/r01_kernel_bench_bsz64.jsonl)"}
         cms = conv_timer.durations_ms()
         if cms:
             # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call).
