@@ -32,77 +32,74 @@ def _save(path, solver, epoch, optimizer, scheduler):
                 'optimizer_state_dict': optimizer.state_dict(), 'scheduler_state_dict': scheduler.state_dict()}, path)
 
 
+def _evaluate(deep_eq_module, loader, img_path, device, **kw):
+    return harness.test_solver_sci(test_dataloader=loader, deep_eq_module=deep_eq_module, save_img_path=img_path, device=device, **kw)
+
+
+def _step(batch, deep_eq_module, loss_function, device):
+    """One forward of the training loop (:55-69): batch to the GPU, Phi_sum, x0 = At(y, Phi) without tape, taped DEQ forward."""
+    gt = batch['gt'].to(device)
+    y, Phi = batch['meas'].to(device), batch['mask'].to(device)
+    Phi_sum = operators.phi_sum(Phi)
+    with torch.no_grad():
+        x0 = operators.initial_point(y, Phi, Phi_sum, gt)
+    rec = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=x0)
+    return rec, gt, loss_function(rec, gt)
+
+
 def train_solver_sci(single_iterate_solver, train_dataloader, optimizer, save_model_path, loss_function, n_epochs,
                      deep_eq_module, use_dataparallel=False, scheduler=None, print_every_n_steps=100,
                      save_every_n_steps=1000, start_epoch=0, test_dataloader=None, train_img_path=None,
                      test_img_path=None, best_img_path=None, tflog_path=None, device="cuda", history=None):
-    start_time = time.time()
-    cur_nimg = 0
+    t_start = time.time()
     writer = _summary_writer(tflog_path)
-    previous_loss = 10.0
-    reset_flag = False
-    best_psnr = 0
+    seen, best_psnr, first_loss, reload_next = 0, 0, 10.0, False
     for epoch in range(start_epoch, n_epochs):
-        if reset_flag:                                         # the loss blew up last epoch: back to the saved state (:45-48)
+        if reload_next:                                        # the loss blew up last epoch: back to the saved state (:45-48)
             saved = torch.load(save_model_path, map_location=device, weights_only=False)
             single_iterate_solver.load_state_dict(saved['solver_state_dict'])
             optimizer.load_state_dict(saved['optimizer_state_dict'])
-        reset_flag = False
-        psnr_sum = 0
-        loss = None
-        for ii, sample_batch in enumerate(train_dataloader):
-            cur_nimg += sample_batch['gt'].size(0)
+            reload_next = False
+        epoch_psnr, loss = 0, None
+        for step, batch in enumerate(train_dataloader):
+            seen += batch['gt'].size(0)
             optimizer.zero_grad()
-            gt_batch = sample_batch['gt'].to(device)
-            y = sample_batch['meas'].to(device)
-            Phi = sample_batch['mask'].to(device)
-            Phi_sum = operators.phi_sum(Phi)
-            with torch.no_grad():
-                x0 = operators.initial_point(y, Phi, Phi_sum, gt_batch)
-            reconstruction = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=x0)
-            loss = loss_function(reconstruction, gt_batch)
+            rec, gt, loss = _step(batch, deep_eq_module, loss_function, device)
             if np.isnan(loss.item()):
                 print('Loss is nan!')
-                reset_flag = True
+                reload_next = True
                 break
             loss.backward()
             optimizer.step()
-            if ii == 0:
-                previous_loss = loss.item()
-            PSNR = harness.psnr(reconstruction.clip(0, 1).cpu().detach().numpy(), gt_batch.cpu().detach().numpy())
-            psnr_sum += PSNR
-            stats = OrderedDict([('main/PSNR', PSNR), ('main/loss', loss.mean().item()),
-                                 ('config/lr', optimizer.param_groups[0]['lr']), ('main/best_PSNR', best_psnr)])
+            if step == 0:
+                first_loss = loss.item()
+            cur = harness.psnr(rec.clip(0, 1).cpu().detach().numpy(), gt.cpu().detach().numpy())
+            epoch_psnr += cur
+            lr = optimizer.param_groups[0]['lr']
+            stats = OrderedDict([('main/PSNR', cur), ('main/loss', loss.mean().item()), ('config/lr', lr), ('main/best_PSNR', best_psnr)])
             if history is not None:
-                history.append({"epoch": epoch, "step": ii, "loss": stats['main/loss'], "psnr": PSNR,
-                                "lr": stats['config/lr'], "forward_res": deep_eq_module.forward_res,
-                                "backward_res": getattr(deep_eq_module, "backward_res", None)})
+                history.append({"epoch": epoch, "step": step, "loss": stats['main/loss'], "psnr": cur, "lr": lr,
+                                "forward_res": deep_eq_module.forward_res, "backward_res": getattr(deep_eq_module, "backward_res", None)})
             if writer is not None:
-                walltime = time.time() - start_time
                 for name, value in stats.items():
-                    writer.add_scalar(name, value, global_step=int(cur_nimg), walltime=walltime)
+                    writer.add_scalar(name, value, global_step=int(seen), walltime=time.time() - t_start)
                 writer.flush()
-            if ii % print_every_n_steps == 0:
-                print("Epoch: " + str(epoch) + " Step: " + str(ii) + " Loss: " + str(loss.cpu().detach().numpy()) +
-                      " PSNR: %2.2f dB" % PSNR + " best PSNR (test): %2.2f dB" % best_psnr +
-                      " lr: %.8f" % optimizer.param_groups[0]['lr'], flush=True)
-            if (ii + 1) % save_every_n_steps == 0:
-                cur_psnr, all_images = harness.test_solver_sci(test_dataloader=test_dataloader, deep_eq_module=deep_eq_module,
-                                                               save_img_path=best_img_path, verbose=True, save_image=False,
-                                                               device=device)
-                if cur_psnr > best_psnr:
-                    best_psnr = cur_psnr
-                    for k in all_images:
-                        harness.write_png(k, all_images[k])
+            if step % print_every_n_steps == 0:                # the reference's log line, character for character (:94-98)
+                print(f"Epoch: {epoch} Step: {step} Loss: {loss.cpu().detach().numpy()} PSNR: {cur:2.2f} dB"
+                      f" best PSNR (test): {best_psnr:2.2f} dB lr: {lr:.8f}", flush=True)
+            if (step + 1) % save_every_n_steps == 0:           # mid-epoch evaluation; keep the best model and its images (:100-124)
+                test_psnr, images = _evaluate(deep_eq_module, test_dataloader, best_img_path, device, verbose=True, save_image=False)
+                if test_psnr > best_psnr:
+                    best_psnr = test_psnr
+                    for path, img in images.items():
+                        harness.write_png(path, img)
                     print('saving best model')
                     _save(save_model_path + 'best.ckpt', single_iterate_solver, epoch, optimizer, scheduler)
-        avg_psnr = psnr_sum / len(train_dataloader)
-        print('avg PSNR in epoch %d: %.2f dB' % (epoch, avg_psnr))
-        if (previous_loss - loss.item()) / previous_loss < -10.0 or np.isnan(loss.item()):
-            reset_flag = True
+        print('avg PSNR in epoch %d: %.2f dB' % (epoch, epoch_psnr / len(train_dataloader)))
+        if (first_loss - loss.item()) / first_loss < -10.0 or np.isnan(loss.item()):   # exploded: reload next epoch (:137-138)
+            reload_next = True
         scheduler.step()
-        if not reset_flag:
+        if not reload_next:
             _save(save_model_path + 'epoch_%d.ckpt' % epoch, single_iterate_solver, epoch, optimizer, scheduler)
             print('dict saved!')
-        harness.test_solver_sci(test_dataloader=test_dataloader, deep_eq_module=deep_eq_module, save_img_path=test_img_path,
-                                device=device)
+        _evaluate(deep_eq_module, test_dataloader, test_img_path, device)
