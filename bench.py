@@ -4,14 +4,16 @@
 Winograd 64->64 conv of the denoiser), the HBM roofline of the fused Phi/Phi^T + GAP-update kernel and the
 reference algorithm timed on the host CPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full reconstruction pass (x0 = Phi^T y, max_iter+1 f-calls, final all-gather) over
 one synthetic batch of `--batch-per-gpu` measurements per GPU (SURVEY 8(d) C3 recipe: Bernoulli(0.5)
-masks, x ~ U[0,1), y = Phi x, seed 1234+rank), inputs resident in HBM when the timed region starts.
+masks, x ~ U[0,1), y = Phi x, seed 1234), inputs resident in HBM when the timed region starts.
 Weak scaling: the per-GPU batch is fixed (BASELINE config 3: 64 measurements over 8 GPUs = 8 per GPU,
-which is also the 8 shipped measurements of config 2 at N=1).  Prints ONE JSON line on rank 0.
+which is also the 8 shipped measurements of config 2 at N=1).  The global batch is sharded by
+deqsci_amd.distributed.sharded_reconstruct (contiguous slices, no data-path collective, ONE all-gather).
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -25,7 +27,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from deqsci_amd import distributed  # noqa: E402  (no GPU work at import)
+
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3
 
 
 def mix_gap_bytes(bsz, H, W, B, n):
@@ -69,10 +74,67 @@ def cpu_baseline(iters_sample, full_calls, H, W, B, kind):
     fps = B / (per_call * full_calls)
     return {"value": fps, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"1 synthetic {H}x{W}x{B} measurement, {kind}, and_maxiters={iters_sample} ({f.calls} f-calls, "
-                      f"{dt:.1f} s) scaled per f-call to the reference's {full_calls} calls"}
+                      f"{dt:.1f} s) scaled per f-call to the {full_calls} f-calls the GPU step executes (the reference runs "
+                      f"one more, dead, call: new_equilibrium_utils_yaping.py:271-272)"}
 
 
-def main():
+class _PlumbingStub:
+    """--plumbing-selftest only: stands in for DEQSCIEngine so that the launcher, the rendezvous, the sharding and the
+    all-gather can be exercised on a box without GPUs (tests/test_distributed_gloo.py).  It reconstructs nothing
+    (returns Phi^T y) and its output line says so; it is not a fallback of any product path."""
+    m = 5
+
+    def __init__(self, iters):
+        self.last_info = {"f_calls": iters + 1, "res": None}
+
+    def reconstruct(self, y, Phi):
+        return (y.unsqueeze(-1) * Phi).contiguous()
+
+
+def hbm_stream_roofline(H, W, B, m, dev, bsz=64, sets=3, budget_s=1.5):
+    """Outside the timed frames/s region: the two fused streaming kernels of the DEQ loop on a working set far beyond
+    the 256 MiB Infinity Cache (bsz 64, three rotating buffer sets), HIP-event timed, algorithmic bytes per launch
+    against the 8 TB/s HBM3E peak (SURVEY 8(d) "making the GB/s honest")."""
+    from deqsci_amd import _hip
+    HWB, BHW = _hip.LAYOUT_HWB, _hip.LAYOUT_BHW
+    N = H * W * B
+    S = []
+    for s in range(sets):
+        g = torch.Generator(device=dev).manual_seed(77 + s)
+        zp = torch.randn(bsz, B, H, W, device=dev, generator=g)
+        Phip = (torch.rand(bsz, B, H, W, device=dev, generator=g) < 0.5).float()
+        y = torch.rand(bsz, H, W, device=dev, generator=g) * 4
+        Ps = _hip.phi_sum(Phip, BHW)
+        ws = _hip.AndersonWorkspace(bsz, N, m, dev)
+        ws.F.normal_(generator=g)
+        ws.G.normal_(generator=g)
+        ws.alpha[:, :m] = 1.0 / m
+        S.append((zp, Phip, y, Ps, ws, torch.empty_like(zp), torch.empty_like(zp)))
+    cases = {
+        "gap_update_bhw (K3)": (gap_bytes(bsz, H, W, B),
+                                lambda t: _hip.gap_update(t[0], t[1], t[2], t[3], BHW, BHW, out=t[5])),
+        f"mix_gap_bhw n={m} (K7+K3)": (mix_gap_bytes(bsz, H, W, B, m),
+                                       lambda t: _hip.anderson_mix_gap(t[4], 1.0, m, t[1], t[2], t[3], t[5], t[6], BHW)),
+    }
+    out = {}
+    for name, (nbytes, fn) in cases.items():
+        for i in range(2 * sets):
+            fn(S[i % sets])
+        torch.cuda.synchronize()
+        launches = max(sets, int(budget_s / len(cases) / (nbytes / 5e12)) // sets * sets)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(launches):
+            fn(S[i % sets])
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / launches
+        out[name] = {"achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * t, "launches_timed": launches}
+    return {"workload": f"bsz {bsz} at {H}x{W}x{B}, {sets} rotating buffer sets (working set >> 256 MiB Infinity Cache)", "kernels": out}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -86,47 +148,71 @@ def main():
     ap.add_argument("--no-fused-epilogue", action="store_true")
     ap.add_argument("--no-fused-edges", action="store_true")
     ap.add_argument("--no-winograd", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-hbm-stream", action="store_true")
+    ap.add_argument("--plumbing-selftest", action="store_true",
+                    help="CPU + gloo + a stub engine: exercises launcher/sharding/all-gather only (no GPU, no reconstruction)")
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import deqsci_amd
-    from deqsci_amd import _hip, checkpoint
+def build_engine(args, dev):
+    from deqsci_amd import checkpoint
     from deqsci_amd.cli import build_denoiser
     from deqsci_amd.engine import DEQSCIEngine
-
     # MIOpen find mode (cudnn.benchmark) is deliberately left off: on this conv it picks a slower igemm tile
     # (642 us vs 579 us) and writes that choice into the user find-db (measured, tools/gpu_12.sh).
-    H, W, B = (int(v) for v in args.size.split("x"))
-    bsz = args.batch_per_gpu
     net = build_denoiser(args.denoiser).eval()
     net.load_state_dict({k.replace("nonlinear_op.", ""): v for k, v in
                          checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
     net = net.to(dev)
-    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
-                       channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
-                       fused_edges=not args.no_fused_edges, winograd=not args.no_winograd)
-    y, Phi, _ = make_batch(bsz, H, W, B, 1234 + rank, dev)
-    gathered = torch.empty((world * bsz, H, W, B), device=dev, dtype=torch.float32) if world > 1 else None
+    kw = {}
+    if args.no_graph:
+        kw["use_graph"] = False
+    return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
+                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
+                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd, **kw)
 
-    # per-launch timing of the fused Phi/Phi^T+GAP-update kernel from the dispatch's own HIP-event
-    # timestamps (hipExtLaunchKernelGGL start/stop events on the stream the kernel runs on)
-    timer = _hip.KernelTimer()
-    conv_timer = _hip.KernelTimer()
-    timing_on = [False]
-    if not args.no_kernel_timing:
+
+def make_step(eng, y_global, Phi_global, gather_timer):
+    """One bench step = the product's multi-GPU entry point on the global batch: this rank's contiguous slice through
+    the engine, then the path's one all-gather (identity at world size 1)."""
+    def step():
+        return distributed.sharded_reconstruct(eng.reconstruct, y_global, Phi_global, timer=gather_timer)
+    return step
+
+
+def run_rank(args):
+    selftest = args.plumbing_selftest
+    if not selftest and not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    rank, world, local_rank, dev = distributed.init_from_env("gloo" if selftest else "nccl")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    H, W, B = (int(v) for v in args.size.split("x"))
+    bsz = args.batch_per_gpu
+    if selftest:
+        eng = _PlumbingStub(args.iters)
+        _hip = None
+    else:
+        from deqsci_amd import _hip
+        eng = build_engine(args, dev)
+    # the GLOBAL batch, generated identically on every rank (seed 1234); sharded_reconstruct cuts rank r's slice
+    y, Phi, _ = make_batch(world * bsz, H, W, B, 1234, dev)
+    gather_timer = distributed.GatherTimer()
+    step = make_step(eng, y, Phi, gather_timer)
+
+    # per-launch timing of the fused Phi/Phi^T+GAP-update kernel and of the Winograd conv from the dispatch's own
+    # HIP-event timestamps (hipExtLaunchKernelGGL start/stop events on the stream the kernel runs on); all events are
+    # created before the timed region and destroyed after it
+    timing = not (selftest or args.no_kernel_timing) and rank == 0
+    timer = conv_timer = None
+    conv_shape = []
+    if timing:
+        timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
+        conv_timer = _hip.KernelTimer(capacity=400)                 # a sample of launches is enough
+        timing_on = [False]
         orig = _hip.anderson_mix_gap
 
         def timed_mix_gap(ws, beta, n, *a):
@@ -135,36 +221,34 @@ def main():
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
         orig_wg = _hip.conv3x3_c64_winograd
-        conv_shape = []
 
         def timed_winograd(x, U, bias=None, relu=True, out=None):
-            if not timing_on[0] or len(conv_timer.pairs) >= 400:      # a sample of launches is enough
+            if not timing_on[0] or conv_timer.full:
                 return orig_wg(x, U, bias, relu, out)
             conv_shape[:] = [x.shape[0], x.shape[2], x.shape[3]]
             return conv_timer.winograd(x, U, bias, relu, out)
         _hip.conv3x3_c64_winograd = timed_winograd
 
-    def step():
-        rec = eng.reconstruct(y, Phi)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, rec)          # the path's one collective (RCCL over xGMI)
-        return rec
-
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     fence()
-    timing_on[0] = True
+    gather_timer.total_seconds()
+    gather_timer.seconds, gather_timer.calls = 0.0, 0
+    if timing:
+        timing_on[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    timing_on[0] = False
+    if timing:
+        timing_on[0] = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,6 +256,7 @@ def main():
 
     frames = world * bsz * B * args.steps
     value = frames / elapsed
+    f_calls = eng.last_info["f_calls"]
     out = {
         "metric": "reconstructed frames/sec at 256x256x8, 180 DEQ iters",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,30 +266,35 @@ def main():
                                f"(BASELINE config 3 per-GPU shard = config 2's 8 measurements at N=1); "
                                f"{args.denoiser} denoiser ({'net_gray.pth weights, substitute for the missing ffdnet.ckpt' if args.denoiser == 'ffdnet' else 'cnn.ckpt'}), "
                                f"Anderson m=5 lam=1e-2 beta=1, and_maxiters={args.iters}, tol=1e-5",
-                   "global_batch": world * bsz, "frames_per_measurement": B, "f_calls_per_step": eng.last_info["f_calls"],
+                   "global_batch": world * bsz, "frames_per_measurement": B, "f_calls_per_step": f_calls,
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU"},
         "final_res": eng.last_info["res"],
+        "allgather_ms_per_step": 1e3 * gather_timer.total_seconds() / max(args.steps, 1) if world > 1 else 0.0,
     }
+    if selftest:
+        out.update({"metric": "PLUMBING SELFTEST - launcher/sharding/all-gather only, no reconstruction", "data": "selftest",
+                    "dtype": "none", "value": 0.0})
     if rank == 0:
-        ms = timer.durations_ms()
+        ms = timer.durations_ms() if timing else []
         if ms:
             avg_s = 1e-3 * sum(ms) / len(ms)
             nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")     # rocprofv3 --pmc passes, tools/pmc_traffic.sh
-            if os.path.exists(tfile):
-                with open(tfile) as fh:
-                    for rec in json.load(fh):
-                        k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
-                        if rec["bsz"] == bsz and rec["size"] == args.size and k:
-                            traffic = k["hbm_bytes_per_launch"]
-            out["hbm_roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}, 3> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update)",
-                               "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
-                                   "note": "the fused Phi/Phi^T + GAP-update kernel BASELINE.json's north_star sets its >= 60 % of HBM "
-                                           "peak target on (bsz 64, working set >> Infinity Cache: profiles/r01_kernel_bench_bsz64.jsonl)"}
-        cms = conv_timer.durations_ms()
+            for tname in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
+                tfile = os.path.join(ROOT, "profiles", tname)
+                if traffic is None and os.path.exists(tfile):
+                    with open(tfile) as fh:
+                        for rec in json.load(fh):
+                            k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
+                            if rec["bsz"] == bsz and rec["size"] == args.size and k:
+                                traffic = k["hbm_bytes_per_launch"]
+            out["hbm_roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update), in the DEQ loop",
+                                   "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
+                                   "note": f"in-loop figure at bsz {bsz}: the kernel's {nbytes / 2**20:.0f} MiB working set sits partly in the "
+                                           "256 MiB Infinity Cache; hbm_stream_roofline is the same kernel on a working set far beyond it"}
+        cms = conv_timer.durations_ms() if timing else []
         if cms:
             # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call).
             # Algorithmic flops per launch = the MFMA flops of the Winograd F(2x2,3x3) form = direct flops / 2.25,
@@ -213,27 +303,47 @@ def main():
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
             cavg = 1e-3 * sum(cms) / len(cms)
             n_conv = 13 if args.denoiser == "ffdnet" else 2       # 64->64 layers per denoiser call (models.py:53-58 / SimpleCNN_models.py:47-53)
-            share = cavg * n_conv * eng.last_info["f_calls"] / (elapsed / args.steps)
+            share = cavg * n_conv * f_calls / (elapsed / args.steps)
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            wfile = os.path.join(ROOT, "profiles", "r01_pmc_winograd.json")
-            if os.path.exists(wfile):
-                with open(wfile) as fh:
-                    rec = json.load(fh)
-                if rec.get("shape") == [nimg, 64, ch, cw]:
-                    wtraffic = rec["hbm_bytes_per_launch"]
+            for wname in ("r02_pmc_winograd.json", "r01_pmc_winograd.json"):
+                wfile = os.path.join(ROOT, "profiles", wname)
+                if wtraffic is None and os.path.exists(wfile):
+                    with open(wfile) as fh:
+                        rec = json.load(fh)
+                    if rec.get("shape") == [nimg, 64, ch, cw]:
+                        wtraffic = rec["hbm_bytes_per_launch"]
             out["roofline"] = {"kernel": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)",
-                               "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                               "frac": direct / 2.25 / cavg / 1e12 / 157.3, "traffic": wtraffic,
+                               "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": direct / 2.25 / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
                                "algorithmic_flops_per_launch": direct / 2.25, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
                                "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3)}
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_iters, args.iters + 2, H, W, B, args.denoiser)
+        if timing:
+            timer.close()
+            conv_timer.close()
+        if world == 1 and not selftest:
+            if not args.no_hbm_stream:
+                del y, Phi
+                out["hbm_stream_roofline"] = hbm_stream_roofline(H, W, B, eng.m, dev)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_iters, f_calls, H, W, B, args.denoiser)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if distributed.relaunch_needed(args.gpus):
+        # started as plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (counting
+        # devices does not initialise it) and the ranks are NEW processes, one per GPU.
+        if not args.plumbing_selftest and torch.cuda.device_count() < args.gpus:
+            sys.exit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        sys.exit(distributed.launch_ranks([sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv),
+                                          args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

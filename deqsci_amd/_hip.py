@@ -400,48 +400,67 @@ def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):
 
 # ----------------------------------------------------------------------------- measurement helpers (bench.py)
 class KernelTimer:
-    """Per-launch kernel durations of the fused mix+GAP kernel from the dispatch's own timestamps
-    (deqsci_anderson_mix_gap_timed_f32); read after the stream has been synchronised."""
+    """Per-launch kernel durations from the dispatch's own start/stop timestamps (the *_timed_f32 entry points record
+    HIP events around the kernel on the stream it runs on).  All events are created up front (`capacity` launches) and
+    destroyed by close(); launches beyond the capacity run untimed.  Read durations after synchronising the stream."""
 
-    def __init__(self):
-        self.pairs = []
+    _plain_mix_gap = staticmethod(anderson_mix_gap)          # bound here: callers may monkey-patch the module names
+    _plain_winograd = staticmethod(conv3x3_c64_winograd)
 
-    def _event(self):
-        h = _ptr()
-        _check(load().deqsci_event_create(ctypes.byref(h)), "event_create")
-        return h
+    def __init__(self, capacity=0):
+        self.events = []
+        self.used = 0
+        for _ in range(2 * capacity):
+            h = _ptr()
+            _check(load().deqsci_event_create(ctypes.byref(h)), "event_create")
+            self.events.append(h)
+
+    def _pair(self):
+        if 2 * self.used + 1 >= len(self.events):
+            return None
+        e = self.events[2 * self.used], self.events[2 * self.used + 1]
+        self.used += 1
+        return e
+
+    def reset(self):
+        self.used = 0
+
+    @property
+    def full(self):
+        return 2 * self.used + 1 >= len(self.events)
 
     def mix_gap(self, ws, beta, n, phi, y, phisum, x_out, z1, layout):
+        ev = self._pair()
+        if ev is None:
+            return self._plain_mix_gap(ws, beta, n, phi, y, phisum, x_out, z1, layout)
         bsz, H, W, B = _dims(layout, z1.shape)
-        e0, e1 = self._event(), self._event()
         with _dev(ws.F):
             _check(load().deqsci_anderson_mix_gap_timed_f32(
                 _p(ws.F), _p(ws.G), _p(ws.alpha), float(beta), n, ws.m, _p(phi, "Phi"), _p(y, "y"), _p(phisum, "Phi_sum"),
-                _p(x_out, "x_out"), _p(z1, "z1"), bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream(), e0, e1),
+                _p(x_out, "x_out"), _p(z1, "z1"), bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream(), ev[0], ev[1]),
                 "anderson_mix_gap_timed")
-        self.pairs.append((e0, e1))
 
     def winograd(self, x, u_packed, bias=None, relu=True, out=None):
+        ev = self._pair()
+        if ev is None:
+            return self._plain_winograd(x, u_packed, bias, relu, out)
         n, c, H, W = x.shape
         o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-        e0, e1 = self._event(), self._event()
         with _dev(x):
             _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True),
-                                                                o.data_ptr(), n, H, W, 1 if relu else 0, _stream(), e0, e1),
+                                                                o.data_ptr(), n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]),
                    "conv3x3_c64_winograd_timed")
-        self.pairs.append((e0, e1))
         return o
 
     def durations_ms(self):
         out = []
         ms = _f32()
-        for e0, e1 in self.pairs:
-            _check(load().deqsci_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "event_elapsed_ms")
+        for i in range(self.used):
+            _check(load().deqsci_event_elapsed_ms(self.events[2 * i], self.events[2 * i + 1], ctypes.byref(ms)), "event_elapsed_ms")
             out.append(ms.value)
         return out
 
     def close(self):
-        for e0, e1 in self.pairs:
-            load().deqsci_event_destroy(e0)
-            load().deqsci_event_destroy(e1)
-        self.pairs = []
+        for e in self.events:
+            load().deqsci_event_destroy(e)
+        self.events, self.used = [], 0

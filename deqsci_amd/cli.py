@@ -1,9 +1,13 @@
 """Command-line driver with the reference's flags (video_sci_proxgrad.py:23-49), inference only.
 
     python -m deqsci_amd.cli --denoiser ffdnet --loadpath deqsci_amd/weights/ffdnet_gray.npz \\
-        --testpath data/test_gray/ --and_maxiters 180 --inference True
+        --testpath data/test_gray/ --and_maxiters 180 --inference True [--gpu_ids 0,1,2,3]
 
-Flags keep the reference's names; they are typed here (the reference leaves several as strings).
+Every flag of the reference parses (so its test_*.sh command lines run unchanged); the training-only ones
+(--n_epochs --batch_size --lr --lr_gamma --sched_step --trainpath --print_every_n_steps --save_every_n_steps --etainit
+--sigma) are accepted and ignored, and `--inference False` is refused: training is outside this build.
+`--gpu_ids a,b,..` with more than one id is this build's addition: one process per listed GPU, every clip's
+measurements sharded over them (deqsci_amd.distributed), rank 0 prints and writes the PNGs.
 """
 import argparse
 import os
@@ -12,11 +16,13 @@ import time
 
 import torch
 
-from . import checkpoint
-from .harness import SCITestDataset, test_solver_sci
+from . import checkpoint, distributed
+from .harness import SCITestDataset, evaluate, png_payloads, write_png
 from .networks import DnCNN, FFDNet
 from .operators import A_torch_, At_torch_
 from .solvers import DEQFixedPoint, EquilibriumProxGradSCI, andersonexp
+
+SHIPPED = {'ffdnet': 'ffdnet_gray', 'SimpleCNN': 'cnn', 'RealSN_SimpleCNN': 'rsn_cnn'}
 
 
 def build_denoiser(name, n_channels=1):
@@ -40,64 +46,75 @@ def build_pipeline(denoiser, loadpath=None, and_maxiters=100, and_m=5, and_beta=
     return solver, deq
 
 
-def train(args):
-    """The training branch of video_sci_proxgrad.py (:129-133,:190-202,:258-268): <trainpath>/{gt/,measurement/,mask.mat},
-    Adam + StepLR, MSE(mean), checkpoints under <savepath>/model/, images under <savepath>/img/{train,test,best}/."""
-    from .harness import SCITrainingDatasetSubset, train_solver_sci
-    save_model_path = args.savepath + 'model/'
-    img = {k: args.savepath + f'img/{k}/' for k in ('train', 'test', 'best')}
-    for path in (save_model_path, *img.values()):
-        os.makedirs(path, exist_ok=True)
-    dataset = SCITrainingDatasetSubset(args.trainpath + 'gt/', args.trainpath + 'measurement/', args.trainpath + 'mask.mat')
-    loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=args.batch_size, shuffle=True, drop_last=True, pin_memory=True)
-    test_loader = torch.utils.data.DataLoader(dataset=SCITestDataset(args.testpath), batch_size=1, shuffle=False, drop_last=True)
-    solver, deq = build_pipeline(args.denoiser, args.loadpath or None, args.and_maxiters, args.and_m, args.and_beta)
-    solver.nonlinear_op.train()
-    optimizer = torch.optim.Adam(params=solver.parameters(), lr=args.lr)
-    scheduler = torch.optim.lr_scheduler.StepLR(optimizer=optimizer, step_size=args.sched_step, gamma=args.lr_gamma)
-    train_solver_sci(single_iterate_solver=solver, train_dataloader=loader, test_dataloader=test_loader, optimizer=optimizer,
-                     save_model_path=save_model_path, deep_eq_module=deq, loss_function=torch.nn.MSELoss(reduction='mean'),
-                     n_epochs=args.n_epochs, scheduler=scheduler, print_every_n_steps=args.print_every_n_steps,
-                     save_every_n_steps=args.save_every_n_steps, start_epoch=0, train_img_path=img['train'],
-                     test_img_path=img['test'], best_img_path=img['best'], tflog_path=args.savepath)
-
-
-def main(argv=None):
+def parser():
     p = argparse.ArgumentParser(description="DEQ-SCI inference on MI355X")
-    p.add_argument('--n_epochs', default=80, type=int)
-    p.add_argument('--batch_size', type=int, default=1)
+    p.add_argument('--gpu_ids', default='0')
     p.add_argument('--and_maxiters', default=100, type=int)
     p.add_argument('--and_beta', type=float, default=1.0)
     p.add_argument('--and_m', type=int, default=5)
     p.add_argument('--denoiser', default='ffdnet')
     p.add_argument('--savepath', default="./save/test/")
-    p.add_argument('--loadpath', default=None)
+    p.add_argument('--loadpath', default='')
     p.add_argument('--testpath', default="./data/test_gray/")
     p.add_argument('--inference', default='True')
-    p.add_argument('--gpu_ids', default='0')
-    p.add_argument('--lr', type=float, default=0.0001)
-    p.add_argument('--lr_gamma', type=float, default=0.9)
-    p.add_argument('--sched_step', type=int, default=10)
-    p.add_argument('--trainpath', default="./data/train/")
-    p.add_argument('--print_every_n_steps', type=int, default=1)
-    p.add_argument('--save_every_n_steps', type=int, default=50)
-    args = p.parse_args(argv)
+    ignored = p.add_argument_group("accepted for command-line compatibility, unused by inference")
+    ignored.add_argument('--n_epochs', default=80)
+    ignored.add_argument('--batch_size', type=int, default=1)
+    ignored.add_argument('--lr', type=float, default=0.0001)
+    ignored.add_argument('--etainit', type=float, default=0.9)
+    ignored.add_argument('--lr_gamma', type=float, default=0.9)
+    ignored.add_argument('--sched_step', type=int, default=10)
+    ignored.add_argument('--trainpath', default="")
+    ignored.add_argument('--print_every_n_steps', type=int, default=1)
+    ignored.add_argument('--save_every_n_steps', type=int, default=50)
+    ignored.add_argument('--sigma', type=int, default=0)
+    return p
+
+
+def run(args):
+    """One rank (or the only process): build, evaluate every clip, rank 0 reports."""
+    rank, world, _, dev = distributed.init_from_env("nccl")
+    loadpath = args.loadpath or checkpoint.shipped(SHIPPED[args.denoiser])
+    _, deq = build_pipeline(args.denoiser, loadpath, args.and_maxiters, args.and_m, args.and_beta, device=dev)
+    if rank == 0:
+        print('loaded dict!')
+        os.makedirs(args.savepath, exist_ok=True)
+    images = {}
+
+    def on_clip(r):
+        if rank == 0:
+            images.update(png_payloads(r, args.savepath))
+            print([r.name], '  PSNR: %.2f dB' % r.mean_psnr)
+    t0 = time.time()
+    avg, results = evaluate(deq, SCITestDataset(args.testpath), device=dev, on_clip=on_clip)
+    dt = time.time() - t0
+    if rank == 0:
+        print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg)
+        for path, img in images.items():
+            write_png(path, img)
+        n = sum(r.frames for r in results)
+        print(f"{n} frames in {dt:.2f} s -> {n / dt:.2f} frames/s on {world} GPU(s) (excl. PNG export)")
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return avg
+
+
+def main(argv=None):
+    args = parser().parse_args(argv)
+    if str(args.inference).lower() in ('false', '0', ''):
+        sys.exit("deqsci_amd is the inference hot path only: --inference False (training) is out of scope")
+    if args.denoiser not in SHIPPED:
+        raise NotImplementedError('unknown denoiser!')
+    ids = [int(v) for v in str(args.gpu_ids).split(',') if v != '']
     if not torch.cuda.is_available():
         sys.exit("deqsci_amd needs an MI355X: there is no CPU path")
-    torch.cuda.set_device(int(str(args.gpu_ids).split(',')[0]))
-    if str(args.inference).lower() in ('false', '0', ''):
-        return train(args)
-    loadpath = args.loadpath or checkpoint.shipped({'ffdnet': 'ffdnet_gray', 'SimpleCNN': 'cnn',
-                                                    'RealSN_SimpleCNN': 'rsn_cnn'}[args.denoiser])
-    _, deq = build_pipeline(args.denoiser, loadpath, args.and_maxiters, args.and_m, args.and_beta)
-    print('loaded dict!')
-    loader = torch.utils.data.DataLoader(dataset=SCITestDataset(args.testpath), batch_size=1, shuffle=False, drop_last=True)
-    os.makedirs(args.savepath, exist_ok=True)
-    t0 = time.time()
-    avg, images = test_solver_sci(deq, test_dataloader=loader, save_img_path=args.savepath)
-    dt = time.time() - t0
-    print(f"{len(images)} frames in {dt:.2f} s -> {len(images) / dt:.2f} frames/s (incl. PNG export)")
-    return avg
+    if distributed.relaunch_needed(len(ids)):
+        cmd = [sys.executable, "-m", "deqsci_amd.cli"] + list(sys.argv[1:] if argv is None else argv)
+        sys.exit(distributed.launch_ranks(cmd, len(ids), device_ids=ids))
+    if len(ids) == 1 and "LOCAL_RANK" not in os.environ:
+        os.environ["LOCAL_RANK"] = str(ids[0])
+    return run(args)
 
 
 if __name__ == "__main__":

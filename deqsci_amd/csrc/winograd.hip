@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             const int iy = py0 + rpr[k], ix = px0 + rpc[k];
             rok[k] = rdst[k] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
             const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            roff[k] = (uint32_t)(((cy * W + cx) * 64 + 4 * (tid & 1)) * 4);
+            roff[k] = ((uint32_t)(cy * W + cx) * 64u + 4u * (uint32_t)(tid & 1)) * 4u;   // < 2^32: H*W < 2^24 (launcher)
         }
     };
     // Two register sets: the chunk fetched during stage c is stored to LDS at the end of stage c+1, a whole stage (about
@@ -450,7 +450,8 @@ static int winograd_impl(const float* x, const float* u_packed, const float* bia
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     const int64_t tiles_x = ceil_div(ceil_div(W, 2), 8), tiles_y = ceil_div(ceil_div(H, 2), WG_TROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
-    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W > (int64_t)INT32_MAX / 64) return DEQSCI_ERR_UNSUPPORTED;   // 32-bit offsets
+    // 32-bit arithmetic in the kernel: tile indices, and the per-image BYTE offset of a pixel (H*W*64 channels*4 B < 2^32)
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W >= (int64_t)1 << 24) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t resident = (8 / WG_WAVES) * (int64_t)num_cus(); // persistent workgroups: 16 wavefronts (2 per SIMD) on every CU
     const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));

@@ -5,7 +5,21 @@ training/sci_equilibrium_training.py:157,171), so a global batch of M measuremen
 contiguous slices, one per rank, every rank runs the single-GPU engine on its slice with no
 data-path collective, and ONE all_gather_into_tensor (RCCL over xGMI; gloo in the CPU tests) at
 the end assembles the (M,H,W,B) result on every rank.  One process per GPU.
+
+    shard_bounds          contiguous slice of a rank
+    gather_shards         local shard -> all ranks' shards (THE collective of the path; times itself)
+    sharded_reconstruct   global batch on every rank -> slice, reconstruct, gather_shards
+    launch_ranks          start N fresh child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
+                          environment) - what `bench.py --gpus N` and `cli --gpu_ids 0,1,..` use when
+                          they are not already running under torch.distributed.run
+    init_from_env         process-group set-up of one rank from that environment
 """
+import os
+import socket
+import subprocess
+import sys
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -17,29 +31,147 @@ def shard_bounds(M, world_size, rank):
     return lo, min(lo + per, M), per
 
 
-def sharded_reconstruct(reconstruct_fn, y, Phi, group=None, **kw):
+class GatherTimer:
+    """Accumulates the time spent in the path's one collective (reported next to the throughput)."""
+
+    def __init__(self):
+        self.seconds, self.calls, self._pending = 0.0, 0, []
+
+    def add(self, start, stop):
+        self._pending.append((start, stop))
+        self.calls += 1
+
+    def total_seconds(self):
+        for a, b in self._pending:
+            if isinstance(a, float):
+                self.seconds += b - a
+            else:                                   # torch.cuda.Event pair; caller has synchronised the device
+                self.seconds += a.elapsed_time(b) * 1e-3
+        self._pending = []
+        return self.seconds
+
+
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def gather_shards(local, group=None, out=None, timer=None):
+    """local (per,...) on every rank -> (R*per,...) on every rank, rank-major.  No process group (or a group of
+    one) = identity.  `out` may be a preallocated result buffer.  With `timer`, the collective is bracketed by
+    events on the current stream (perf_counter for CPU tensors)."""
+    if not _active(group):
+        return local
+    R = dist.get_world_size(group)
+    full = out if out is not None else torch.empty((R * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype,
+                                                     device=local.device)
+    if timer is not None and local.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        dist.all_gather_into_tensor(full, local, group=group)
+        e1.record()
+        timer.add(e0, e1)
+    elif timer is not None:
+        t0 = time.perf_counter()
+        dist.all_gather_into_tensor(full, local, group=group)
+        timer.add(t0, time.perf_counter())
+    else:
+        dist.all_gather_into_tensor(full, local, group=group)
+    return full
+
+
+def sharded_reconstruct(reconstruct_fn, y, Phi, group=None, timer=None, **kw):
     """y (M,H,W), Phi (M|1,H,W,B) hold the GLOBAL batch on every rank (or are generated
     identically); returns the (M,H,W,B) reconstruction on every rank.  `reconstruct_fn(y_local,
     Phi_local, **kw) -> (n,H,W,B)`."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active(group):
         return reconstruct_fn(y, Phi, **kw)
     R, r = dist.get_world_size(group), dist.get_rank(group)
     M = y.shape[0]
     lo, hi, per = shard_bounds(M, R, r)
     shared = Phi.dim() == 3 or (Phi.shape[0] == 1 and M > 1)
     out_shape = (per,) + tuple(y.shape[1:]) + (Phi.shape[-1],)
-    local = torch.zeros(out_shape, dtype=torch.float32, device=y.device)
-    if hi > lo:
-        local[:hi - lo] = reconstruct_fn(y[lo:hi].contiguous(), Phi if shared else Phi[lo:hi].contiguous(), **kw)
-    full = torch.empty((R * per,) + out_shape[1:], dtype=torch.float32, device=y.device)
-    dist.all_gather_into_tensor(full, local, group=group)
-    return full[:M]
+    if hi - lo == per:
+        local = reconstruct_fn(y[lo:hi].contiguous(), Phi if shared else Phi[lo:hi].contiguous(), **kw).contiguous()
+    else:                                           # ragged tail / idle rank: pad the shard with zeros
+        local = torch.zeros(out_shape, dtype=torch.float32, device=y.device)
+        if hi > lo:
+            local[:hi - lo] = reconstruct_fn(y[lo:hi].contiguous(), Phi if shared else Phi[lo:hi].contiguous(), **kw)
+    return gather_shards(local, group=group, timer=timer)[:M]
 
 
 def gather_scalars(values, group=None):
     """Per-measurement scalars (PSNR, res, ...) of the local shard -> list over all ranks."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active(group):
         return list(values)
     out = [None] * dist.get_world_size(group)
     dist.all_gather_object(out, list(values), group=group)
     return [v for part in out for v in part]
+
+
+# ----------------------------------------------------------------------------- launching ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(argv, n, device_ids=None, timeout=None):
+    """Run `argv` (a full command line) as n child processes, rank r with RANK=r, LOCAL_RANK=device_ids[r] (default r),
+    WORLD_SIZE=n and a fresh 127.0.0.1 rendezvous port.  Children are NEW processes (never an exec of this one, which
+    may already have initialised the GPU); rank 0 inherits stdout, every rank inherits stderr.  Returns the largest
+    exit code; if a rank fails the others are terminated."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r if device_ids is None else device_ids[r]), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC is the only one this driver supports
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = None if timeout is None else time.time() + timeout
+    worst = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0:
+                worst = max(worst, rc if rc > 0 else 1)
+                for q in live:
+                    q.terminate()
+        if deadline is not None and time.time() > deadline:
+            for q in live:
+                q.kill()
+            return 124
+        time.sleep(0.05)
+    return worst
+
+
+def init_from_env(backend=None):
+    """-> (rank, world, local_rank, device).  Creates the default process group when WORLD_SIZE > 1
+    (backend "nccl" = RCCL on a GPU box, "gloo" for CPU plumbing tests)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return rank, world, local_rank, device
+
+
+def relaunch_needed(n):
+    """True when n > 1 ranks were asked for and this process is not already one of them."""
+    return n > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1

@@ -92,18 +92,21 @@ class _Denoiser:
         self.tail_w = self.head_w = None
         self.plain_head_w = self.plain_tail_w = None
         from .networks import DnCNN
+        from .networks.simplecnn import RealSNConv2d
         seq = None
         if isinstance(net, FFDNet) and not net.training and net.num_input_channels == 1 and self.fold_bn:
             seq = net.intermediate_dncnn.itermediate_dncnn
         elif isinstance(net, DnCNN) and not net.training and self.fold_bn and all(
-                isinstance(mod, (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU)) for mod in net.dncnn):
-            seq = net.dncnn                       # SimpleCNN / DnCNN-17: conv [+BN] + ReLU blocks
+                isinstance(mod, (torch.nn.Conv2d, RealSNConv2d, torch.nn.BatchNorm2d, torch.nn.ReLU)) for mod in net.dncnn):
+            seq = net.dncnn                       # SimpleCNN / RealSN_SimpleCNN / DnCNN-17: conv [+BN] + ReLU blocks
         if seq is not None:
             mods = list(seq)
             layers, i = [], 0
             while i < len(mods):
                 conv = mods[i]
-                assert isinstance(conv, torch.nn.Conv2d) and conv.bias is None
+                # RealSNConv2d in eval mode = conv2d with its stored, already normalised `weight` buffer
+                # (networks/provable/model/conv_sn_chen.py:65-67): the same HIP kernels run it
+                assert isinstance(conv, RealSNConv2d) or (isinstance(conv, torch.nn.Conv2d) and conv.bias is None)
                 w, b = conv.weight.detach(), None
                 i += 1
                 if i < len(mods) and isinstance(mods[i], torch.nn.BatchNorm2d):
@@ -240,7 +243,7 @@ class DEQSCIEngine:
             ws = _hip.AndersonWorkspace(bsz, H * W * B, m, device, res_rows=rows)
             ws.xbuf = [torch.empty((bsz, B, H, W), device=device, dtype=torch.float32) for _ in range(2)]
             ws.z1 = torch.empty((bsz, B, H, W), device=device, dtype=torch.float32)
-            ws.host_res = torch.zeros((rows, 1 + bsz), dtype=torch.float32).pin_memory()
+            ws.host_res = torch.full((rows, 1 + bsz), float('inf'), dtype=torch.float32).pin_memory()   # unfinished copy != converged
             self._ws = {key: ws}          # one live shape at a time: history is bsz*m*N*8 bytes
         return ws
 
@@ -267,6 +270,10 @@ class DEQSCIEngine:
         `self.last_info` holds res (whole batch), per-sample res, iterations and f-call count."""
         if not (isinstance(y, torch.Tensor) and y.is_cuda):
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
+        with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
+            return self._reconstruct(y, Phi, Phi_sum, initial_point)
+
+    def _reconstruct(self, y, Phi, Phi_sum, initial_point):
         y = _hip.f32c(y)
         bsz, H, W = y.shape
         Phi4 = _hip.f32c(Phi if Phi.dim() == 4 else Phi.unsqueeze(0))

@@ -1,80 +1,45 @@
-"""Evaluation harness with the reference's behaviour.
+"""Evaluation harness: clips in, reconstructions + PSNR out.
 
-    load_test_data / SCITestDataset   utils/sci_dataloader.py:241-274 (v5 .mat, sorted file order)
-    load_mat / SCITrainingDatasetSubset   ibid. :163-239 (training pairs gt/ + measurement/ + mask.mat)
-    train_solver_sci                  training/sci_equilibrium_training.py:28-150 (implemented in training.py)
-    test_solver_sci                   training/sci_equilibrium_training.py:152-205
-    psnr                              skimage.metrics.peak_signal_noise_ratio for float input, range 1
-    tensor_to_np                      ibid. :19-21 (PNG payload: clip(0,1)*255)
+The unit of work here is a CLIP (one .mat file: mask, M snapshot measurements, 8*M ground-truth frames).
+`reconstruct_clip` hands ALL measurements of a clip to the DEQ module as one batch sharing the clip's mask
+(the reference feeds them one by one, training/sci_equilibrium_training.py:171-181; rows of a batch are
+independent problems, so the results are the same unless the whole-batch tolerance test fires - SURVEY 8(a)
+caveat), optionally sharded over the ranks of a process group (deqsci_amd.distributed).  `evaluate` walks a
+directory of clips; `test_solver_sci` is a thin adapter with the reference's signature, return value,
+printed lines and PNG naming (ibid. :152-205) on top of the two.
+
+    load_test_data / SCITestDataset   utils/sci_dataloader.py:241-274 (MATLAB v5 files, sorted file order)
+    psnr                              skimage.metrics.peak_signal_noise_ratio for float input, data range 1
+    frame_payload                     the float image the reference hands to cv2.imwrite (ibid. :19-21)
 """
 import math
 import os
+from dataclasses import dataclass, field
 
 import numpy as np
 import torch
 
-from . import operators
+from . import distributed, operators
+
+FIRST_MEASUREMENT_ONLY = ("drop", "runner")      # clips the reference scores on snapshot 0 only (:167-168)
 
 
 def load_test_data(matfile):
+    """-> {'gt' (H,W,B*M) in [0,1], 'mask' (H,W,B), 'meas' (H,W,M) scaled by 1/255}, all float32."""
     import scipy.io as sio
     try:
         f = sio.loadmat(matfile)
         meas, mask, orig = np.float32(f['meas']), np.float32(f['mask']), np.float32(f['orig'])
-    except NotImplementedError:                           # MATLAB v7.3 = HDF5, stored in MATLAB (column-major) order
+    except NotImplementedError as e:                      # MATLAB v7.3 = HDF5 (utils/sci_dataloader.py:249-254)
         try:
             import h5py
-        except ImportError as e:
+        except ImportError:
             raise NotImplementedError(f"{matfile}: MATLAB v7.3 files need h5py, which is not installed") from e
-        with h5py.File(matfile, 'r') as f:                # utils/sci_dataloader.py:249-254
+        with h5py.File(matfile, 'r') as f:                # HDF5 keeps MATLAB's column-major order: transpose back
             meas = np.float32(f['meas']).transpose()
             mask = np.float32(f['mask']).transpose()
             orig = np.float32(f['orig']).transpose()
     return {'gt': orig / 255, 'mask': mask, 'meas': meas / 255}
-
-
-def load_mat(location, key):
-    """utils/sci_dataloader.py:163-214: one array of the TRAINING set.  key 'gt' (variable patch_save | p1 | p2 | p3, /255),
-    'meas' (/255) or 'mask'; MATLAB v5 files through scipy, v7.3 (HDF5, column-major: transposed back) through h5py."""
-    import scipy.io as sio
-
-    def pick(f):
-        if key == 'gt':
-            for name in ('patch_save', 'p1', 'p2', 'p3'):
-                if name in f:
-                    return np.asarray(f[name]) / 255
-            raise KeyError(f"{location}: none of patch_save/p1/p2/p3")
-        if key == 'meas':
-            return np.asarray(f['meas']) / 255
-        if key == 'mask':
-            return np.asarray(f['mask'])
-        raise KeyError(f"unknown key {key!r}")
-    try:
-        return np.float32(pick(sio.loadmat(location)))
-    except NotImplementedError:
-        try:
-            import h5py
-        except ImportError as e:
-            raise NotImplementedError(f"{location}: MATLAB v7.3 files need h5py, which is not installed") from e
-        with h5py.File(location, 'r') as f:
-            return np.float32(pick(f)).transpose()
-
-
-class SCITrainingDatasetSubset(torch.utils.data.Dataset):
-    """utils/sci_dataloader.py:218-239: <gt_directory>/<name>.mat and <meas_directory>/<name>.mat pairs, one shared mask."""
-
-    def __init__(self, gt_directory, meas_directory, mask_location):
-        names = directory_filelist(gt_directory)
-        self.full_gt_filelist = [gt_directory + n for n in names]
-        self.full_meas_filelist = [meas_directory + n for n in names]
-        self.mask = load_mat(mask_location, 'mask')
-
-    def __len__(self):
-        return len(self.full_gt_filelist)
-
-    def __getitem__(self, item):
-        return {'gt': load_mat(self.full_gt_filelist[item], 'gt'), 'mask': self.mask,
-                'meas': load_mat(self.full_meas_filelist[item], 'meas')}
 
 
 def directory_filelist(target_directory):
@@ -102,76 +67,150 @@ def psnr(rec, gt):
     return 10.0 * math.log10(1.0 / np.mean((a - b) ** 2, dtype=np.float64))
 
 
-def tensor_to_np(tensor):
-    return tensor.clip(0, 1).cpu().detach().unsqueeze(2).numpy() * 255.
+def frame_payload(frame):
+    """One reconstructed frame (H,W) -> the (H,W,1) float image in [0,255] that goes to the PNG writer."""
+    return (frame.detach().clamp(0, 1).cpu().numpy() * 255.)[:, :, None]
+
+
+tensor_to_np = frame_payload          # the reference's name for it
 
 
 def write_png(path, img):
     """cv2.imwrite(path, float image) casts with saturate_cast<uchar>(round-half-even); PIL is what is
-    installed here, so the rounding is restated (np.rint = half-to-even, then clip)."""
+    installed here, so that rounding is restated (np.rint = half-to-even, then clip) - unpinned: no cv2."""
     from PIL import Image
     a = np.clip(np.rint(np.asarray(img, dtype=np.float64)), 0, 255).astype(np.uint8)
     Image.fromarray(a[..., 0] if a.ndim == 3 else a).save(path)
 
 
+# ----------------------------------------------------------------------------- clips
+@dataclass
+class ClipResult:
+    name: str
+    rec: torch.Tensor                 # (M,H,W,B) reconstructions of the scored measurements, on the device
+    psnr: list                        # per measurement, dB
+    res: list                         # per measurement: relative fixed-point residual at exit (None if unknown)
+    frames: int = 0
+    seconds: float = 0.0
+    info: dict = field(default_factory=dict)
+
+    @property
+    def mean_psnr(self):
+        return sum(self.psnr) / len(self.psnr)
+
+
+def as_clip(sample):
+    """A dataset item, with or without the DataLoader's leading batch dimension of 1 -> plain (H,W,*) tensors."""
+    name = sample['file']
+    if isinstance(name, (list, tuple)):
+        name = name[0]
+
+    def plain(v, nd):
+        t = torch.as_tensor(v)
+        return t[0] if t.dim() == nd + 1 else t
+    return {'file': name, 'gt': plain(sample['gt'], 3), 'mask': plain(sample['mask'], 3), 'meas': plain(sample['meas'], 3)}
+
+
+def scored_measurements(name, n_meas):
+    """Indices of the snapshot measurements the benchmark scores for this clip."""
+    return [0] if any(k in name for k in FIRST_MEASUREMENT_ONLY) else list(range(n_meas))
+
+
+def _residuals(deep_eq_module, n):
+    eng = getattr(deep_eq_module, "_engine", None)
+    info = eng[1].last_info if eng else None
+    if info and len(info.get("res_per_sample", ())) == n:
+        return list(info["res_per_sample"]), info
+    r = getattr(deep_eq_module, "forward_res", None)
+    if isinstance(r, list):
+        r = r[-1] if r else None
+    return [r] * n, (info or {})
+
+
+def reconstruct_clip(deep_eq_module, clip, device="cuda", batch=True, group=None):
+    """All scored measurements of one clip through `deep_eq_module.forward(y, Phi, Phi_sum, initial_point=, train_flag=False)`.
+    batch=True: one call with y (M,H,W) and the shared mask (1,H,W,B); batch=False: M calls of batch 1 (the reference's
+    schedule).  With a process group the measurements are sharded over its ranks and all-gathered."""
+    import time
+    clip = as_clip(clip)
+    Phi = clip['mask'].to(device)[None].contiguous()                  # (1,H,W,B)
+    B = Phi.shape[-1]
+    ids = scored_measurements(clip['file'], clip['meas'].shape[-1])
+    y = clip['meas'].to(device).permute(2, 0, 1)[ids].contiguous()    # (M,H,W)
+    Phi_sum = operators.phi_sum(Phi)
+
+    def run(y_part, Phi_part):
+        with torch.no_grad():
+            x0 = operators.initial_point(y_part, Phi_part, Phi_sum, None)
+        rec = deep_eq_module.forward(y_part, Phi_part, Phi_sum, initial_point=x0, train_flag=False)
+        res, _ = _residuals(deep_eq_module, y_part.shape[0])
+        return rec.detach(), res
+
+    t0 = time.perf_counter()
+    res = []
+    if batch:
+        def run_collect(y_part, Phi_part):
+            rec, r = run(y_part, Phi_part)
+            res.extend(r)
+            return rec
+        rec = distributed.sharded_reconstruct(run_collect, y, Phi, group=group)
+        res = distributed.gather_scalars(res, group=group)
+    else:
+        parts = []
+        for i in range(len(ids)):
+            r, rr = run(y[i:i + 1], Phi)
+            parts.append(r)
+            res.extend(rr)
+        rec = torch.cat(parts)
+    if rec.is_cuda:
+        torch.cuda.synchronize(rec.device)
+    dt = time.perf_counter() - t0
+    gt = clip['gt']
+    rec_np = rec.clamp(0, 1).cpu().numpy()
+    ps = [psnr(rec_np[i], gt[..., B * m:B * (m + 1)].numpy()) for i, m in enumerate(ids)]
+    return ClipResult(name=clip['file'], rec=rec, psnr=ps, res=res, frames=B * len(ids), seconds=dt,
+                      info={"measurements": ids, "batched": bool(batch)})
+
+
+def evaluate(deep_eq_module, clips, device="cuda", batch=True, group=None, on_clip=None):
+    """-> (mean over clips of the clip's mean PSNR, [ClipResult])."""
+    results = []
+    for sample in clips:
+        r = reconstruct_clip(deep_eq_module, sample, device=device, batch=batch, group=group)
+        results.append(r)
+        if on_clip is not None:
+            on_clip(r)
+    return sum(r.mean_psnr for r in results) / len(results), results
+
+
+def png_payloads(result, prefix=""):
+    """{path: (H,W,1) float image} for every frame of a clip, named like the reference's export (:185-187):
+    '<prefix><file>_reconstruction_<frame index within the scored frames>.png'."""
+    out = {}
+    B = result.rec.shape[-1]
+    for i in range(result.rec.shape[0]):
+        for b in range(B):
+            out[prefix + '%s_reconstruction_%d.png' % (result.name, i * B + b)] = frame_payload(result.rec[i, :, :, b])
+    return out
+
+
 def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, verbose=True, save_image=True,
-                    device="cuda", records=None, batch_measurements=False):
-    """Per clip: Phi_sum; drop*/runner* keep measurement 0; per measurement x0 = At(y,Phi), DEQ forward,
-    PSNR; clip mean; grand mean.  Returns (avg_psnr, {png_path: HxWx1 float image}).
-    batch_measurements=True (not in the reference) hands all measurements of a clip to the solver as ONE
-    batch sharing the clip's mask; identical results unless the whole-batch tolerance test fires."""
-    all_images = {}
-    psnr_sum_for_avg, num_for_avg = 0, 0
-    for sample_batch in test_dataloader:
-        gt_batch = sample_batch['gt'].to(device)
-        y_batch = sample_batch['meas'].to(device)
-        Phi = sample_batch['mask'].to(device)
-        Phi_sum = operators.phi_sum(Phi)
-        file_name = sample_batch['file']
-        if ('drop' in file_name[0]) or ('runner' in file_name[0]):
-            y_batch = y_batch[:, :, :, 0].unsqueeze(3)
-        psnr_sum = 0
-        bsz, h, w, f = y_batch.shape
-        batched = None
-        if batch_measurements and f > 1:
-            yb = y_batch[0].permute(2, 0, 1).contiguous()
-            with torch.no_grad():
-                x0 = operators.initial_point(yb, Phi, Phi_sum, gt_batch)
-            batched = deep_eq_module.forward(yb, Phi, Phi_sum, initial_point=x0, train_flag=False)
-        for fi in range(f):
-            gt = gt_batch[:, :, :, fi * 8:(fi + 1) * 8]
-            y = y_batch[:, :, :, fi].contiguous()
-            if batched is not None:
-                reconstruction = batched[fi:fi + 1]
-            else:
-                with torch.no_grad():
-                    initial_point = operators.initial_point(y, Phi, Phi_sum, gt_batch)
-                reconstruction = deep_eq_module.forward(y, Phi, Phi_sum, initial_point=initial_point, train_flag=False)
-            rec_np = reconstruction.clip(0, 1).cpu().detach().numpy()
-            PSNR = psnr(rec_np, gt.cpu().numpy())
-            if records is not None:
-                records.append({"id": f"{file_name[0]}:{fi}", "psnr": PSNR, "res": deep_eq_module.forward_res,
-                                "rec": reconstruction.detach().cpu()})
-            for frame_id in range(8):
-                all_images[(save_img_path or "") + '%s_reconstruction_%d.png' % (file_name[0], fi * 8 + frame_id)] = \
-                    tensor_to_np(reconstruction[0, :, :, frame_id])
-            psnr_sum += PSNR
-        current_psnr = psnr_sum / f
-        psnr_sum_for_avg += current_psnr
-        num_for_avg += 1
+                    device="cuda", records=None, batch_measurements=True):
+    """Adapter with the reference's signature (training/sci_equilibrium_training.py:152): returns
+    (average PSNR, {png path: float image}); prints one line per clip and the total; writes the PNGs."""
+    images = {}
+
+    def on_clip(r):
+        images.update(png_payloads(r, save_img_path or ""))
+        if records is not None:
+            for i, m in enumerate(r.info["measurements"]):
+                records.append({"id": f"{r.name}:{m}", "psnr": r.psnr[i], "res": r.res[i], "rec": r.rec[i:i + 1].cpu()})
         if verbose:
-            print(file_name, '  PSNR: %.2f dB' % current_psnr)
-    avg_psnr = psnr_sum_for_avg / num_for_avg
+            print([r.name], '  PSNR: %.2f dB' % r.mean_psnr)
+    avg, _ = evaluate(deep_eq_module, test_dataloader, device=device, batch=batch_measurements, on_clip=on_clip)
     if verbose:
-        print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg_psnr)
+        print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg)
     if save_image:
-        for k in all_images:
-            write_png(k, all_images[k])
-    return avg_psnr, all_images
-
-
-def train_solver_sci(*args, **kwargs):
-    """training/sci_equilibrium_training.py:28-150 - see deqsci_amd/training.py (this module is what the reference's
-    `from training import sci_equilibrium_training` becomes, so the name lives here too)."""
-    from .training import train_solver_sci as _train
-    return _train(*args, **kwargs)
+        for path, img in images.items():
+            write_png(path, img)
+    return avg, images

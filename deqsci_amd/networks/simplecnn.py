@@ -37,7 +37,8 @@ class DnCNN(nn.Module):
         sigmas = [pow(lip, 1.0 / num_of_layers) if lip > 0.0 else 0.0 for _ in range(num_of_layers)]
         if adaptive:
             sigmas = [5.0, 2.0, 1.0, 0.681, 0.464, 0.316]
-            assert len(sigmas) == num_of_layers, "Length of SN list uncompatible with num of layers."
+            if len(sigmas) != num_of_layers:
+                raise AssertionError(f"adaptive spectral-norm schedule has {len(sigmas)} entries, the network {num_of_layers} layers")
 
         def conv_layer(cin, cout, sigma):
             if sigma > 0.0:

@@ -155,6 +155,35 @@ class ProxGradSCI:
         return z1 - noise.view(bsz, B, H, Wd).permute(0, 2, 3, 1)
 
 
+class PluginProxGradSCI:
+    """The same single-iterate map for an arbitrary denoiser plugin, dispatched on `net.tag` exactly as
+    solvers/equilibrium_solvers_yaping.py:402-425: 'conv2d' / 'conv3d' return the network output itself, 'denoiser' /
+    '3d_denoiser' subtract it as predicted noise; the 2-D tags see (bsz*B,1,H,W) images, the 3-D tags the
+    (bsz,1,B,H,W) video ('ffdnet' is ProxGradSCI above)."""
+
+    def __init__(self, net, tag=None):
+        self.net = net
+        self.tag = tag if tag is not None else net.tag
+        assert self.tag in ("conv2d", "conv3d", "denoiser", "3d_denoiser")
+        self.calls = 0
+
+    @torch.no_grad()
+    def __call__(self, z, y, Phi, Phi_sum):
+        bsz, H, Wd, B = z.shape
+        z1 = gap_update(z, y, Phi, Phi_sum)
+        planar = z1.permute(0, 3, 1, 2)
+        self.calls += 1
+        if self.tag == "conv2d":                                           # :402-404
+            return self.net(planar.contiguous().view(bsz * B, 1, H, Wd)).view(bsz, B, H, Wd).permute(0, 2, 3, 1)
+        if self.tag == "conv3d":                                           # :405-407
+            return self.net(planar.unsqueeze(1).contiguous()).squeeze(1).permute(0, 2, 3, 1)
+        if self.tag == "denoiser":                                         # :418-420
+            noise = self.net(planar.contiguous().view(bsz * B, 1, H, Wd))
+            return z1 - noise.view(bsz, B, H, Wd).permute(0, 2, 3, 1)
+        noise = self.net(planar.unsqueeze(1).contiguous())                 # '3d_denoiser' :421-423
+        return z1 - noise.squeeze(1).permute(0, 2, 3, 1)
+
+
 # ----------------------------------------------------------------------------- fixed-point drivers
 def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, gram_dtype=None):
     """Anderson acceleration exactly as solvers/new_equilibrium_utils_yaping.py:153-189:

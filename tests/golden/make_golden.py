@@ -18,7 +18,8 @@ Groups:
   g5  e2e_*.npz/.json    the reference's real test_solver_sci over data/test_gray
   g6  sigma.npz          FFDNet sigma sequence (repeated fp32 multiply)
   g7  admm_toy.npz       ADMM variant on a toy denoiser
-  g9  training_toy.npz   the reference's train_solver_sci for 2 epochs x 3 steps on seeded toy batches
+  g10 e2e_ffdnet_anderson_180_spread.json  config 2 under x0 perturbations / fp64 Gram: the reference's own spread
+  g11 plugin_tags.npz    toy plugins for the tags conv2d / conv3d / 3d_denoiser through the reference solver + DEQ
   g8  backward.npz       training-mode DEQFixedPoint: implicit-differentiation gradients (SimpleCNN, cnn.ckpt)
 """
 import hashlib
@@ -62,6 +63,8 @@ def build_denoiser(name):
         net.load_state_dict(sd)
     elif name == "SimpleCNN":
         net = DnCNN(1, num_of_layers=4, lip=0.0, no_bn=True, tag="denoiser")
+    elif name == "RealSN_SimpleCNN":                                  # video_sci_proxgrad.py:181-183
+        net = DnCNN(1, num_of_layers=4, lip=1.0, no_bn=True, tag="denoiser")
     else:
         raise NotImplementedError(name)
     net.eval()
@@ -72,8 +75,8 @@ def build_solver(name):
     net = build_denoiser(name)
     solver = EquilibriumProxGradSCI(A=A_torch_, At=At_torch_, nonlinear_operator=net,
                                     eta=0.2, minval=-1, maxval=1)
-    if name == "SimpleCNN":
-        sd = torch.load(REF + "/models/cnn.ckpt", map_location="cpu",
+    if name in ("SimpleCNN", "RealSN_SimpleCNN"):
+        sd = torch.load(REF + ("/models/cnn.ckpt" if name == "SimpleCNN" else "/models/rsn_cnn.ckpt"), map_location="cpu",
                         weights_only=False)["solver_state_dict"]
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         solver.load_state_dict(sd)
@@ -254,7 +257,12 @@ KEEP_REC = {  # (denoiser, iterator, iters) -> measurement ids whose full rec is
     ("ffdnet", "anderson", 30): ("traffic_cacti.mat:0",),
     ("ffdnet", "anderson", 10): ("traffic_cacti.mat:0", "drop8_cacti.mat:0"),
     ("SimpleCNN", "anderson", 10): ("traffic_cacti.mat:3",),
+    ("RealSN_SimpleCNN", "anderson", 10): ("traffic_cacti.mat:0", "drop8_cacti.mat:0"),
+    ("RealSN_SimpleCNN", "anderson", 100): ("traffic_cacti.mat:0",),
 }
+# runs whose PNG payloads (the float images the reference hands to cv2.imwrite, sci_equilibrium_training.py:19-21,185-187)
+# are kept for the first and the last exported frame of every clip
+KEEP_PNG = {("SimpleCNN", "anderson", 10), ("RealSN_SimpleCNN", "anderson", 10)}
 
 
 def g5(name, iterator, iters, only_first=False):
@@ -316,12 +324,23 @@ def g5(name, iterator, iters, only_first=False):
     meta = {"denoiser": name, "iterator": iterator, "and_maxiters": iters, "avg_psnr": float(avg),
             "n_png_payloads": len(images), "wall_s": wall, "threads": torch.get_num_threads(),
             "torch": torch.__version__, "measurements": log,
-            "weights": "net_gray.pth (substitute for missing ffdnet.ckpt)" if name == "ffdnet" else "cnn.ckpt"}
+            "weights": {"ffdnet": "net_gray.pth (substitute for missing ffdnet.ckpt)", "SimpleCNN": "cnn.ckpt",
+                        "RealSN_SimpleCNN": "rsn_cnn.ckpt"}[name]}
     tag = f"{name}_{iterator}_{iters}" + ("_first" if only_first else "")
     with open(HERE + f"/e2e_{tag}.json", "w") as fh:
         json.dump(meta, fh, indent=1)
     if recs:
         np.savez_compressed(HERE + f"/e2e_{tag}_rec.npz", **recs)
+    if (name, iterator, iters) in KEEP_PNG and not only_first:
+        keys = list(images)
+        last = {}
+        for k in keys:                                               # last exported frame of every clip
+            last[k.split("_reconstruction_")[0]] = k
+        keep = sorted({k for k in keys if k.endswith("_reconstruction_0.png")} | set(last.values()))
+        meta["png_payload_keys"] = keep
+        with open(HERE + f"/e2e_{tag}.json", "w") as fh:
+            json.dump(meta, fh, indent=1)
+        np.savez_compressed(HERE + f"/e2e_{tag}_png.npz", **{k: np.asarray(images[k], dtype=np.float32) for k in keep})
     print("g5 ->", tag, "avg", avg, "wall", wall)
 
 
@@ -408,67 +427,154 @@ def g8(kind="SimpleCNN"):
           {k: float(v.norm()) for k, v in out.items() if k.startswith("grad.")})
 
 
-def _toy_training_data(seed=77, steps=3, bsz=2, H=24, W=20, B=8):
-    g = torch.Generator().manual_seed(seed)
-    train = []
-    for _ in range(steps):
-        Phi = (torch.rand(bsz, H, W, B, generator=g) < 0.5).float()
-        gt = torch.rand(bsz, H, W, B, generator=g)
-        train.append({"gt": gt, "meas": A_torch_(gt, Phi), "mask": Phi})
-    Phi = (torch.rand(1, H, W, B, generator=g) < 0.5).float()
-    gt = torch.rand(1, H, W, B, generator=g)
-    test = [{"gt": gt, "meas": A_torch_(gt, Phi).unsqueeze(3), "mask": Phi, "file": ["toy"]}]
-    return train, test
+# --------------------------------------------------------------------------- g11 (plugin tags)
+class ToyPlugin(torch.nn.Module):
+    """Seeded toy denoiser plugins for the tags without shipped weights (equilibrium_solvers_yaping.py:402-407,421-423):
+    one 3x3(x3) convolution + tanh, 2-D for 'conv2d', 3-D for 'conv3d' / '3d_denoiser'.  The weights go into the golden."""
+
+    def __init__(self, tag, weight):
+        super().__init__()
+        self.tag = tag
+        self.weight = torch.nn.Parameter(weight)          # requires_grad: the reference registers a hook on the output (:280)
+
+    def forward(self, x):
+        conv = torch.nn.functional.conv3d if self.weight.dim() == 5 else torch.nn.functional.conv2d
+        return 0.5 * torch.tanh(conv(x, self.weight, padding=1))
 
 
-def g9():
-    """The reference's own training loop (training/sci_equilibrium_training.py:28-150) for 2 epochs of 3 Adam steps on seeded
-    toy batches (SimpleCNN from cnn.ckpt, lr 1e-4, StepLR(1, 0.9), MSE mean, Anderson m=5 max_iter=8): loss of every step,
-    the PSNR the loop prints, the weights after training, what the epoch checkpoint holds."""
-    import tempfile
+def g11():
+    out = {}
+    g = torch.Generator().manual_seed(4242)
+    bsz, H, W, B = 2, 12, 10, 4
+    Phi = (torch.rand(bsz, H, W, B, generator=g) < 0.5).float()
+    Phi[:, 0, :2, :] = 0
+    x = torch.rand(bsz, H, W, B, generator=g)
+    y = A_torch_(x, Phi)
+    Phi_sum = torch.sum(Phi, axis=3)
+    Phi_sum[Phi_sum == 0] = 1
+    out.update(Phi=Phi, y=y, Phi_sum=Phi_sum)
+    for tag in ("conv2d", "conv3d", "3d_denoiser"):
+        w = 0.3 * torch.randn((1, 1, 3, 3) if tag == "conv2d" else (1, 1, 3, 3, 3), generator=g)
+        solver = EquilibriumProxGradSCI(A=A_torch_, At=At_torch_, nonlinear_operator=ToyPlugin(tag, w), eta=0.2)
+        x0 = initial_point(y, Phi, Phi_sum, None)
+        out[tag + "_w"] = w
+        out[tag + "_f_x0"] = solver(x0, y, Phi, Phi_sum)
+        deq = eq_utils.DEQFixedPoint(solver, eq_utils.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=9, tol=1e-9)
+        rec = deq.forward(y, Phi, Phi_sum, initial_point=x0, train_flag=False)
+        out[tag + "_rec"] = rec.detach()
+        out[tag + "_res"] = torch.tensor(deq.forward_res, dtype=torch.float64)
+        print("g11", tag, "res", deq.forward_res)
+    np.savez_compressed(HERE + "/plugin_tags.npz", **{k: v.detach().numpy() for k, v in out.items()})
 
-    class _Writer:                                  # torch.utils.tensorboard is not installed here
-        def __init__(self, *a, **k):
-            pass
 
-        def add_scalar(self, *a, **k):
-            pass
+# --------------------------------------------------------------------------- g10 (config-2 spread)
+def g10(seeds="1-8", threads=6, only=None, iters=180):
+    """BASELINE config 2 (FFDNet, Anderson, and_maxiters=180, every shipped measurement) is chaotic on the
+    `traffic` clip: this measures the REFERENCE's own spread.  Every measurement is run through the
+    reference's DEQFixedPoint.forward (new_equilibrium_utils_yaping.py:249-281) as ONE batch of variants of the
+    same problem: [unperturbed, x0*(1+1e-7*randn(seed s)) for s in seeds, unperturbed with the Gram matrix of
+    :178 accumulated in fp64].  alpha is per sample in the reference (:180-182) and the batch residual never
+    reaches tol, so each batch row is an independent bsz=1 run; row 0 is checked against the sha16 of the
+    bsz=1 harness golden (e2e_ffdnet_anderson_180.json).  Output: e2e_ffdnet_anderson_180_spread.json."""
+    torch.set_num_threads(int(threads))
+    lo, hi = (int(v) for v in str(seeds).split("-"))
+    seed_list = list(range(lo, hi + 1))
+    iters = int(iters)
+    fn = HERE + f"/e2e_ffdnet_anderson_{iters}_spread.json"
+    book = json.load(open(fn)) if os.path.exists(fn) else {"measurements": {}}
+    base_gold = {m["id"]: m for m in json.load(open(HERE + f"/e2e_ffdnet_anderson_{iters}.json"))["measurements"]}
+    solver, deq = build_deq("ffdnet", iters)
+    state = {"n": 0, "x": None, "fx": None, "res": None, "f64row": None}
+    orig_forward = solver.forward
 
-        def flush(self):
-            pass
-    sci_train.tensorboard.SummaryWriter = _Writer
-    train, test = _toy_training_data()
-    solver = build_solver("SimpleCNN")
-    w0 = {k: v.detach().clone() for k, v in solver.state_dict().items()}
-    deq = eq_utils.DEQFixedPoint(solver, eq_utils.andersonexp, m=5, beta=1.0, lam=1e-2, max_iter=8, tol=1e-5)
-    opt = torch.optim.Adam(params=solver.parameters(), lr=1e-4)
-    sched = torch.optim.lr_scheduler.StepLR(optimizer=opt, step_size=1, gamma=0.9)
-    losses = []
-    mse = torch.nn.MSELoss(reduction="mean")
+    def traced(z, yy, P, Ps, _o=orig_forward):
+        state["n"] += 1
+        r = _o(z, yy, P, Ps)
+        if state["n"] == iters:                               # last call inside andersonexp (k = max_iter-1)
+            d = (r - z).reshape(z.shape[0], -1).norm(dim=1)
+            state["res"] = (d / (1e-5 + r.reshape(z.shape[0], -1).norm(dim=1))).tolist()
+        return r
+    solver.forward = traced
+    real_bmm = torch.bmm
 
-    def loss_fn(rec, gt):
-        l = mse(rec, gt)
-        losses.append(float(l.detach()))
-        return l
-    tmp = tempfile.mkdtemp() + "/"
-    ref_shims.PSNR_LOG.clear()
-    sci_train.train_solver_sci(single_iterate_solver=solver, train_dataloader=train, test_dataloader=test, optimizer=opt,
-                               save_model_path=tmp, deep_eq_module=deq, loss_function=loss_fn, n_epochs=2, scheduler=sched,
-                               print_every_n_steps=1, save_every_n_steps=1000, start_epoch=0, train_img_path=tmp,
-                               test_img_path=tmp, best_img_path=tmp, tflog_path=tmp)
-    ck = torch.load(tmp + "epoch_1.ckpt", map_location="cpu", weights_only=False)
-    out = {"losses": np.array(losses, dtype=np.float64), "psnr_log": np.array(ref_shims.PSNR_LOG, dtype=np.float64),
-           "ckpt_epoch": np.array(ck["epoch"]), "lr_after": np.array(opt.param_groups[0]["lr"], dtype=np.float64)}
-    assert sorted(ck.keys()) == ["epoch", "optimizer_state_dict", "scheduler_state_dict", "solver_state_dict"]
-    for i, b in enumerate(train):
-        out[f"train{i}.gt"], out[f"train{i}.mask"] = b["gt"].numpy(), b["mask"].numpy()
-    out["test.gt"], out["test.mask"] = test[0]["gt"].numpy(), test[0]["mask"].numpy()
-    for k, v in solver.state_dict().items():
-        out["w." + k] = v.detach().numpy()
-        out["dw." + k] = (v.detach() - w0[k]).numpy()
-        assert torch.equal(ck["solver_state_dict"][k], v)
-    np.savez_compressed(HERE + "/training_toy.npz", **out)
-    print("g9 ->", HERE + "/training_toy.npz", losses, ref_shims.PSNR_LOG)
+    def bmm_f64_last_row(a, b):
+        out = real_bmm(a, b)
+        i = state["f64row"]
+        if i is not None and a.shape[0] > i and a.shape[1] <= 5 and a.dtype == torch.float32:
+            out[i] = real_bmm(a[i:i + 1].double(), b[i:i + 1].double())[0].float()
+        return out
+    torch.bmm = bmm_f64_last_row
+    try:
+        for fname in sorted(os.listdir(DATA)):
+            d = load_test_data(DATA + fname)
+            nmeas = 1 if ("drop" in fname or "runner" in fname) else d["meas"].shape[2]
+            Phi1 = torch.from_numpy(d["mask"])[None]
+            for fi in range(nmeas):
+                mid = f"{fname}:{fi}"
+                if only and mid not in only.split(","):
+                    continue
+                entry = book["measurements"].setdefault(mid, {"variants": {}})
+                todo = [s for s in seed_list if f"seed{s}" not in entry["variants"]]
+                names = ["base"] + [f"seed{s}" for s in todo] + ["gram_fp64"]
+                V = len(names)
+                y1 = torch.from_numpy(d["meas"][..., fi])[None]
+                gt1 = torch.from_numpy(d["gt"][..., 8 * fi:8 * fi + 8])[None]
+                Ps1 = torch.sum(Phi1, axis=3)
+                Ps1[Ps1 == 0] = 1
+                x0 = initial_point(y1, Phi1, Ps1, gt1)
+                xs = [x0]
+                for s in todo:
+                    g = torch.Generator().manual_seed(s)
+                    xs.append(x0 * (1 + 1e-7 * torch.randn(x0.shape, generator=g)))
+                xs.append(x0)
+                X0 = torch.cat(xs).contiguous()
+                state.update(n=0, f64row=V - 1)
+                t0 = time.time()
+                rec = deq.forward(y1.expand(V, -1, -1).contiguous(), Phi1.expand(V, -1, -1, -1).contiguous(),
+                                  Ps1.expand(V, -1, -1).contiguous(), initial_point=X0, train_flag=False)
+                rec = rec.detach()
+                base = rec[0]
+                sha = sha16(base[None].numpy().clip(0, 1))
+                entry["base_sha16_clip"] = sha
+                entry["base_matches_bsz1_golden"] = bool(sha == base_gold[mid]["sha16_clip"])
+                entry["f_calls"] = state["n"]
+                for i, nm in enumerate(names):
+                    r = rec[i:i + 1]
+                    entry["variants"][nm] = {
+                        "psnr": float(ref_shims._psnr(r.clip(0, 1).numpy(), gt1.numpy())),
+                        "res": float(state["res"][i]),
+                        "rel_l2_vs_base": float((r[0] - base).norm() / base.norm())}
+                ps = [v["psnr"] for v in entry["variants"].values()]
+                entry["psnr_min"], entry["psnr_max"] = min(ps), max(ps)
+                entry["res_min"] = min(v["res"] for v in entry["variants"].values())
+                entry["res_max"] = max(v["res"] for v in entry["variants"].values())
+                entry["rel_l2_max"] = max(v["rel_l2_vs_base"] for v in entry["variants"].values())
+                entry["seconds"] = entry.get("seconds", 0.0) + time.time() - t0
+                book.update(denoiser="ffdnet", iterator="anderson", and_maxiters=iters, torch=torch.__version__,
+                            perturbation="x0*(1+1e-7*randn), torch.Generator().manual_seed(seed); gram_fp64 = "
+                                         "torch.bmm of :178 in float64 for that row",
+                            weights="net_gray.pth (substitute for missing ffdnet.ckpt)")
+                with open(fn, "w") as fh:
+                    json.dump(book, fh, indent=1)
+                print("g10", mid, "V", V, "psnr [%.4f, %.4f]" % (entry["psnr_min"], entry["psnr_max"]),
+                      "base ok", entry["base_matches_bsz1_golden"], "%.0f s" % (time.time() - t0), flush=True)
+    finally:
+        torch.bmm = real_bmm
+    # harness-level averages (test_solver_sci :193-200: mean over clips of the clip's mean over measurements)
+    ms = book["measurements"]
+    if len(ms) == 8:
+        vnames = sorted(set.intersection(*[set(m["variants"]) for m in ms.values()]))
+        avgs = {}
+        for vn in vnames:
+            clips = {}
+            for mid, m in ms.items():
+                clips.setdefault(mid.split(":")[0], []).append(m["variants"][vn]["psnr"])
+            avgs[vn] = float(np.mean([np.mean(v) for v in clips.values()]))
+        book["avg_psnr_by_variant"] = avgs
+        book["avg_psnr_min"], book["avg_psnr_max"] = min(avgs.values()), max(avgs.values())
+        with open(fn, "w") as fh:
+            json.dump(book, fh, indent=1)
+        print("g10 avg psnr band", book["avg_psnr_min"], book["avg_psnr_max"])
 
 
 if __name__ == "__main__":
@@ -476,6 +582,12 @@ if __name__ == "__main__":
     for arg in sys.argv[1:]:
         if arg.startswith("g8:"):
             g8(arg.split(":")[1])
+        elif arg.startswith("g10"):
+            # g10=seeds=1-8,threads=6,iters=180,only=drop8_cacti.mat:0+traffic_cacti.mat:0
+            kw = dict(p.split("=", 1) for p in arg[4:].split(",") if p)
+            if "only" in kw:
+                kw["only"] = kw["only"].replace("+", ",")
+            g10(**kw)
         elif arg.startswith("g5"):
             parts = arg.split(":")
             g5(parts[1], parts[2], int(parts[3]), only_first=(len(parts) > 4 and parts[4] == "first"))

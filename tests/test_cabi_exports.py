@@ -44,6 +44,13 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_sci_forward_f32(p16 + 4, p16, p16, 1, 2, 2, 8, 0, 0, None) == -3
     assert lib.deqsci_gap_update_f32(p16, p16, p16, p16, p16, 1, 2, 2, 8, 0, 1, 0, None) == -4     # aliasing across layouts
     assert lib.deqsci_anderson_mix_f32(p16, p16, p16, p16, 1.0, 9, 1, 8, 9, None) == -4           # m > DEQSCI_MAX_M
+    # Winograd conv: the kernel forms a 32-bit byte offset (pixel * 256 B), so images of 2^24 pixels or more are refused
+    q16 = p16 + 64
+    assert lib.deqsci_conv3x3_c64_winograd_f32(p16, p16, None, q16, 1, 4096, 4096, 1, None) == -4
+    assert lib.deqsci_conv3x3_c64_winograd_f32(p16, p16, None, q16, 1, 8192, 2048, 1, None) == -4
+    assert lib.deqsci_conv3x3_c64_winograd_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4      # in place
+    assert lib.deqsci_conv3x3_c64_winograd_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
+    assert lib.deqsci_conv3x3_c64_winograd_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
 
 
 def test_gfx950_code_object_present():

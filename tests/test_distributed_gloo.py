@@ -61,3 +61,72 @@ def test_sharded_reconstruct_ragged_batch_shared_mask():
 
 def test_single_measurement_two_ranks():
     _run(1, shared=False)
+
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own step() plumbing (make_step -> sharded_reconstruct -> gather_shards) with a stub engine."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    from deqsci_amd import distributed
+    r, w, _, dev = distributed.init_from_env("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    y, Phi, _ = bench.make_batch(world * 3, 8, 6, 4, 1234, dev)
+    calls = []
+
+    class Stub:
+        def reconstruct(self, yl, Pl):
+            calls.append(tuple(yl.shape))
+            return (yl.unsqueeze(-1) * Pl + rank).contiguous()
+    timer = distributed.GatherTimer()
+    step = bench.make_step(Stub(), y, Phi, timer)
+    full = step()
+    want = torch.cat([y[i * 3:(i + 1) * 3].unsqueeze(-1) * Phi[i * 3:(i + 1) * 3] + i for i in range(world)])
+    ok = torch.equal(full, want) and calls == [(3, 8, 6)] and timer.calls == 1 and timer.total_seconds() > 0
+    q.put((rank, bool(ok), tuple(full.shape)))
+    dist.destroy_process_group()
+
+
+def test_bench_step_plumbing_two_ranks():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(ok for _, ok, _ in res), res
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun must start two ranks itself: exercised end to end with the
+    CPU plumbing self-test (gloo, stub engine - the GPU box runs the same launcher with nccl and the real engine)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest", "--batch-per-gpu", "3",
+                          "--size", "16x12x8", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                               # ONE JSON line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 6 and rec["steps"] == 2 and rec["data"] == "selftest"
+    assert rec["allgather_ms_per_step"] > 0
+
+
+def test_launch_ranks_propagates_failure():
+    import sys
+    from deqsci_amd.distributed import launch_ranks
+    code = "import os,sys,time; r=int(os.environ['RANK']); assert os.environ['WORLD_SIZE']=='2'; time.sleep(0.2 if r==0 else 30); sys.exit(3 if r==0 else 0)"
+    assert launch_ranks([sys.executable, "-c", code], 2, timeout=60) == 3
+    assert launch_ranks([sys.executable, "-c", "import os; assert os.environ['LOCAL_RANK'] in ('5','7')"], 2, device_ids=[5, 7], timeout=60) == 0

@@ -200,3 +200,68 @@ def test_oracle_training_backward_matches_reference(kind):
             assert rel_l2(W[k[len("grad.nonlinear_op."):]].grad.numpy(), g[k]) < 1e-5, k
             n += 1
     assert n == (4 if kind == "SimpleCNN" else 41)
+
+
+class ToyPlugin(torch.nn.Module):
+    """The toy plugins of tests/golden/make_golden.py g11, restated: 0.5 tanh(conv3x3[x3](x, w))."""
+
+    def __init__(self, tag, weight):
+        super().__init__()
+        self.tag = tag
+        self.weight = torch.nn.Parameter(weight, requires_grad=False)
+
+    def forward(self, x):
+        conv = torch.nn.functional.conv3d if self.weight.dim() == 5 else torch.nn.functional.conv2d
+        return 0.5 * torch.tanh(conv(x, self.weight, padding=1))
+
+
+@pytest.mark.parametrize("tag", ["conv2d", "conv3d", "3d_denoiser"])
+def test_plugin_tags_golden(tag):
+    """Tag dispatch of equilibrium_solvers_yaping.py:402-407,421-423 (no shipped weights use these tags): the oracle's
+    PluginProxGradSCI against the reference's EquilibriumProxGradSCI + DEQFixedPoint/andersonexp on seeded toy plugins."""
+    g = np.load(os.path.join(GOLDEN, "plugin_tags.npz"))
+    Phi, y, Ps = T(g["Phi"]), T(g["y"]), T(g["Phi_sum"])
+    f = orc.PluginProxGradSCI(ToyPlugin(tag, T(g[tag + "_w"])))
+    x0 = orc.initial_point(y, Phi)
+    assert rel_l2(f(x0, y, Phi, Ps), g[tag + "_f_x0"]) < 1e-6
+    rec, res = orc.deq_forward(f, orc.andersonexp, y, Phi, Ps, x0, m=5, beta=1.0, lam=1e-2, max_iter=9, tol=1e-9)
+    assert f.calls == 1 + 11
+    assert rel_l2(rec, g[tag + "_rec"]) < 1e-5
+    assert abs(res - float(g[tag + "_res"])) < 1e-4 * float(g[tag + "_res"])
+
+
+def test_realsn_simplecnn_golden():
+    """RealSN_SimpleCNN (video_sci_proxgrad.py:181-183, models/rsn_cnn.ckpt): in eval mode the spectral-norm convolutions
+    use their stored normalised `weight` buffers (conv_sn_chen.py:65-67), i.e. SimpleCNN with other weights."""
+    meta = _e2e("RealSN_SimpleCNN_anderson_10")
+    assert meta["weights"] == "rsn_cnn.ckpt" and len(meta["measurements"]) == 8
+    want = [m for m in meta["measurements"] if m["id"] == "traffic_cacti.mat:0"][0]
+    f = orc.ProxGradSCI("SimpleCNN", weights=orc.load_weights("rsn_cnn"))
+    r = orc.run_harness("SimpleCNN", 10, clips=["traffic_cacti.mat"], max_meas=1, fmap=f)["measurements"][0]
+    assert r["f_calls"] == want["f_calls"] == 12
+    assert abs(r["psnr"] - want["psnr"]) < 1e-3 and abs(r["res"] - want["res"]) < 1e-3 * want["res"]
+    rec = np.load(os.path.join(GOLDEN, "e2e_RealSN_SimpleCNN_anderson_10_rec.npz"))["traffic_m0"]
+    assert rel_l2(r["rec"].numpy(), rec) < 1e-5
+    # the PNG payload the reference exports for this frame is clip(rec, 0, 1) * 255 (sci_equilibrium_training.py:19-21)
+    png = np.load(os.path.join(GOLDEN, "e2e_RealSN_SimpleCNN_anderson_10_png.npz"))
+    assert sorted(png.files) == sorted(meta["png_payload_keys"]) and len(png.files) == 6
+    pay = png["traffic_cacti.mat_reconstruction_0.png"]
+    assert pay.shape == (256, 256, 1) and pay.min() >= 0 and pay.max() <= 255
+    assert np.abs(pay[..., 0] - np.clip(rec[0, :, :, 0], 0, 1) * 255).max() < 1e-4
+
+
+def test_config2_spread_file():
+    """The reference's own response to 1e-7 perturbations of x0 / an fp64 Gram at FFDNet + Anderson @180 (make_golden g10):
+    every batch row 0 reproduced the bsz=1 harness run bit for bit, so the batch rows ARE independent reference runs."""
+    fn = os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")
+    if not os.path.exists(fn):
+        pytest.skip("spread ensemble not generated yet")
+    with open(fn) as fh:
+        sp = json.load(fh)
+    base = {m["id"]: m for m in _e2e("ffdnet_anderson_180")["measurements"]}
+    assert sp["and_maxiters"] == 180 and sp["denoiser"] == "ffdnet"
+    for mid, m in sp["measurements"].items():
+        assert m["base_matches_bsz1_golden"] and m["f_calls"] == 182
+        assert abs(m["variants"]["base"]["psnr"] - base[mid]["psnr"]) < 1e-9
+        assert len([k for k in m["variants"] if k.startswith("seed")]) >= 8 and "gram_fp64" in m["variants"]
+        assert m["psnr_min"] <= base[mid]["psnr"] <= m["psnr_max"]
