@@ -756,7 +756,7 @@ def test_config2_ffdnet_anderson_180_all_measurements():
     from deqsci_amd.harness import SCITestDataset, test_solver_sci
     with open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")) as fh:
         sp = json.load(fh)
-    assert len(sp["measurements"]) == 8
+    assert len(sp["measurements"]) == 8 and "avg_psnr_min" in sp
     _, deq = _pipeline("ffdnet", 180)
     records = []
     avg, _ = test_solver_sci(deq, test_dataloader=SCITestDataset(orc.DATA_DIR), save_img_path="", verbose=False, save_image=False,

@@ -3,6 +3,8 @@ re-purposed as the stamp buffer, 40 uint64 per block; slot 38/39 = XCC_ID / HW_I
 import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from deqsci_amd import _hip
+if os.environ.get("WG_LIB"):                                  # a variant library built by tools/wg_variants.sh
+    _hip._LIB_PATH = os.environ["WG_LIB"]
 N, H, W = 64, 128, 128
 x = torch.randn(N, 64, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
 U = _hip.pack_winograd_weights(torch.randn(64, 64, 3, 3, device="cuda") * 0.05)
