@@ -118,60 +118,106 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------------
 // K5 + K6
 // ------------------------------------------------------------------------------------------------
+// Latency matters here, not throughput: the kernel sits alone between two f-calls (19 us of a 690 us iteration at batch 1 in
+// its first, lane-0-does-everything form).  So: ONE sweep over the partial rows with every load in flight at once, the
+// elimination with one matrix COLUMN per lane in registers (pivot / factors broadcast by v_readlane), and only the
+// 20-odd operations of the back substitution left to a single lane.  Every floating-point operation is the one the serial
+// form did, in the same order per element, so the results are bit-identical to it.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
                                                               int nchunks, int slot, int n_filled, int n, float lam, float eps) {
     // one wavefront per sample; the last block to arrive folds the per-sample norms into the
     // whole-batch residual (agent-scope release -> ticket -> acquire; the ticket resets itself).
-    __shared__ double M[MAXM + 1][MAXM + 2];
+    constexpr int NN = MAXM + 1;                                // rows of the largest bordered system
+    __shared__ double Gl[GRAM_STRIDE];                          // this sample's Gram matrix (+ |F|^2, |G|^2)
+    __shared__ double M[NN][NN + 1];
     const int s = blockIdx.x, lane = threadIdx.x;
     double* gs = gram + (int64_t)s * GRAM_STRIDE;
     unsigned* ticket = reinterpret_cast<unsigned*>(gram + (int64_t)bsz * GRAM_STRIDE);
     const float* ps = partials + (int64_t)s * nchunks * PART_STRIDE;
-    for (int j = 0; j <= n_filled; ++j) {
-        const int col = j < n_filled ? j : MAXM;
-        double a = 0.0;
-        for (int c = lane; c < nchunks; c += WAVE) a += (double)ps[(int64_t)c * PART_STRIDE + col];
-        a = wave_sum(a);
+    // ---- fp64 finish of the block partials: column j < n_filled = <G_slot, G_j>, column MAXM = |F_slot|^2
+    double a[PART_STRIDE];
+#pragma unroll
+    for (int j = 0; j < PART_STRIDE; ++j) a[j] = 0.0;
+    for (int c = lane; c < nchunks; c += WAVE) {
+        const float* row = ps + (int64_t)c * PART_STRIDE;
+#pragma unroll
+        for (int j = 0; j < PART_STRIDE; ++j) a[j] += (double)row[j];
+    }
+    for (int i = lane; i < MAXM * MAXM + 2; i += WAVE) Gl[i] = gs[i];      // the rows of the other slots, from earlier iterations
+#pragma unroll
+    for (int j = 0; j < PART_STRIDE; ++j) a[j] = wave_sum(a[j]);           // totals in lane 0
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < MAXM; ++j)
+            if (j < n_filled) { Gl[slot * MAXM + j] = a[j]; Gl[j * MAXM + slot] = a[j]; gs[slot * MAXM + j] = a[j]; gs[j * MAXM + slot] = a[j]; }
+        Gl[MAXM * MAXM] = a[MAXM];                              // |F_k|^2
+        gs[MAXM * MAXM] = a[MAXM];
+    }
+    __syncthreads();
+    const double ff = Gl[MAXM * MAXM], gg = Gl[slot * MAXM + slot];
+    if (lane == 0) {
+        gs[MAXM * MAXM + 1] = gg;                               // |G_k|^2
+        res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
+    }
+    if (n > 0) {
+        // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180), augmented with the right-hand
+        // side as column nn; lane c holds column c
+        const int nn = n + 1;
+        double col[NN];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) {
+            double v = 0.0;
+            if (i < nn && lane <= nn) {
+                if (lane == nn) v = (i == 0) ? 1.0 : 0.0;
+                else if (i == 0 && lane == 0) v = 0.0;
+                else if (i == 0 || lane == 0) v = 1.0;
+                else v = Gl[(i - 1) * MAXM + (lane - 1)] + (i == lane ? (double)lam : 0.0);
+            }
+            col[i] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NN; ++k) {                          // LU, partial pivoting (as LAPACK gesv)
+            if (k < nn) {
+                int piv = k;
+                double best = fabs(col[k]);
+#pragma unroll
+                for (int i = k + 1; i < NN; ++i)
+                    if (i < nn) { const double v = fabs(col[i]); if (v > best) { best = v; piv = i; } }
+                piv = __builtin_amdgcn_readlane(piv, k);        // column k lives in lane k
+#pragma unroll
+                for (int i = k + 1; i < NN; ++i)
+                    if (i == piv) { const double t = col[k]; col[k] = col[i]; col[i] = t; }
+                const double inv = 1.0 / col[k];                // (meaningful in lane k)
+#pragma unroll
+                for (int i = k + 1; i < NN; ++i)
+                    if (i < nn) {
+                        const double f = readlane_f64(col[i] * inv, k);
+                        col[i] -= f * col[k];
+                    }
+            }
+        }
+        if (lane <= nn) {
+#pragma unroll
+            for (int i = 0; i < NN; ++i) M[i][lane] = col[i];
+        }
+        __syncthreads();
         if (lane == 0) {
-            if (j < n_filled) { gs[slot * MAXM + j] = a; gs[j * MAXM + slot] = a; }
-            else gs[MAXM * MAXM] = a;                           // |F_k|^2
+            for (int i = nn - 1; i >= 0; --i) {
+                double v = M[i][nn];
+                for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
+                M[i][nn] = v / M[i][i];
+            }
+            for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
         }
     }
     if (lane != 0) return;
-    const double ff = gs[MAXM * MAXM], gg = gs[slot * MAXM + slot];
-    gs[MAXM * MAXM + 1] = gg;                                   // |G_k|^2
-    res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
-    if (n > 0) {
-        // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180)
-        const int nn = n + 1;
-        for (int i = 0; i < nn; ++i)
-            for (int j = 0; j < nn; ++j) {
-                double v;
-                if (i == 0 && j == 0) v = 0.0;
-                else if (i == 0 || j == 0) v = 1.0;
-                else v = gs[(i - 1) * MAXM + (j - 1)] + (i == j ? (double)lam : 0.0);
-                M[i][j] = v;
-            }
-        for (int i = 0; i < nn; ++i) M[i][nn] = (i == 0) ? 1.0 : 0.0;
-        for (int k = 0; k < nn; ++k) {                        // LU, partial pivoting (as LAPACK gesv)
-            int piv = k;
-            double best = fabs(M[k][k]);
-            for (int i = k + 1; i < nn; ++i) { const double v = fabs(M[i][k]); if (v > best) { best = v; piv = i; } }
-            if (piv != k) for (int j = 0; j <= nn; ++j) { const double t = M[k][j]; M[k][j] = M[piv][j]; M[piv][j] = t; }
-            const double inv = 1.0 / M[k][k];
-            for (int i = k + 1; i < nn; ++i) {
-                const double f = M[i][k] * inv;
-                for (int j = k; j <= nn; ++j) M[i][j] -= f * M[k][j];
-            }
-        }
-        for (int i = nn - 1; i >= 0; --i) {
-            double v = M[i][nn];
-            for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
-            M[i][nn] = v / M[i][i];
-        }
-        for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
-    }
     if (bsz == 1) { res[0] = res[1]; return; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -406,9 +452,11 @@ static int mix_gap_impl(const float* F_hist, const float* G_hist, const float* a
     const int64_t P = H * W, N = P * B;
     const float omb = 1.0f - beta;
     const int pol = pick_policy(bsz * P * (4 * B * (n + 3) + 8), POL_NTLS);
-    // hipExtLaunchKernelGGL stamps ev0/ev1 with the dispatch's own begin/end (what rocprofv3 reports);
-    // with null events it is an ordinary launch.
-#define MG_LAUNCH(KERNEL, TP1, GRID) POL2_DISPATCH(pol, hipExtLaunchKernelGGL((KERNEL<TP1, POL>), GRID, dim3(TB), 0, st, ev0, ev1, 0, F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared))
+    // hipExtLaunchKernelGGL stamps ev0/ev1 with the dispatch's own begin/end (what rocprofv3 reports); without events the
+    // launch is an ordinary one (capturable into a hipGraph).
+#define MG_ARGS F_hist, G_hist, alpha, omb, n, m, phi, y, phisum, x_out, z1, P, phi_shared
+#define MG_LAUNCH(KERNEL, TP1, GRID) POL2_DISPATCH(pol, { if (ev0 || ev1) hipExtLaunchKernelGGL((KERNEL<TP1, POL>), GRID, dim3(TB), 0, st, ev0, ev1, 0, MG_ARGS); \
+                                                           else hipLaunchKernelGGL((KERNEL<TP1, POL>), GRID, dim3(TB), 0, st, MG_ARGS); })
     if (layout == DEQSCI_LAYOUT_HWB && (B == 4 || B == 8 || B == 16 || B == 32)) {
         const int LPv = (int)(B / 4);
         const dim3 grid(ceil_div(P * LPv, TB * UNR), bsz);

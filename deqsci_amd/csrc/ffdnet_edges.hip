@@ -37,6 +37,7 @@ __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * TT_H, c0 = blockIdx.x * TT_W;
     const int lr = threadIdx.x / TT_W, lc = threadIdx.x % TT_W;
+
     const float* hn = h + (int64_t)n * H * W * 64;
     float acc[COUT];
 #pragma unroll
@@ -151,14 +152,15 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
 // VGPRs for the whole 32 x 32-position tile; a wavefront handles 4 neighbouring positions, so its store is one
 // contiguous 1 KiB.  The 68 x 68 full-resolution patch sits in LDS (zero outside the image = the conv's zero
 // padding of the unshuffled channels); the 16 lanes of a position read it by broadcast.
-constexpr int HD_T = 32;                      // tile side in half-res positions
-constexpr int HD_P = 2 * HD_T + 4;            // patch side in full-res pixels
-constexpr int HD_PS = HD_P + 2;               // LDS row stride (even: float2 reads stay 8-B aligned)
-constexpr int HD_SS = HD_T + 3;               // row stride of the sigma plane (HD_T + 2 columns)
-
+// HD_T = tile side in half-res positions: 32, or 16 for grids that would leave CUs idle (8 images of 128 x 128 are 128 tiles of
+// 32 x 32 - half the chip - each a serial loop of 64 trips)
+template <int HD_T>
 __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                          const float* __restrict__ sigma, int sigma_stride,
                                                          float* __restrict__ h, int H, int W) {
+    constexpr int HD_P = 2 * HD_T + 4;            // patch side in full-res pixels
+    constexpr int HD_PS = HD_P + 2;               // LDS row stride (even: float2 reads stay 8-B aligned)
+    constexpr int HD_SS = HD_T + 3;               // row stride of the sigma plane (HD_T + 2 columns)
     __shared__ __attribute__((aligned(16))) float patch[HD_P * HD_PS];
     __shared__ float sgm[(HD_T + 2) * HD_SS];
     const int n = blockIdx.z;
@@ -235,8 +237,13 @@ extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, con
     if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)ceil_div(W, HD_T), (unsigned)ceil_div(H, HD_T), (unsigned)n);
-    hipLaunchKernelGGL(ffdnet_head_kernel, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
+    if (ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus()) {
+        const dim3 grid((unsigned)ceil_div(W, 32), (unsigned)ceil_div(H, 32), (unsigned)n);
+        hipLaunchKernelGGL(ffdnet_head_kernel<32>, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
+    } else {
+        const dim3 grid((unsigned)ceil_div(W, 16), (unsigned)ceil_div(H, 16), (unsigned)n);
+        hipLaunchKernelGGL(ffdnet_head_kernel<16>, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
+    }
     return launch_status();
 }
 

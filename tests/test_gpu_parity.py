@@ -442,7 +442,7 @@ def test_ffdnet_tail_kernel_vs_torch(shape):
     assert float((got_b.double() - want_b).norm() / want_b.norm()) < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96)])
+@pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96), (130, 128, 128)])   # last: the 32 x 32 tile variant
 def test_ffdnet_head_kernel_vs_torch(shape):
     """sigma map + pixel_unshuffle + conv3x3(5->64) + ReLU as one HIP kernel vs the torch ops (incl. ragged
     tiles, per-image sigma and the zero-padded sigma ring at the border)."""
@@ -775,3 +775,65 @@ def test_config2_ffdnet_anderson_180_all_measurements():
         assert rlo <= res <= rhi, (mid, res, rlo, rhi)
     aw = sp["avg_psnr_max"] - sp["avg_psnr_min"]
     assert sp["avg_psnr_min"] - 0.25 * aw - 0.01 <= avg <= sp["avg_psnr_max"] + 0.25 * aw + 0.01, (avg, sp["avg_psnr_min"], sp["avg_psnr_max"])
+
+
+def test_engine_graph_replay_is_bit_identical_to_eager():
+    """The hipGraph path replays the same kernels with the same arguments: first call of a shape eager, second captured,
+    later ones replayed with new inputs - all bit-identical to an engine that never uses a graph; and when the tolerance
+    test would have fired inside a replayed run the call is redone eagerly and stops where the reference stops."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 14)[0].nonlinear_op
+    eager = DEQSCIEngine(net, max_iter=14, use_graph=False)
+    graph = DEQSCIEngine(net, max_iter=14, use_graph=True)
+    want = [eager.reconstruct(ys[i:i + 1], Phi).clone() for i in range(3)]
+    assert eager.last_info["graph"] is False
+    got0 = graph.reconstruct(ys[0:1], Phi)                   # first call of the shape: eager warm-up
+    assert graph.last_info["graph"] is False and torch.equal(got0, want[0])
+    got0 = graph.reconstruct(ys[0:1], Phi)                   # capture + first replay
+    assert graph.last_info["graph"] is True and torch.equal(got0, want[0])
+    for i in (1, 2):                                         # replays with new measurements in the static input buffers
+        got = graph.reconstruct(ys[i:i + 1], Phi)
+        assert graph.last_info["graph"] is True and torch.equal(got, want[i])
+    assert graph.last_info["f_calls"] == eager.last_info["f_calls"] == 15
+    assert graph.last_info["res"] == eager.last_info["res"] and graph.last_info["res_per_sample"] == eager.last_info["res_per_sample"]
+    # "auto": one 256x256 measurement is graph territory, a batch of 6 is not
+    auto = DEQSCIEngine(net, max_iter=5)
+    auto.reconstruct(ys[0:1], Phi)
+    auto.reconstruct(ys[0:1], Phi)
+    assert auto.last_info["graph"] is True
+    auto.reconstruct(ys, Phi)
+    auto.reconstruct(ys, Phi)
+    assert auto.last_info["graph"] is False
+    # early stop inside a replayed run -> eager redo with the reference's stopping rule
+    Phi2, Phie2, x2, z2, y2, Ps2 = make_case(1, 16, 16, 8, seed=11)
+    e1 = DEQSCIEngine(_Contract(), max_iter=50, tol=1e-4, use_graph=False)
+    g1 = DEQSCIEngine(_Contract(), max_iter=50, tol=1e-4, use_graph=True)
+    ref = e1.reconstruct(G(y2), G(Phi2)).clone()
+    for _ in range(3):
+        out = g1.reconstruct(G(y2), G(Phi2))
+        assert torch.equal(out, ref) and g1.last_info["f_calls"] == e1.last_info["f_calls"] < 40 and g1.last_info["graph"] is False
+
+
+def test_harness_frames_per_second_measurement_by_measurement():
+    """Not a parity gate: records the drop-in usage's speed (FFDNet @180, one measurement per call, the reference's schedule)
+    with the graph path, and checks the per-measurement PSNRs agree with the eager engine's to the last digit."""
+    import time
+    from deqsci_amd.harness import SCITestDataset, test_solver_sci
+    _, deq = _pipeline("ffdnet", 180)
+    ds = SCITestDataset(orc.DATA_DIR)
+    rec_g, rec_e = [], []
+    test_solver_sci(deq, test_dataloader=ds, save_img_path="", verbose=False, save_image=False, batch_measurements=False)   # warm-up + capture
+    test_solver_sci(deq, test_dataloader=ds, save_img_path="", verbose=False, save_image=False, batch_measurements=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    test_solver_sci(deq, test_dataloader=ds, save_img_path="", verbose=False, save_image=False, batch_measurements=False, records=rec_g)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert deq._engine_for().last_info["graph"] is True
+    deq._engine_for().use_graph = False
+    test_solver_sci(deq, test_dataloader=ds, save_img_path="", verbose=False, save_image=False, batch_measurements=False, records=rec_e)
+    assert [r["psnr"] for r in rec_g] == [r["psnr"] for r in rec_e]
+    print(f"\nharness FFDNet@180 measurement-by-measurement (hipGraph): 64 frames in {dt:.3f} s = {64 / dt:.1f} frames/s")
+    assert 64 / dt > 40
