@@ -67,6 +67,17 @@ def psnr(rec, gt):
     return 10.0 * math.log10(1.0 / np.mean((a - b) ** 2, dtype=np.float64))
 
 
+def clip_psnr(rec, gt, ids):
+    """PSNR of every scored measurement of a clip: rec (M,H,W,B) on its device, gt (H,W,B*Mall) on the host.  The same
+    arithmetic as `psnr` (float32 difference and square, float64 mean), evaluated where rec lives so that only M scalars
+    cross PCIe."""
+    B = rec.shape[-1]
+    g = torch.stack([torch.as_tensor(gt[..., B * m:B * (m + 1)]) for m in ids]).to(rec.device, torch.float32)
+    d = rec.detach().clamp(0, 1) - g
+    mse = (d * d).double().mean(dim=(1, 2, 3))
+    return [10.0 * math.log10(1.0 / float(v)) for v in mse.cpu()]
+
+
 def frame_payload(frame):
     """One reconstructed frame (H,W) -> the (H,W,1) float image in [0,255] that goes to the PNG writer."""
     return (frame.detach().clamp(0, 1).cpu().numpy() * 255.)[:, :, None]
@@ -165,9 +176,7 @@ def reconstruct_clip(deep_eq_module, clip, device="cuda", batch=True, group=None
     if rec.is_cuda:
         torch.cuda.synchronize(rec.device)
     dt = time.perf_counter() - t0
-    gt = clip['gt']
-    rec_np = rec.clamp(0, 1).cpu().numpy()
-    ps = [psnr(rec_np[i], gt[..., B * m:B * (m + 1)].numpy()) for i, m in enumerate(ids)]
+    ps = clip_psnr(rec, clip['gt'], ids)
     return ClipResult(name=clip['file'], rec=rec, psnr=ps, res=res, frames=B * len(ids), seconds=dt,
                       info={"measurements": ids, "batched": bool(batch)})
 
