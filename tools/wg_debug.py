@@ -17,7 +17,7 @@ for mode in ("delta_center", "random"):
     else:
         w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
     U = _hip.pack_winograd_weights(w)
-    for shape, use_b, relu in (((1, 32, 32), True, 1), ((3, 40, 56), True, 0), ((70, 64, 80), True, 0), ((70, 64, 80), True, 1), ((300, 16, 16), True, 0)):
+    for shape, use_b, relu in (((1, 16, 16), False, 0), ((1, 32, 32), True, 1), ((3, 40, 56), True, 0), ((2, 17, 23), True, 1), ((70, 64, 80), True, 1), ((64, 128, 128), True, 1), ((300, 16, 16), True, 0)):
         x = torch.randn(shape[0], 64, shape[1], shape[2], device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
         b = torch.randn(64, device="cuda", generator=g) if use_b else None
         want = F.conv2d(x.double(), w.double(), b.double() if use_b else None, padding=1)
