@@ -161,6 +161,11 @@ def init_from_env(backend=None):
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
+    elif backend == "gloo+cuda0":
+        # test rig for a ONE-GPU box: every rank on cuda:0, the collective through gloo (RCCL refuses two ranks on one device).
+        # Exercises the real engine + sharding + all-gather plumbing with world size > 1; says nothing about RCCL or speed.
+        torch.cuda.set_device(0)
+        device, backend = torch.device("cuda", 0), "gloo"
     else:
         device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():

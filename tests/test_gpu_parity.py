@@ -837,3 +837,21 @@ def test_harness_frames_per_second_measurement_by_measurement():
     assert [r["psnr"] for r in rec_g] == [r["psnr"] for r in rec_e]
     print(f"\nharness FFDNet@180 measurement-by-measurement (hipGraph): 64 frames in {dt:.3f} s = {64 / dt:.1f} frames/s")
     assert 64 / dt > 40
+
+
+def test_bench_two_ranks_on_one_gpu_real_engine():
+    """World size 2 with the REAL engine: `bench.py --gpus 2 --ranks-share-gpu0` starts two rank processes that share cuda:0
+    and gather through gloo (RCCL refuses two ranks on one device; the build pool has one GPU per box).  Checks the launcher,
+    the sharded step and the gathered result's bookkeeping - not speed, not RCCL."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-share-gpu0", "--batch-per-gpu", "2", "--iters", "12",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-stream"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["f_calls_per_step"] == 13
+    assert rec["allgather_ms_per_step"] > 0 and rec["value"] > 0 and 0 < rec["final_res"] < 1
