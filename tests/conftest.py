@@ -11,6 +11,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the CPU oracle (torch / oneDNN) is fastest at ~16 threads; on the 128-core GPU host the default (all cores) is 5x slower
+    import torch
+    if (os.cpu_count() or 1) > 32:
+        torch.set_num_threads(16)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "slow: long CPU oracle runs")
 

@@ -855,3 +855,33 @@ def test_bench_two_ranks_on_one_gpu_real_engine():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["f_calls_per_step"] == 13
     assert rec["allgather_ms_per_step"] > 0 and rec["value"] > 0 and 0 < rec["final_res"] < 1
+
+
+def test_engine_512x512x16_ffdnet_vs_oracle():
+    """BASELINE config 4 with its own denoiser: FFDNet at 512x512x16 (half-resolution planes of 256x256 through the head / tail
+    stencils and the Winograd layers, the B = 16 kernel instantiations, batch 2 with per-sample masks), and_maxiters=5, against
+    the CPU oracle with an exactly accumulated Gram (see test_engine_512x512x16_vs_oracle for why) and, per f-call, against
+    the oracle's single-iterate map."""
+    g = torch.Generator().manual_seed(14)
+    H = W = 512
+    B = 16
+    Phi = (torch.rand(2, H, W, B, generator=g) < 0.5).float()
+    x = torch.rand(2, H, W, B, generator=g)
+    y = orc.sci_forward(x, Phi)
+    Ps = orc.phi_sum(Phi)
+    kw = dict(m=5, beta=1.0, lam=1e-2, max_iter=5, tol=1e-5)
+    f64 = orc.ProxGradSCI("ffdnet")
+    want64, wres = orc.deq_forward(f64, orc.andersonexp, y, Phi, Ps, orc.initial_point(y, Phi), gram_dtype=torch.float64, **kw)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 5)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=5)
+    got = eng.reconstruct(G(y), G(Phi)).cpu().numpy()
+    assert eng.last_info["f_calls"] == 6 and f64.calls == 7
+    assert rel_l2(got, want64.numpy()) < 5e-5
+    assert abs(eng.last_info["res"] - wres) < 5e-3 * wres
+    # one f-call on its own (GAP + FFDNet at sigma_0): the drop-in solver against the oracle map
+    solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 5)
+    f1 = orc.ProxGradSCI("ffdnet")
+    z0 = orc.initial_point(y, Phi)
+    with torch.no_grad():
+        out = solver(G(z0), G(y), G(Phi), G(Ps))
+    assert rel_l2(out.cpu().numpy(), f1(z0, y, Phi, Ps).numpy()) < 1e-5
