@@ -468,7 +468,7 @@ def g11():
 
 
 # --------------------------------------------------------------------------- g10 (config-2 spread)
-def g10(seeds="1-8", threads=6, only=None, iters=180):
+def g10(seeds="1-8", threads=6, only=None, iters=180, gram64=0):
     """BASELINE config 2 (FFDNet, Anderson, and_maxiters=180, every shipped measurement) is chaotic on the
     `traffic` clip: this measures the REFERENCE's own spread.  Every measurement is run through the
     reference's DEQFixedPoint.forward (new_equilibrium_utils_yaping.py:249-281) as ONE batch of variants of the
@@ -480,7 +480,8 @@ def g10(seeds="1-8", threads=6, only=None, iters=180):
     lo, hi = (int(v) for v in str(seeds).split("-"))
     seed_list = list(range(lo, hi + 1))
     iters = int(iters)
-    fn = HERE + f"/e2e_ffdnet_anderson_{iters}_spread.json"
+    gram64 = int(gram64)      # 1: EVERY row with the Gram matrix of :178 in float64 (the reference algorithm with an exact Gram)
+    fn = HERE + f"/e2e_ffdnet_anderson_{iters}_spread" + ("_gram64" if gram64 else "") + ".json"
     book = json.load(open(fn)) if os.path.exists(fn) else {"measurements": {}}
     base_gold = {m["id"]: m for m in json.load(open(HERE + f"/e2e_ffdnet_anderson_{iters}.json"))["measurements"]}
     solver, deq = build_deq("ffdnet", iters)
@@ -500,7 +501,9 @@ def g10(seeds="1-8", threads=6, only=None, iters=180):
     def bmm_f64_last_row(a, b):
         out = real_bmm(a, b)
         i = state["f64row"]
-        if i is not None and a.shape[0] > i and a.shape[1] <= 5 and a.dtype == torch.float32:
+        if i == "all" and a.shape[1] <= 5 and a.dtype == torch.float32:
+            return real_bmm(a.double(), b.double()).float()
+        if i is not None and i != "all" and a.shape[0] > i and a.shape[1] <= 5 and a.dtype == torch.float32:
             out[i] = real_bmm(a[i:i + 1].double(), b[i:i + 1].double())[0].float()
         return out
     torch.bmm = bmm_f64_last_row
@@ -515,7 +518,7 @@ def g10(seeds="1-8", threads=6, only=None, iters=180):
                     continue
                 entry = book["measurements"].setdefault(mid, {"variants": {}})
                 todo = [s for s in seed_list if f"seed{s}" not in entry["variants"]]
-                names = ["base"] + [f"seed{s}" for s in todo] + ["gram_fp64"]
+                names = (["base"] + [f"seed{s}" for s in todo] + ["gram_fp64"]) if not gram64 else (["g64_base"] + [f"g64_seed{s}" for s in todo])
                 V = len(names)
                 y1 = torch.from_numpy(d["meas"][..., fi])[None]
                 gt1 = torch.from_numpy(d["gt"][..., 8 * fi:8 * fi + 8])[None]
@@ -526,9 +529,10 @@ def g10(seeds="1-8", threads=6, only=None, iters=180):
                 for s in todo:
                     g = torch.Generator().manual_seed(s)
                     xs.append(x0 * (1 + 1e-7 * torch.randn(x0.shape, generator=g)))
-                xs.append(x0)
+                if not gram64:
+                    xs.append(x0)
                 X0 = torch.cat(xs).contiguous()
-                state.update(n=0, f64row=V - 1)
+                state.update(n=0, f64row="all" if gram64 else V - 1)
                 t0 = time.time()
                 rec = deq.forward(y1.expand(V, -1, -1).contiguous(), Phi1.expand(V, -1, -1, -1).contiguous(),
                                   Ps1.expand(V, -1, -1).contiguous(), initial_point=X0, train_flag=False)
@@ -536,7 +540,7 @@ def g10(seeds="1-8", threads=6, only=None, iters=180):
                 base = rec[0]
                 sha = sha16(base[None].numpy().clip(0, 1))
                 entry["base_sha16_clip"] = sha
-                entry["base_matches_bsz1_golden"] = bool(sha == base_gold[mid]["sha16_clip"])
+                entry["base_matches_bsz1_golden"] = bool(sha == base_gold[mid]["sha16_clip"]) if not gram64 else None
                 entry["f_calls"] = state["n"]
                 for i, nm in enumerate(names):
                     r = rec[i:i + 1]

@@ -49,7 +49,7 @@ def main():
         print(name, {k: round(v["psnr"], 4) for k, v in rows.items()}, flush=True)
     # x0 perturbations through the default engine (the reference ensemble's recipe)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=iters, tol=1e-5)
-    for seed in (1, 2, 3):
+    for seed in range(1, 9):
         rows = {}
         for clip in clips:
             Phi = clip["mask"].to(dev)[None].contiguous()

@@ -47,8 +47,11 @@ def main():
            "Weights: `cnn.ckpt` (SimpleCNN), `rsn_cnn.ckpt` (RealSN_SimpleCNN), `net_gray.pth` (FFDNet substitute for the missing "
            "`ffdnet.ckpt`). 3 shipped clips = 8 measurements = 64 frames. Reference numbers: `tests/golden/e2e_*.json`.", ""]
     ds = list(SCITestDataset(DATA))                          # the three clips, read from disk once (file I/O is not what is timed)
+    only = sys.argv[2] if len(sys.argv) > 2 else None         # e.g. "ffdnet:180"
     for kind, iters in (("SimpleCNN", 10), ("SimpleCNN", 100), ("SimpleCNN", 180), ("RealSN_SimpleCNN", 10), ("RealSN_SimpleCNN", 100),
                         ("ffdnet", 10), ("ffdnet", 30), ("ffdnet", 180)):
+        if only and only != f"{kind}:{iters}":
+            continue
         meta_path = os.path.join(GOLDEN, f"e2e_{kind}_anderson_{iters}.json")
         if not os.path.exists(meta_path):
             continue
