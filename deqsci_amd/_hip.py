@@ -41,6 +41,8 @@ SIGNATURES = {
     "deqsci_conv3x3_c1_to_64_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_winograd44_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -395,6 +397,31 @@ def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):
     with _dev(x):
         _check(load().deqsci_conv3x3_c64_winograd_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
                                                       n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd")
+    return o
+
+
+def pack_winograd44_weights(w):
+    """(64,64,3,3) conv weight -> U = G g G^T of Winograd F(4x4,3x3) (6x6 per cout, cin; computed in float64, rounded once) in the
+    LDS order of csrc/winograd44.hip: [cin chunk c (8)][s (18)][rg (2)][cgp (2)][q (4)][i (16)][j (2)][ks (2)] with transform
+    position (3 rg + s // 6, s % 6), cout = 32 cgp + 16 j + i, cin = 8 c + 2 q + ks."""
+    if tuple(w.shape) != (64, 64, 3, 3):
+        raise DeqsciHipError(f"winograd conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                      [0, 0, 1]], dtype=torch.float64, device=w.device)
+    U = G @ w.detach().double() @ G.t()                             # (cout, cin, 6, 6)
+    U = U.reshape(2, 2, 16, 8, 4, 2, 2, 3, 6)                       # [cgp][j][i][c][q][ks][rg][sr][sc]
+    return U.permute(3, 7, 8, 6, 0, 4, 2, 1, 5).contiguous().float()   # [c][sr][sc][rg][cgp][q][i][j][ks]
+
+
+def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None):
+    """x (n,64,H,W) channels_last -> relu(conv3x3(x, w, pad=1) + bias), Winograd F(4x4,3x3) (the large-batch kernel)."""
+    n, c, H, W = x.shape
+    if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
+        raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
+    o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+    with _dev(x):
+        _check(load().deqsci_conv3x3_c64_winograd44_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
+                                                        n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd44")
     return o
 
 

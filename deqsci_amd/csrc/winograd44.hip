@@ -1,0 +1,437 @@
+// 3x3 convolution 64 -> 64 channels (pad 1, stride 1, fp32, channels_last) as Winograd F(4x4,3x3) on the fp32 matrix
+// cores of MI355X, bias (folded BatchNorm) and ReLU fused.  Same layer as csrc/winograd.hip (networks/ffdnet/models.py:53-58,
+// SimpleCNN_models.py:47-53), 2.25 multiplications per output instead of 4: the large-batch kernel.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      6x6 input patch d (stride 4) -> 4x4 outputs, 36 transform positions
+//
+// Block tile = 4 x 8 Winograd tiles (16 x 32 output pixels) x 64 couts, ONE persistent 8-wave workgroup per CU walking the
+// block tiles of "its" XCD, input channels in chunks of 8 (as in winograd.hip).  What is different, and why:
+//   * 36 positions x (16 tiles x 16 couts) accumulators do not fit one wave next to its operands, and a wave alone on a
+//     SIMD cannot stream its weight operands from LDS at the matrix-pipe rate (44 cycles per MFMA instead of 32,
+//     tools/ubench/mfma_f32_stage.hip).  So the 6 ROWS of the position grid are split between two waves: wave
+//     (rg, cgp, tg) owns position rows [3 rg, 3 rg + 3) x couts [32 cgp, +32) x tiles [16 tg, +16): 18 x 2 accumulators
+//     of v_mfma_f32_16x16x4_f32 (144 registers).  The split is free for the input transform - V = B^T d B restricted to
+//     three rows of B^T is exactly half the work (column pass 6 x 6 ops, row pass 3 x 12) - so a wave spends ONE packed
+//     vector instruction per MFMA on it (72 : 72), as F(2x2,3x3) does with its two cout halves.
+//   * the output transform needs all 6 rows: each wave reduces ITS rows to the 4x4 partial result, keeps two output rows
+//     and hands the other two to its partner wave through LDS (4 rounds of 32 KB per block tile, 7 barriers).
+//   * one weight chunk is 36 x 64 x 8 floats = 72 KB: it is SINGLE-buffered and refilled in two halves behind two barriers
+//     per stage (positions are consumed in the same order by every wave: after the first 10 of a wave's 18 positions
+//     everyone has passed barrier X1 and the DMA may overwrite them with the next chunk, the other 8 after X2), each half
+//     with half a stage of lead time.  Raw input tiles (18 x 34 pixels x 8 channels) stay double-buffered.
+//   * the 6x6 patch is read from LDS while it is transformed (it would cost 72 registers to hold); pixel stride 10 floats
+//     and a 4-float shift per group of four pixel rows make those reads bank-conflict free.
+// LDS: 72 KB weights + 2 x 25 KB raw + 32 KB exchange + bias = 154.3 KB.  Rounding: 1.2e-6 per layer against fp64
+// (F(2x2,3x3): 2.1e-7); end to end the FFDNet gates do not move (tools/f44_numerics.py, profiles/r02_f44_numerics.jsonl).
+#include "common.hpp"
+#include <hip/hip_ext.h>
+#include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is named as a clobber of the LDS-DMA asm below, on purpose
+
+#ifndef W44_ABL
+#define W44_ABL 0     // debugging / timing ablations only: 1 = no raw DMA, 2 = no weight DMA, 4 = no output stores, 8 = no exchange
+#endif
+
+namespace deqsci {
+namespace w44 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 8, NCHUNK = 64 / CK;
+constexpr int WAVES = 8, TBW = 64 * WAVES;
+constexpr int TILE_ROWS = 4, TILE_COLS = 8;                  // Winograd tiles per block tile
+constexpr int OUT_ROWS = 4 * TILE_ROWS, OUT_COLS = 4 * TILE_COLS;
+constexpr int RAW_ROWS = OUT_ROWS + 2, RAW_COLS = OUT_COLS + 2;              // 18 x 34 staged pixels
+constexpr int RAW_HALF_U = RAW_ROWS * RAW_COLS;              // 612 units of 16 bytes per channel half
+constexpr int RAW_DMA = 20;                                  // DMA instructions of 64 units per chunk tile (1224 units used)
+constexpr int RAW_BUF = RAW_DMA * 64 * 4;                    // 5120 floats = 20 KB
+constexpr uint32_t RAW_OOB = 0x80000000u;                    // buffer offset of a pixel outside the image: beyond num_records -> zeros
+constexpr int NSTEP = 18;                                    // positions per wave
+constexpr int U_STEP = 2 * 2 * 64 * 4;                       // floats of one step in LDS: [rg][cgp][lane][j][ks]
+constexpr int U_CHUNK = NSTEP * U_STEP;                      // 18432 floats = 72 KB
+constexpr int SPLIT = 10;                                    // steps [0, SPLIT) are refilled behind X1, [SPLIT, 18) behind X2
+constexpr int XCH = WAVES * 4 * 64 * 4;                      // exchange area: 4 x 16 bytes per lane and wave = 32 KB
+constexpr int DMA1_PIECES = SPLIT * U_STEP * 4 / 1024 / WAVES;             // 5 KiB per wave
+constexpr int DMA2_PIECES = (NSTEP - SPLIT) * U_STEP * 4 / 1024 / WAVES;   // 4 KiB per wave
+static_assert(DMA1_PIECES == 5 && DMA2_PIECES == 4, "DMA split");
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, float k, f32x2 c) { return __builtin_elementwise_fma(a, (f32x2){k, k}, c); }
+
+// float offset of patch pixel (pr, pc) from patch pixel (0, 0) of the same tile in the raw layout (see the kernel)
+__device__ __forceinline__ constexpr int patch_off(int pr, int pc) {
+    return (pr * RAW_COLS + ((pc & 3) == 0 ? 0 : (pc & 3) == 1 ? 9 : (pc & 3) == 2 ? 18 : 26) + (pc >> 2)) * 4;
+}
+
+// 1-D input transform of F(4,3): y = B^T x, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void bt_lo(const f32x2* x, f32x2& y0, f32x2& y1, f32x2& y2) {
+    y0 = fma2(x[2], -5.0f, fma2(x[0], 4.0f, x[4]));
+    const f32x2 a = fma2(x[2], -4.0f, x[4]), b = fma2(x[1], -4.0f, x[3]);
+    y1 = a + b;
+    y2 = a - b;
+}
+__device__ __forceinline__ void bt_hi(const f32x2* x, f32x2& y3, f32x2& y4, f32x2& y5) {
+    const f32x2 c = x[4] - x[2], d = x[3] - x[1];
+    y3 = fma2(d, 2.0f, c);
+    y4 = fma2(d, -2.0f, c);
+    y5 = fma2(x[3], -5.0f, fma2(x[1], 4.0f, x[5]));
+}
+
+__global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
+                                                                   const float* __restrict__ bias, float* __restrict__ y,
+                                                                   int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles,
+                                                                   uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+    __shared__ __attribute__((aligned(16))) float Us[U_CHUNK];
+    __shared__ __attribute__((aligned(16))) float Raw[2 * RAW_BUF];
+    __shared__ __attribute__((aligned(16))) float Xs[XCH];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = (int)uniform((uint32_t)(tid >> 6));
+    const int rg = wave & 1, cgp = (wave >> 1) & 1, tg = wave >> 2;
+
+    int t_first, t_step, t_end;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((nb & 7) == 0) {
+            const int per_xcd = (n_tiles + 7) >> 3;
+            t_first = (b & 7) * per_xcd + (b >> 3);
+            t_step = nb >> 3;
+            t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
+        } else { t_first = b; t_step = nb; t_end = n_tiles; }
+    }
+    if (t_first >= t_end) return;
+
+    // ---- raw staging by the LDS-DMA path: the chunk tile is 1224 units of 16 bytes (pixel, channel half) = 20 instructions
+    // buffer_load_dwordx4 ... lds of 64 units; wave w issues instructions w, w + 8 and w + 16 (waves 4..7: w + 8 again, so that
+    // every wave has the same number of operations in flight).  The LDS side is lane-linear (M0 + 16 lane), the global side a
+    // per-lane offset, so the tile's LAYOUT is chosen by which pixel each lane fetches:
+    //     unit(half, row, col) = 612 half + 34 row + COLMAP(col),  COLMAP(col) = {0, 9, 18, 26}[col & 3] + (col >> 2)
+    // i.e. the columns of one residue class mod 4 are consecutive.  A patch read touches, per half wave, the pixels
+    // (R + 4 ty, C + 4 tx) of 16 tiles: units base + tx + 136 ty = 16 distinct residues mod 16, every bank exactly once.
+    // Pixels outside the image get an offset beyond the buffer descriptor's range: the hardware writes zeros for them
+    // (tools/ubench/buffer_lds_oob.hip), so the zero padding costs no instruction.
+    uint32_t voff[3];
+    i32x4 rsrc;
+    auto set_fetch_tile = [&](int t) {
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        const uint64_t base = (uint64_t)(x + (int64_t)n * H * W * 64);
+        rsrc.x = (int)uniform((uint32_t)base);
+        rsrc.y = (int)uniform((uint32_t)(base >> 32));            // stride 0: raw buffer, offsets in bytes
+        rsrc.z = (int)uniform((uint32_t)(H * W) * 256u);          // num_records = bytes of one image (< 2^32: launcher)
+        rsrc.w = 0x00020000;
+        const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;   // image coordinates of staged pixel (0,0)
+        int el = lane;
+        asm volatile("" : "+v"(el));                               // (keeps hipcc from carrying the unit decode through the loop)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = (j == 2 && wave >= 4) ? wave + 8 : wave + 8 * j;
+            const int u = 64 * k + el;
+            const int half = u >= RAW_HALF_U, ru = u - half * RAW_HALF_U;
+            const int row = (ru * 1928) >> 16, cu = ru - row * RAW_COLS;          // ru / 34 for ru < 768
+            const int col = cu < 9 ? 4 * cu : (cu < 18 ? 4 * (cu - 9) + 1 : (cu < 26 ? 4 * (cu - 18) + 2 : 4 * (cu - 26) + 3));
+            const int iy = py0 + row, ix = px0 + col;
+            const bool ok = u < 2 * RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            voff[j] = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half : RAW_OOB;
+        }
+    };
+    const uint32_t raw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Raw;
+    // chunk c of the fetch tile -> Raw[buf]: the scalar offset selects the 8 channels (32 bytes) of the chunk
+    auto dma_raw = [&](int c, int buf) {
+        const uint32_t soff = uniform((uint32_t)c * (CK * 4));
+        int w = wave;
+        asm volatile("" : "+s"(w));                                // recompute the M0 values here (scalar ALU is free; SGPRs are not)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = (j == 2 && w >= 4) ? w + 8 : w + 8 * j;
+            const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + k * 1024));
+            if (!(W44_ABL & 1))
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                             ::"s"(m0v), "v"(voff[j]), "s"(rsrc), "s"(soff) : "memory", "m0");
+        }
+    };
+
+    // ---- weight chunk: host-packed in LDS order; half 1 = bytes [0, 40 KiB), half 2 = [40 KiB, 72 KiB); wave w moves a
+    // contiguous share of each half by the LDS-DMA path, pieces of 1 KiB that differ only in their immediate offset
+    const uint32_t us_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
+    const uint32_t dma_voff = (uint32_t)(lane * 16);
+    auto dma_setup = [&](int c, int half) -> uint64_t {
+        int w = wave;
+        asm volatile("" : "+s"(w));
+        const uint32_t share = half == 0 ? (uint32_t)(w * DMA1_PIECES * 1024 + 2048)
+                                         : (uint32_t)(SPLIT * U_STEP * 4 + w * DMA2_PIECES * 1024 + 2048);
+        const uint64_t g = (uint64_t)(Ug + (int64_t)c * U_CHUNK) + share;
+        asm volatile("s_mov_b32 m0, %0" ::"s"(uniform(us_lds + share)) : "m0");
+        return ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
+    };
+#define W44_DMA(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF ::"v"(dma_voff), "s"(dg) : "memory")
+    auto dma_half = [&](int c, int half) {
+        const uint64_t dg = dma_setup(c, half);
+        if (W44_ABL & 2) return;
+        W44_DMA(-2048); W44_DMA(-1024); W44_DMA(0); W44_DMA(1024);
+        if (half == 0) W44_DMA(2048);
+    };
+
+    f32x4 acc[NSTEP][2];
+
+    // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16 tg + i and channels {2q, 2q+1} of the chunk
+    const int mi = lane & 15, mq = lane >> 4;
+    const int ty = mi >> 3, tx = mi & 7;
+    // float offset of channel pair mq of patch pixel (0,0) of the lane's tile in a raw buffer; patch pixel (pr, pc) is a constant away
+    const int pbase = ((mq >> 1) * RAW_HALF_U + 4 * (2 * tg + ty) * RAW_COLS + tx) * 4 + 2 * (mq & 1);
+    const float* ub = Us + ((rg * 2 + cgp) * 64 + lane) * 4;
+
+    f32x2 v[NSTEP];
+    // V = B^T d B, rows [3 rg, 3 rg + 3) only
+    auto transform = [&](int buf) __attribute__((always_inline)) {
+        const float* pp = Raw + buf * RAW_BUF;
+        f32x2 t[3][6];
+        if (rg == 0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x2 d[6];
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) d[pr] = *reinterpret_cast<const f32x2*>(pp + pbase + patch_off(pr, j));
+                bt_lo(d, t[0][j], t[1][j], t[2][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                f32x2 d[6];
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) d[pr] = *reinterpret_cast<const f32x2*>(pp + pbase + patch_off(pr, j));
+                bt_hi(d, t[0][j], t[1][j], t[2][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            bt_lo(t[r], v[r * 6], v[r * 6 + 1], v[r * 6 + 2]);
+            bt_hi(t[r], v[r * 6 + 3], v[r * 6 + 4], v[r * 6 + 5]);
+        }
+    };
+
+    // ---- output transform Y = A^T M A, A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Each wave reduces its
+    // three rows of M: W = M A (3 x 4), then the partial A^T W over its rows (4 x 4); rg 0 finishes output rows 0, 1 and rg 1
+    // rows 2, 3, the other two rows of the partial go to the partner wave (wave ^ 1) through Xs.  The bias is already inside:
+    // position (1,1) has coefficient 1 in all 16 outputs and its accumulator (rg 0, step 7) starts from the bias.
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        float* yn = y + (int64_t)n * H * W * 64;
+        // every lane-dependent address of the epilogue is derived from an opaque copy of the lane index: hipcc would otherwise
+        // hoist them out of the persistent loop and keep a dozen registers alive through the MFMA stages (= spills there)
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int ei = el & 15, eq = el >> 4;
+        const int oy = OUT_ROWS * by + 4 * (2 * tg + (ei >> 3)) + 2 * rg, ox = OUT_COLS * bx + 4 * (ei & 7);
+        float* o = yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
+        float* xw = Xs + (wave * 4 * 64 + el) * 4;
+        const float* xr = Xs + ((wave ^ 1) * 4 * 64 + el) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x2 Wm[3][4];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr) {
+                    f32x2 m[6];
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) m[c] = (f32x2){acc[rr * 6 + c][j][2 * h], acc[rr * 6 + c][j][2 * h + 1]};
+                    const f32x2 a = m[1] + m[2], b = m[1] - m[2], cc = m[3] + m[4], d = m[3] - m[4];
+                    Wm[rr][0] = (m[0] + a) + cc;
+                    Wm[rr][1] = fma2(d, 2.0f, b);
+                    Wm[rr][2] = fma2(cc, 4.0f, a);
+                    Wm[rr][3] = fma2(d, 8.0f, b) + m[5];
+                }
+                f32x2 mine[8], send[8];
+                if (rg == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x2 s = Wm[1][c] + Wm[2][c], dd = Wm[1][c] - Wm[2][c];
+                        mine[c] = Wm[0][c] + s;
+                        mine[4 + c] = dd;
+                        send[c] = s;
+                        send[4 + c] = dd;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x2 s = Wm[0][c] + Wm[1][c], dd = Wm[0][c] - Wm[1][c];
+                        send[c] = s;
+                        send[4 + c] = dd + dd;
+                        mine[c] = s * 4.0f;
+                        mine[4 + c] = fma2(dd, 8.0f, Wm[2][c]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4*>(xw + q * 256) = (f32x4){send[2 * q].x, send[2 * q].y, send[2 * q + 1].x, send[2 * q + 1].y};
+                lds_barrier();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 got = *reinterpret_cast<const f32x4*>(xr + q * 256);
+                    mine[2 * q] += (f32x2){got.x, got.y};
+                    mine[2 * q + 1] += (f32x2){got.z, got.w};
+                }
+                if (!(j == 1 && h == 1)) lds_barrier();               // the partner has read before the next round overwrites
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        f32x2 val = mine[rr * 4 + c];
+                        if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); }
+                        if (!(W44_ABL & 4) && oy + rr < H && ox + c < W)
+                            *reinterpret_cast<f32x2*>(o + 16 * j + 2 * h + ((int64_t)rr * W + c) * 64) = val;
+                    }
+            }
+        }
+    };
+
+    // ---- prologue (once per workgroup): bias, U(0) whole, raw(0), raw(1) staged; V(0) computed; raw(2) on its way
+    if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.0f;
+    set_fetch_tile(t_first);
+    dma_half(0, 0);
+    dma_half(0, 1);
+    dma_raw(0, 0);
+    dma_raw(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform(0);
+    __syncthreads();                                          // everyone has read raw(0): the fetch of raw(2) may overwrite it
+    dma_raw(2, 0);
+    int t_fetch = t_first;
+
+    // One stage = chunk c of the current tile.  PAR = c&1: Raw[PAR^1] holds raw(c+1), Raw[PAR] is receiving raw(c+2).
+    // Vector memory operations of a wave, in issue order: behind X2 of the previous stage [second half of U(c) x4, raw(c+3)
+    // x3]; behind X1 [first half of U(c+1) x5].  vmcnt(3) in front of X1 = the weights are in (the raw tile may still be
+    // landing: it is needed after X1 of the NEXT stage), vmcnt(0) in front of X2.  (Register spills would be scratch = vector
+    // memory operations in between: the loop must compile without any.)
+    auto stage = [&](auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
+        // entry: Us = U(c) (steps >= SPLIT still landing), Raw[PAR^1] = raw(c+1) visible, v = V(c), raw(c+2) landing in Raw[PAR]
+        f32x4 init7[2];
+        if (FIRST) {
+            int el = lane;
+            asm volatile("" : "+v"(el));                      // (address computed here, not carried through the loop)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + 32 * cgp + 16 * j + 4 * (el >> 4));
+                init7[j] = rg == 0 ? bv : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+        constexpr int PF = 2;
+        float4 bq[PF + 1];
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#define W44_STEP(S)                                                                                                                   \
+        {                                                                                                                             \
+            const float4 b = bq[(S) % (PF + 1)];                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+            acc[S][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[S].x, FIRST ? ((S) == 7 ? init7[0] : zero) : acc[S][0], 0, 0, 0); \
+            acc[S][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, v[S].x, FIRST ? ((S) == 7 ? init7[1] : zero) : acc[S][1], 0, 0, 0); \
+            acc[S][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, v[S].y, acc[S][0], 0, 0, 0);                                        \
+            acc[S][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, v[S].y, acc[S][1], 0, 0, 0);                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        }
+        // ---- first part: steps [0, SPLIT)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bq[i] = *reinterpret_cast<const float4*>(ub + i * U_STEP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < SPLIT; ++s) {
+            if (s + PF < SPLIT) bq[(s + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (s + PF) * U_STEP);
+            W44_STEP(s);
+        }
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // second half of U(c) in LDS
+        lds_barrier();                                        // X1: steps >= SPLIT of U(c) visible; everyone is done with steps < SPLIT
+        dma_half((c + 1) & 7, 0);
+        // ---- second part: steps [SPLIT, 18)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bq[(SPLIT + i) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (SPLIT + i) * U_STEP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = SPLIT; s < NSTEP; ++s) {
+            if (s + PF < NSTEP) bq[(s + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (s + PF) * U_STEP);
+            W44_STEP(s);
+        }
+        __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise starts the transform above the MFMAs that still read v)
+        transform(PAR ^ 1);                                   // V(c+1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first half of U(c+1) and raw(c+2) are in LDS
+        lds_barrier();                                        // X2: both visible; everyone is done with U(c) and raw(c+1)
+        if (c == 7) epilogue(t_cur);                          // (its stores first: older than the DMA, they never hold vmcnt(3) up)
+        if (c == 5) {                                         // chunks c+3.. of the fetch stream belong to the next tile
+            if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
+            set_fetch_tile(t_fetch);
+        }
+        dma_half((c + 1) & 7, 1);
+        dma_raw((c + 3) & 7, PAR ^ 1);                        // raw(c+3) into the buffer raw(c+1) has just been read from
+    };
+    using std::integral_constant;
+#pragma unroll 1
+    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+        stage(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
+        stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, 1, t_cur);
+#pragma unroll 1
+        for (int c = 2; c < NCHUNK; c += 2) {
+            stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, c, t_cur);
+            stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c + 1, t_cur);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace w44
+}  // namespace deqsci
+
+using namespace deqsci;
+
+static void w44_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = 31 + s;
+    *mg = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+}
+
+static int winograd44_impl(const float* x, const float* u_packed, const float* bias, float* y, int64_t n, int64_t H, int64_t W,
+                           int relu, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    if (!x || !u_packed || !y) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, w44::OUT_COLS), tiles_y = ceil_div(H, w44::OUT_ROWS);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W >= (int64_t)1 << 24) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t resident = (int64_t)num_cus();
+    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    w44_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    w44_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
+    if (ev0 || ev1)
+        hipExtLaunchKernelGGL(w44::winograd44_conv64_kernel, grid, dim3(w44::TBW), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W,
+                              relu, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);
+    else
+        hipLaunchKernelGGL(w44::winograd44_conv64_kernel, grid, dim3(w44::TBW), 0, st, x, u_packed, bias, y, (int)H, (int)W, relu,
+                           (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);
+    return launch_status();
+}
+
+extern "C" int deqsci_conv3x3_c64_winograd44_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
+                                                 int64_t H, int64_t W, int relu, deqsci_stream_t stream) {
+    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, stream, nullptr, nullptr);
+}
+
+extern "C" int deqsci_conv3x3_c64_winograd44_timed_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
+                                                       int64_t H, int64_t W, int relu, deqsci_stream_t stream, void* start_event,
+                                                       void* stop_event) {
+    if (!start_event || !stop_event) return DEQSCI_ERR_NULL;
+    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, stream, static_cast<hipEvent_t>(start_event),
+                           static_cast<hipEvent_t>(stop_event));
+}

@@ -163,6 +163,14 @@ int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* s
 int deqsci_conv3x3_c64_winograd_f32(const float* x, const float* u_packed, const float* bias, float* y,
                                     int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream);
 
+/* The same layer as Winograd F(4x4,3x3): 2.25 instead of 4 multiplications per output, the large-batch kernel (block tiles of
+ *     16 x 32 output pixels, one persistent workgroup per CU: it wants >= ~2 block tiles per CU; small launches belong to the
+ *     F(2x2,3x3) entry point above).  Same arguments; u_packed = U = G g G^T (6x6 per cout, cin) ordered
+ *     [cin chunk c (8)][s (18)][rg (2)][cgp (2)][q (4)][i (16)][j (2)][ks (2)] with transform position (3 rg + s / 6, s % 6),
+ *     cout = 32 cgp + 16 j + i, cin = 8 c + 2 q + ks.  Rounding ~1.2e-6 per layer (F(2x2,3x3): 2.1e-7). */
+int deqsci_conv3x3_c64_winograd44_f32(const float* x, const float* u_packed, const float* bias, float* y,
+                                      int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream);
+
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
  * without the marker-packet overhead of events recorded around a launch. */
@@ -176,6 +184,9 @@ int deqsci_anderson_mix_gap_timed_f32(const float* F_hist, const float* G_hist, 
 int deqsci_conv3x3_c64_winograd_timed_f32(const float* x, const float* u_packed, const float* bias, float* y,
                                           int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream,
                                           void* start_event, void* stop_event);
+int deqsci_conv3x3_c64_winograd44_timed_f32(const float* x, const float* u_packed, const float* bias, float* y,
+                                            int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream,
+                                            void* start_event, void* stop_event);
 int deqsci_event_create(void** ev);
 int deqsci_event_destroy(void* ev);
 int deqsci_event_elapsed_ms(void* start_event, void* stop_event, float* ms);   /* after the stream is synchronised */
