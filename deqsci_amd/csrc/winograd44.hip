@@ -28,8 +28,19 @@
 #include <type_traits>
 #pragma clang diagnostic ignored "-Winline-asm"   // m0 is named as a clobber of the LDS-DMA asm below, on purpose
 
+#ifndef W44_RAW_DMA
+#define W44_RAW_DMA 1 // 1 = raw tiles by buffer_load ... lds (no staging registers; measured slower: the scattered 16-byte units cost the
+                      // texture path ~3 cycles per lane), 0 = through registers
+#endif
+#ifndef W44_RAWPOS
+#define W44_RAWPOS 0  // experiment: 1 = raw DMA issued behind X1 (one chunk later) instead of behind X2
+#endif
+#ifndef W44_PF
+#define W44_PF 2      // weight operands are read this many positions ahead
+#endif
 #ifndef W44_ABL
-#define W44_ABL 0     // debugging / timing ablations only: 1 = no raw DMA, 2 = no weight DMA, 4 = no output stores, 8 = no exchange
+#define W44_ABL 0     // debugging / timing ablations only: 1 = no raw DMA, 2 = no weight DMA, 4 = no output stores, 16 = no input transform,
+                      // 32 = no output transform at all, 64 = no patch reads (transform of constants)
 #endif
 
 namespace deqsci {
@@ -45,8 +56,9 @@ constexpr int TILE_ROWS = 4, TILE_COLS = 8;                  // Winograd tiles p
 constexpr int OUT_ROWS = 4 * TILE_ROWS, OUT_COLS = 4 * TILE_COLS;
 constexpr int RAW_ROWS = OUT_ROWS + 2, RAW_COLS = OUT_COLS + 2;              // 18 x 34 staged pixels
 constexpr int RAW_HALF_U = RAW_ROWS * RAW_COLS;              // 612 units of 16 bytes per channel half
-constexpr int RAW_DMA = 20;                                  // DMA instructions of 64 units per chunk tile (1224 units used)
-constexpr int RAW_BUF = RAW_DMA * 64 * 4;                    // 5120 floats = 20 KB
+constexpr int RAW_DMA = 21;                                  // DMA instructions of 64 units per chunk tile (1224 units used)
+constexpr int RAW_BUF = 3 * TBW * 4;                         // 6144 floats = 24 KB: 1536 units of 16 bytes, 1224 used
+constexpr uint32_t RAW_BIAS = 4096;                          // see set_fetch_tile
 constexpr uint32_t RAW_OOB = 0x80000000u;                    // buffer offset of a pixel outside the image: beyond num_records -> zeros
 constexpr int NSTEP = 18;                                    // positions per wave
 constexpr int U_STEP = 2 * 2 * 64 * 4;                       // floats of one step in LDS: [rg][cgp][lane][j][ks]
@@ -59,12 +71,19 @@ static_assert(DMA1_PIECES == 5 && DMA2_PIECES == 4, "DMA split");
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// The lane index, re-derived where it is needed (volatile: not hoisted, not kept): the kernel has no register to spare for
+// carrying it - or anything computed from it - through the loop, and a spilled register costs a scratch load AND a vmcnt(0).
+__device__ __forceinline__ int lane_id() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, float k, f32x2 c) { return __builtin_elementwise_fma(a, (f32x2){k, k}, c); }
 
 // float offset of patch pixel (pr, pc) from patch pixel (0, 0) of the same tile in the raw layout (see the kernel)
 __device__ __forceinline__ constexpr int patch_off(int pr, int pc) {
-    return (pr * RAW_COLS + ((pc & 3) == 0 ? 0 : (pc & 3) == 1 ? 9 : (pc & 3) == 2 ? 18 : 26) + (pc >> 2)) * 4;
+    return (pr * RAW_COLS + ((pc & 3) == 0 ? 0 : (pc & 3) == 1 ? 9 : (pc & 3) == 2 ? 18 : 26) + (pc >> 2)) * 8;
 }
 
 // 1-D input transform of F(4,3): y = B^T x, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
@@ -89,8 +108,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) float Xs[XCH];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = (int)uniform((uint32_t)(tid >> 6));
+    const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     const int rg = wave & 1, cgp = (wave >> 1) & 1, tg = wave >> 2;
 
     int t_first, t_step, t_end;
@@ -105,60 +123,133 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     }
     if (t_first >= t_end) return;
 
-    // ---- raw staging by the LDS-DMA path: the chunk tile is 1224 units of 16 bytes (pixel, channel half) = 20 instructions
-    // buffer_load_dwordx4 ... lds of 64 units; wave w issues instructions w, w + 8 and w + 16 (waves 4..7: w + 8 again, so that
+    // ---- raw staging by the LDS-DMA path: the chunk tile is 1224 units of 16 bytes (pixel, channel half) = 21 instructions
+    // buffer_load_dwordx4 ... lds of 64 units; wave w < 7 issues instructions 3 w .. 3 w + 2 (wave 7 repeats wave 6's, so that
     // every wave has the same number of operations in flight).  The LDS side is lane-linear (M0 + 16 lane), the global side a
     // per-lane offset, so the tile's LAYOUT is chosen by which pixel each lane fetches:
-    //     unit(half, row, col) = 612 half + 34 row + COLMAP(col),  COLMAP(col) = {0, 9, 18, 26}[col & 3] + (col >> 2)
-    // i.e. the columns of one residue class mod 4 are consecutive.  A patch read touches, per half wave, the pixels
-    // (R + 4 ty, C + 4 tx) of 16 tiles: units base + tx + 136 ty = 16 distinct residues mod 16, every bank exactly once.
+    //     pixel slot(row, col) = 34 row + COLMAP(col),  COLMAP(col) = {0, 9, 18, 26}[col & 3] + (col >> 2)   (32 bytes per slot)
+    //     unit = 2 slot + (half ^ ((row >> 2) & 1))
+    // i.e. the columns of one residue class mod 4 are consecutive, the two lanes of a pixel fetch 32 contiguous bytes (one
+    // request), and the channel halves are swapped on every other group of four rows.  A patch read touches, per half wave,
+    // channel pairs 0, 1 of the pixels (R + 4 ty, C + 4 tx) of 16 tiles: float offsets 8 tx + 4 ty + 2 q mod 64 - every bank once.
     // Pixels outside the image get an offset beyond the buffer descriptor's range: the hardware writes zeros for them
     // (tools/ubench/buffer_lds_oob.hip), so the zero padding costs no instruction.
+#if W44_RAW_DMA
     uint32_t voff[3];
     i32x4 rsrc;
     auto set_fetch_tile = [&](int t) {
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
-        const uint64_t base = (uint64_t)(x + (int64_t)n * H * W * 64);
+        // the descriptor starts RAW_BIAS bytes BELOW the image: a wave's three instructions differ in their immediate offset
+        // (which the hardware adds to the LDS and to the global address), the per-lane offsets take it back out
+        const uint64_t base = (uint64_t)(x + (int64_t)n * H * W * 64) - RAW_BIAS;
         rsrc.x = (int)uniform((uint32_t)base);
         rsrc.y = (int)uniform((uint32_t)(base >> 32));            // stride 0: raw buffer, offsets in bytes
-        rsrc.z = (int)uniform((uint32_t)(H * W) * 256u);          // num_records = bytes of one image (< 2^32: launcher)
+        rsrc.z = (int)uniform((uint32_t)(H * W) * 256u + RAW_BIAS);   // num_records (< 2^32: launcher)
         rsrc.w = 0x00020000;
         const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;   // image coordinates of staged pixel (0,0)
-        int el = lane;
-        asm volatile("" : "+v"(el));                               // (keeps hipcc from carrying the unit decode through the loop)
+        const int el = lane_id();
+        const int w = wave < 7 ? wave : 6;                         // 21 instructions cover the tile: wave 7 repeats wave 6
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int k = (j == 2 && wave >= 4) ? wave + 8 : wave + 8 * j;
-            const int u = 64 * k + el;
-            const int half = u >= RAW_HALF_U, ru = u - half * RAW_HALF_U;
-            const int row = (ru * 1928) >> 16, cu = ru - row * RAW_COLS;          // ru / 34 for ru < 768
+            const int u = 64 * (3 * w + j) + el, slot = u >> 1;
+            const int row = (slot * 1928) >> 16, cu = slot - row * RAW_COLS;      // slot / 34 for slot < 768
             const int col = cu < 9 ? 4 * cu : (cu < 18 ? 4 * (cu - 9) + 1 : (cu < 26 ? 4 * (cu - 18) + 2 : 4 * (cu - 26) + 3));
+            const int half = (u & 1) ^ ((row >> 2) & 1);
             const int iy = py0 + row, ix = px0 + col;
-            const bool ok = u < 2 * RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            voff[j] = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half : RAW_OOB;
+            const bool ok = slot < RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            voff[j] = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half + (RAW_BIAS - 1024u * j) : RAW_OOB;
         }
     };
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Raw;
-    // chunk c of the fetch tile -> Raw[buf]: the scalar offset selects the 8 channels (32 bytes) of the chunk
+    // chunk c of the fetch tile -> Raw[buf]: the scalar offset selects the 8 channels (32 bytes) of the chunk; ONE M0 value per
+    // wave (writing M0 between two LDS-DMA instructions costs ~100 cycles each: measured)
     auto dma_raw = [&](int c, int buf) {
+        if (W44_ABL & 1) return;
         const uint32_t soff = uniform((uint32_t)c * (CK * 4));
         int w = wave;
-        asm volatile("" : "+s"(w));                                // recompute the M0 values here (scalar ALU is free; SGPRs are not)
+        asm volatile("" : "+s"(w));                                // recompute the M0 value here (scalar ALU is free; SGPRs are not)
+        const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + 3 * (w < 7 ? w : 6) * 1024));
+#if W44_ABL & 512     // timing experiment (borders wrong): the same fetch with global_load_lds instead of buffer_load ... lds
+        {
+            const uint64_t gb = ((uint64_t)(uint32_t)rsrc.y << 32 | (uint32_t)rsrc.x) + soff;
+            const uint64_t gbu = ((uint64_t)uniform((uint32_t)(gb >> 32)) << 32) | uniform((uint32_t)gb);
+            uint32_t va = voff[0] == RAW_OOB ? 4096u : voff[0], vb = voff[1] == RAW_OOB ? 4096u : voff[1] + 1024u, vc = voff[2] == RAW_OOB ? 4096u : voff[2] + 2048u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                         "global_load_lds_dwordx4 %1, %4\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "global_load_lds_dwordx4 %2, %4\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "global_load_lds_dwordx4 %3, %4"
+                         ::"s"(m0v), "v"(va), "v"(vb), "v"(vc), "s"(gbu) : "memory", "m0", "scc");
+            return;
+        }
+#endif
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "buffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
+                     "buffer_load_dwordx4 %2, %4, %5 offen offset:1024 lds\n\t"
+                     "buffer_load_dwordx4 %3, %4, %5 offen offset:2048 lds"
+                     ::"s"(m0v), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff) : "memory", "m0");
+    };
+#else
+    // (register path) thread handles the LDS units tid + 512 k, k = 0..2 (16 bytes each, 1536 >= 1224: the spare ones are written
+    // as zeros): unit u = 2 slot + (half ^ swap(row)) as above, so the two lanes of a pixel fetch 32 contiguous bytes and the LDS
+    // address of a thread's unit is 16 (tid + 512 k) - no address registers.  Which pixel that is, is decoded once per block tile.
+    uint32_t roff[3];
+    bool rok[3];
+    bool border = true;
+    const float* xf = x;
+    auto set_fetch_tile = [&](int t) {
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        xf = x + (int64_t)n * H * W * 64;
+        const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;
+        border = py0 < 0 || px0 < 0 || py0 + RAW_ROWS > H || px0 + RAW_COLS > W;
+        const int el = wave * 64 + lane_id();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = (j == 2 && w >= 4) ? w + 8 : w + 8 * j;
-            const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + k * 1024));
-            if (!(W44_ABL & 1))
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                             ::"s"(m0v), "v"(voff[j]), "s"(rsrc), "s"(soff) : "memory", "m0");
+        for (int k = 0; k < 3; ++k) {
+            const int u = k * TBW + el, slot = u >> 1;
+            const int row = (slot * 1928) >> 16, cu = slot - row * RAW_COLS;      // slot / 34 for slot < 768
+            const int col = cu < 9 ? 4 * cu : (cu < 18 ? 4 * (cu - 9) + 1 : (cu < 26 ? 4 * (cu - 18) + 2 : 4 * (cu - 26) + 3));
+            const int half = (u & 1) ^ ((row >> 2) & 1);
+            const int iy = py0 + row, ix = px0 + col;
+            rok[k] = slot < RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+            roff[k] = ((uint32_t)(cy * W + cx) * 64u + 4u * (uint32_t)half) * 4u;   // < 2^32: H*W < 2^24 (launcher)
+        }
+        if (!border) {                                             // interior tile: only the spare units are not fetched pixels
+#pragma unroll
+            for (int k = 0; k < 3; ++k) rok[k] = k * TBW + el < 2 * RAW_HALF_U;
         }
     };
+    float4 rawv[3];
+    bool rawok[3];
+    auto fetch_raw = [&](int c) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+#if W44_ABL & 2048     // timing experiment: no global fetch at all (stale registers are stored)
+            asm volatile("" : "+v"(rawv[k].x));
+#elif W44_ABL & 1024   // timing experiment: the same fetches folded into 4 KB (cache hits)
+            rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * CK) + (roff[k] & 0xff0u));
+#else
+            rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * CK) + roff[k]);
+#endif
+            rawok[k] = rok[k];
+        }
+    };
+    auto store_raw = [&](int buf) {
+        const int el = wave * 64 + lane_id();
+        float* dst = Raw + buf * RAW_BUF + 4 * el;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            *reinterpret_cast<float4*>(dst + 4 * TBW * k) = rawok[k] ? rawv[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    auto raw_landed = [&]() { asm volatile("" ::"v"(rawv[0].x), "v"(rawv[1].x), "v"(rawv[2].x)); };
+#endif
 
     // ---- weight chunk: host-packed in LDS order; half 1 = bytes [0, 40 KiB), half 2 = [40 KiB, 72 KiB); wave w moves a
     // contiguous share of each half by the LDS-DMA path, pieces of 1 KiB that differ only in their immediate offset
     const uint32_t us_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
-    const uint32_t dma_voff = (uint32_t)(lane * 16);
     auto dma_setup = [&](int c, int half) -> uint64_t {
         int w = wave;
         asm volatile("" : "+s"(w));
@@ -171,31 +262,36 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
 #define W44_DMA(OFF) asm volatile("global_load_lds_dwordx4 %0, %1 offset:" #OFF ::"v"(dma_voff), "s"(dg) : "memory")
     auto dma_half = [&](int c, int half) {
         const uint64_t dg = dma_setup(c, half);
+        const int dl = lane_id();
+        const uint32_t dma_voff = (uint32_t)(dl * 16);
         if (W44_ABL & 2) return;
         W44_DMA(-2048); W44_DMA(-1024); W44_DMA(0); W44_DMA(1024);
         if (half == 0) W44_DMA(2048);
     };
 
     f32x4 acc[NSTEP][2];
+    bool stores_in_flight = false;                            // (uniform) the previous tile's epilogue issued exactly 16 stores per wave
 
     // MFMA roles: lane (i = lane&15, q = lane>>4) owns tile 16 tg + i and channels {2q, 2q+1} of the chunk
-    const int mi = lane & 15, mq = lane >> 4;
-    const int ty = mi >> 3, tx = mi & 7;
-    // float offset of channel pair mq of patch pixel (0,0) of the lane's tile in a raw buffer; patch pixel (pr, pc) is a constant away
-    const int pbase = ((mq >> 1) * RAW_HALF_U + 4 * (2 * tg + ty) * RAW_COLS + tx) * 4 + 2 * (mq & 1);
-    const float* ub = Us + ((rg * 2 + cgp) * 64 + lane) * 4;
-
     f32x2 v[NSTEP];
     // V = B^T d B, rows [3 rg, 3 rg + 3) only
-    auto transform = [&](int buf) __attribute__((always_inline)) {
+    auto transform = [&](auto rg_c, int buf) __attribute__((always_inline)) {
+        constexpr int RG = decltype(rg_c)::value;
         const float* pp = Raw + buf * RAW_BUF;
+        // float offset of channel pair q of patch pixel (0,0) of the lane's tile in a raw buffer; patch pixel (pr, pc) is a constant
+        // away, with the channel halves the other way round in patch rows 4, 5 (they belong to the next group of four pixel rows).
+        // Recomputed here from an opaque copy of the lane index instead of being carried through the loop.
+        const int tl = lane_id();
+        const int q_ = tl >> 4, ty_ = (tl >> 3) & 1, tx_ = tl & 7;
+        const int pbase0 = (4 * (2 * tg + ty_) * RAW_COLS + tx_) * 8 + 2 * (q_ & 1);
+        const int pbaseA = pbase0 + 4 * ((q_ >> 1) ^ ty_), pbaseB = pbase0 + 4 * ((q_ >> 1) ^ ty_ ^ 1);
         f32x2 t[3][6];
-        if (rg == 0) {
+        if (RG == 0) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 f32x2 d[6];
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) d[pr] = *reinterpret_cast<const f32x2*>(pp + pbase + patch_off(pr, j));
+                for (int pr = 0; pr < 6; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
                 bt_lo(d, t[0][j], t[1][j], t[2][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -204,7 +300,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             for (int j = 0; j < 6; ++j) {
                 f32x2 d[6];
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) d[pr] = *reinterpret_cast<const f32x2*>(pp + pbase + patch_off(pr, j));
+                for (int pr = 0; pr < 6; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
                 bt_hi(d, t[0][j], t[1][j], t[2][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -220,21 +316,23 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // three rows of M: W = M A (3 x 4), then the partial A^T W over its rows (4 x 4); rg 0 finishes output rows 0, 1 and rg 1
     // rows 2, 3, the other two rows of the partial go to the partner wave (wave ^ 1) through Xs.  The bias is already inside:
     // position (1,1) has coefficient 1 in all 16 outputs and its accumulator (rg 0, step 7) starts from the bias.
-    auto epilogue = [&](int t) __attribute__((always_inline)) {
+    auto epilogue = [&](auto rg_c, int t) __attribute__((always_inline)) {
+        constexpr int RG = decltype(rg_c)::value;
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         float* yn = y + (int64_t)n * H * W * 64;
+        stores_in_flight = OUT_ROWS * (by + 1) <= H && OUT_COLS * (bx + 1) <= W;   // every lane stores all 16 values: 16 operations in flight
         // every lane-dependent address of the epilogue is derived from an opaque copy of the lane index: hipcc would otherwise
         // hoist them out of the persistent loop and keep a dozen registers alive through the MFMA stages (= spills there)
-        int el = lane;
-        asm volatile("" : "+v"(el));
+        const int el = lane_id();
         const int ei = el & 15, eq = el >> 4;
-        const int oy = OUT_ROWS * by + 4 * (2 * tg + (ei >> 3)) + 2 * rg, ox = OUT_COLS * bx + 4 * (ei & 7);
+        const int oy = OUT_ROWS * by + 4 * (2 * tg + (ei >> 3)) + 2 * RG, ox = OUT_COLS * bx + 4 * (ei & 7);
         float* o = yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
         float* xw = Xs + (wave * 4 * 64 + el) * 4;
         const float* xr = Xs + ((wave ^ 1) * 4 * 64 + el) * 4;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+            f32x2 keep[8];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 Wm[3][4];
@@ -250,7 +348,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                     Wm[rr][3] = fma2(d, 8.0f, b) + m[5];
                 }
                 f32x2 mine[8], send[8];
-                if (rg == 0) {
+                if (RG == 0) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const f32x2 s = Wm[1][c] + Wm[2][c], dd = Wm[1][c] - Wm[2][c];
@@ -269,6 +367,10 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                         mine[4 + c] = fma2(dd, 8.0f, Wm[2][c]);
                     }
                 }
+#if W44_ABL & 8192     // timing experiment: no exchange
+#pragma unroll
+                for (int q = 0; q < 8; ++q) mine[q] += send[q];
+#else
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     *reinterpret_cast<f32x4*>(xw + q * 256) = (f32x4){send[2 * q].x, send[2 * q].y, send[2 * q + 1].x, send[2 * q + 1].y};
@@ -280,31 +382,36 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                     mine[2 * q + 1] += (f32x2){got.z, got.w};
                 }
                 if (!(j == 1 && h == 1)) lds_barrier();               // the partner has read before the next round overwrites
+#endif
+                if (h == 0) {
 #pragma unroll
-                for (int rr = 0; rr < 2; ++rr)
+                    for (int e = 0; e < 8; ++e) keep[e] = mine[e];
+                } else {
+                    // 16-byte stores: the four lanes of a pixel (mq) write 64 contiguous bytes.  (8-byte stores of each half
+                    // as soon as it is ready were measured at +115 us per launch: half-sector writes.)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        f32x2 val = mine[rr * 4 + c];
-                        if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); }
-                        if (!(W44_ABL & 4) && oy + rr < H && ox + c < W)
-                            *reinterpret_cast<f32x2*>(o + 16 * j + 2 * h + ((int64_t)rr * W + c) * 64) = val;
-                    }
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            f32x4 val = {keep[rr * 4 + c].x, keep[rr * 4 + c].y, mine[rr * 4 + c].x, mine[rr * 4 + c].y};
+                            if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
+                            if (!(W44_ABL & 4) && (!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)   // (4096: timing experiment, never stores)
+                                *reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64) = val;
+                        }
+                }
             }
         }
     };
 
-    // ---- prologue (once per workgroup): bias, U(0) whole, raw(0), raw(1) staged; V(0) computed; raw(2) on its way
-    if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.0f;
-    set_fetch_tile(t_first);
-    dma_half(0, 0);
-    dma_half(0, 1);
-    dma_raw(0, 0);
-    dma_raw(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    transform(0);
-    __syncthreads();                                          // everyone has read raw(0): the fetch of raw(2) may overwrite it
-    dma_raw(2, 0);
+#ifdef W44_STAMP   // profiling build: cycles per phase, summed over the run, written over the bias array: [workgroup][wave][5]
+    uint32_t st_sum[5] = {0, 0, 0, 0, 0};
+    uint64_t st_t = __builtin_readcyclecounter();
+#define W44_MARK(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(now_ - st_t); st_t = now_; } while (0)
+    uint32_t* st_out = reinterpret_cast<uint32_t*>(const_cast<float*>(bias));
+    bias = nullptr;
+#else
+#define W44_MARK(i) do { } while (0)
+#endif
     int t_fetch = t_first;
 
     // One stage = chunk c of the current tile.  PAR = c&1: Raw[PAR^1] holds raw(c+1), Raw[PAR] is receiving raw(c+2).
@@ -312,31 +419,43 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // x3]; behind X1 [first half of U(c+1) x5].  vmcnt(3) in front of X1 = the weights are in (the raw tile may still be
     // landing: it is needed after X1 of the NEXT stage), vmcnt(0) in front of X2.  (Register spills would be scratch = vector
     // memory operations in between: the loop must compile without any.)
-    auto stage = [&](auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
+    auto stage = [&](auto rg_c, auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
+        constexpr int RG = decltype(rg_c)::value;
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         // entry: Us = U(c) (steps >= SPLIT still landing), Raw[PAR^1] = raw(c+1) visible, v = V(c), raw(c+2) landing in Raw[PAR]
         f32x4 init7[2];
         if (FIRST) {
-            int el = lane;
-            asm volatile("" : "+v"(el));                      // (address computed here, not carried through the loop)
+            const int el = lane_id();
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + 32 * cgp + 16 * j + 4 * (el >> 4));
-                init7[j] = rg == 0 ? bv : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+                init7[j] = RG == 0 ? bv : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
-        constexpr int PF = 2;
+        constexpr int PF = W44_PF;
         float4 bq[PF + 1];
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int sl = lane_id();
+        const float* ub = Us + ((RG * 2 + cgp) * 64 + sl) * 4;
+        // The MFMAs are inline asm with the accumulator tied to its own registers: left to itself hipcc allocates many of them
+        // out of place (a copy chain through spare registers) and runs out of registers.  Hazards: an accumulator is touched by
+        // every second MFMA (64 cycles apart) and read by vector code only in the epilogue, behind a barrier.
+#define W44_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define W44_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "v"(B))
 #define W44_STEP(S)                                                                                                                   \
         {                                                                                                                             \
             const float4 b = bq[(S) % (PF + 1)];                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                        \
-            acc[S][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[S].x, FIRST ? ((S) == 7 ? init7[0] : zero) : acc[S][0], 0, 0, 0); \
-            acc[S][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, v[S].x, FIRST ? ((S) == 7 ? init7[1] : zero) : acc[S][1], 0, 0, 0); \
-            acc[S][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, v[S].y, acc[S][0], 0, 0, 0);                                        \
-            acc[S][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, v[S].y, acc[S][1], 0, 0, 0);                                        \
+            if (FIRST && (S) != 7) {                                                                                                  \
+                W44_MFMA0(acc[S][0], b.x, v[S].x);                                                                                    \
+                W44_MFMA0(acc[S][1], b.z, v[S].x);                                                                                    \
+            } else {                                                                                                                  \
+                if (FIRST) { acc[S][0] = init7[0]; acc[S][1] = init7[1]; }                                                            \
+                W44_MFMA(acc[S][0], b.x, v[S].x);                                                                                     \
+                W44_MFMA(acc[S][1], b.z, v[S].x);                                                                                     \
+            }                                                                                                                         \
+            W44_MFMA(acc[S][0], b.y, v[S].y);                                                                                         \
+            W44_MFMA(acc[S][1], b.w, v[S].y);                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                                        \
         }
         // ---- first part: steps [0, SPLIT)
@@ -348,8 +467,32 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             if (s + PF < SPLIT) bq[(s + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (s + PF) * U_STEP);
             W44_STEP(s);
         }
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");      // second half of U(c) in LDS
+        W44_MARK(0);                                          // first MFMA part
+#if W44_RAW_DMA && W44_RAWPOS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        // second half of U(c) in LDS; the raw fetch (3 operations, issued behind it) stays in flight.  Behind a tile that lies
+        // inside the image the 16 output stores of its epilogue (issued behind the weights too) may stay in flight as well:
+        // waiting for their acknowledgements here was measured at ~50 us per launch.
+#if W44_RAW_DMA
+        if (FIRST) { if (stores_in_flight) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#else
+        if (FIRST && stores_in_flight) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+#endif
         lds_barrier();                                        // X1: steps >= SPLIT of U(c) visible; everyone is done with steps < SPLIT
+        W44_MARK(1);                                          // wait + X1
+#if W44_RAW_DMA && !W44_RAWPOS
+        if (FIRST && t_cur != t_first) dma_raw(2, 0);         // (held back behind the previous tile's last transform: see the end of the stage)
+#endif
+#if W44_RAW_DMA && W44_RAWPOS
+        if (c == 6) {                                         // chunks c+2.. of the fetch stream belong to the next tile
+            if (t_fetch + t_step < t_end) t_fetch += t_step;
+            set_fetch_tile(t_fetch);
+        }
+        dma_raw((c + 2) & 7, PAR);
+#endif
         dma_half((c + 1) & 7, 0);
         // ---- second part: steps [SPLIT, 18)
 #pragma unroll
@@ -361,30 +504,100 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             W44_STEP(s);
         }
         __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise starts the transform above the MFMAs that still read v)
-        transform(PAR ^ 1);                                   // V(c+1)
+#if !W44_RAW_DMA
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // raw(c+2) is in registers (the first half of U(c+1) may still be landing)
+        raw_landed();
+        store_raw(PAR);
         __builtin_amdgcn_sched_barrier(0);
+#endif
+        // (the last stage of a tile transforms BEHIND the epilogue: V would otherwise be live across it, 36 registers too many)
+        if (!(W44_ABL & 16) && c != 7) transform(rg_c, PAR ^ 1);    // V(c+1)
+        __builtin_amdgcn_sched_barrier(0);
+        W44_MARK(2);                                          // second MFMA part + transform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // first half of U(c+1) and raw(c+2) are in LDS
-        lds_barrier();                                        // X2: both visible; everyone is done with U(c) and raw(c+1)
-        if (c == 7) epilogue(t_cur);                          // (its stores first: older than the DMA, they never hold vmcnt(3) up)
+        lds_barrier();
+        W44_MARK(3);                                          // wait + X2                                        // X2: both visible; everyone is done with U(c) and raw(c+1)
+        dma_half((c + 1) & 7, 1);                             // (in front of the epilogue's stores: see the wait in front of X1)
+        if (c == 7) {
+            if (!(W44_ABL & 32)) epilogue(rg_c, t_cur);
+#if W44_ABL & 32      // timing experiment: no output transform; one dependent store keeps the accumulators alive
+            else {
+                float sacc = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NSTEP; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                y[(int64_t)t_cur * TBW + wave * 64 + lane_id()] = sacc;
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(W44_ABL & 16)) transform(rg_c, PAR ^ 1);   // V(0) of the next tile: the raw buffer is rewritten behind X1 of its stage 0 at the earliest
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#if !(W44_RAW_DMA && W44_RAWPOS)
         if (c == 5) {                                         // chunks c+3.. of the fetch stream belong to the next tile
             if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
             set_fetch_tile(t_fetch);
         }
-        dma_half((c + 1) & 7, 1);
-        dma_raw((c + 3) & 7, PAR ^ 1);                        // raw(c+3) into the buffer raw(c+1) has just been read from
+#endif
+#if W44_RAW_DMA
+        // raw(c+3) into the buffer raw(c+1) has just been read from - except behind the last stage of a tile, whose transform
+        // (behind the epilogue) may still be reading it in a slower wave: that fetch is issued behind X1 of the next stage
+        if (c != 7) dma_raw((c + 3) & 7, PAR ^ 1);
+#else
+        fetch_raw((c + 3) & 7);                               // raw(c+3): stored into that buffer behind the MFMAs of the next stage
+#endif
     };
     using std::integral_constant;
+    // the two row groups run two separate copies of prologue + loop: with `rg` a run-time value hipcc keeps both arms of every
+    // rg-dependent piece (input transform, output transform) live at once, and whatever is computed in front of the two copies
+    // is kept alive THROUGH the first copy for the second one - either way it spills
+    auto run = [&](auto rg_c) __attribute__((always_inline)) {
+        // ---- prologue (once per workgroup): bias, U(0) whole, raw(0), raw(1) staged; V(0) computed; raw(2) on its way
+        if (wave == 0) { const int bl = lane_id(); bias_s[bl] = bias ? bias[bl] : 0.0f; }
+        set_fetch_tile(t_first);
+        dma_half(0, 0);
+        dma_half(0, 1);
+#if W44_RAW_DMA
+        dma_raw(0, 0);
+        dma_raw(1, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        transform(rg_c, 0);
+        __syncthreads();                                          // everyone has read raw(0): the fetch of raw(2) may overwrite it
+#if !W44_RAWPOS
+        dma_raw(2, 0);
+#endif
+#else
+        fetch_raw(0);
+        store_raw(0);
+        fetch_raw(1);
+        store_raw(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_landed();
+        __syncthreads();
+        transform(rg_c, 0);
+        __syncthreads();
+        fetch_raw(2);                                             // stored to Raw[0] during stage 0
+#endif
 #pragma unroll 1
-    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
-        stage(integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
-        stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, 1, t_cur);
+        for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+            stage(rg_c, integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
+            stage(rg_c, integral_constant<int, 1>{}, integral_constant<bool, false>{}, 1, t_cur);
 #pragma unroll 1
-        for (int c = 2; c < NCHUNK; c += 2) {
-            stage(integral_constant<int, 0>{}, integral_constant<bool, false>{}, c, t_cur);
-            stage(integral_constant<int, 1>{}, integral_constant<bool, false>{}, c + 1, t_cur);
+            for (int c = 2; c < NCHUNK; c += 2) {
+                stage(rg_c, integral_constant<int, 0>{}, integral_constant<bool, false>{}, c, t_cur);
+                stage(rg_c, integral_constant<int, 1>{}, integral_constant<bool, false>{}, c + 1, t_cur);
+            }
         }
-    }
+    };
+    if (rg == 0) run(integral_constant<int, 0>{}); else run(integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef W44_STAMP
+    W44_MARK(4);                                              // (everything else: epilogue, DMA issue, tile switch)
+    if (lane_id() == 0)
+        for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
+#endif
 }
 
 }  // namespace w44

@@ -65,10 +65,15 @@ def timeit():
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
     b = torch.randn(64, device="cuda", generator=g)
-    for shape in ((64, 128, 128), (8, 128, 128), (32, 128, 128), (8, 256, 256)):
+    shapes = ((64, 128, 128), (8, 128, 128), (32, 128, 128), (8, 256, 256))
+    for shape in shapes[:int(os.environ.get("W44_SHAPES", "4"))]:
         x = torch.randn(shape[0], 64, shape[1], shape[2], device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+        if os.environ.get("W44_ZERO_X"):                 # power experiment: all-zero activations
+            x.zero_()
         out = torch.empty_like(x)
         fns = {"f22": (lambda: _hip.conv3x3_c64_winograd(x, U2, b, True, out=out)), "f44": (lambda: _hip.conv3x3_c64_winograd44(x, U4, b, True, out=out))}
+        if os.environ.get("W44_LIB"):
+            fns.pop("f22")
         U2, U4 = _hip.pack_winograd_weights(w), _hip.pack_winograd44_weights(w)
         res = {k: [] for k in fns}
         for rnd in range(9):
@@ -82,7 +87,7 @@ def timeit():
                 e1.record()
                 torch.cuda.synchronize()
                 res[k].append(e0.elapsed_time(e1) / 20 * 1e3)
-        print(json.dumps({"shape": shape, **{k + "_us": round(statistics.median(v), 1) for k, v in res.items()}}), flush=True)
+        print(json.dumps({"lib": os.environ.get("W44_LIB", "product"), "shape": shape, **{k + "_us": round(statistics.median(v), 1) for k, v in res.items()}}), flush=True)
 
 
 if __name__ == "__main__":
