@@ -228,14 +228,15 @@ def run_rank(args):
                 return orig(ws, beta, n, *a)
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
-        orig_wg = _hip.conv3x3_c64_winograd
+        orig_wg = _hip.conv3x3_c64
 
-        def timed_winograd(x, U, bias=None, relu=True, out=None):
+        def timed_conv64(x, weights, bias=None, relu=True, out=None):
             if not timing_on[0] or conv_timer.full:
-                return orig_wg(x, U, bias, relu, out)
-            conv_shape[:] = [x.shape[0], x.shape[2], x.shape[3]]
-            return conv_timer.winograd(x, U, bias, relu, out)
-        _hip.conv3x3_c64_winograd = timed_winograd
+                return orig_wg(x, weights, bias, relu, out)
+            o, kind = conv_timer.conv64(x, weights, bias, relu, out)
+            conv_shape[:] = [x.shape[0], x.shape[2], x.shape[3], kind]
+            return o
+        _hip.conv3x3_c64 = timed_conv64
 
     def fence():
         if world > 1:
@@ -308,25 +309,29 @@ def run_rank(args):
         cms = conv_timer.durations_ms() if timing else []
         if cms:
             # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call).
-            # Algorithmic flops per launch = the MFMA flops of the Winograd F(2x2,3x3) form = direct flops / 2.25,
-            # against the dense fp32 MFMA peak; "hbm_roofline" is the fused streaming kernel of the DEQ loop itself.
-            nimg, ch, cw = conv_shape
+            # Algorithmic flops per launch = the MFMA flops of the Winograd form the launcher picked: direct flops / 4 for
+            # F(4x4,3x3) (36 products per 16 outputs), / 2.25 for F(2x2,3x3), against the dense fp32 MFMA peak;
+            # "hbm_roofline" is the fused streaming kernel of the DEQ loop itself.
+            nimg, ch, cw, kind = conv_shape
+            red = 4.0 if kind == "f44" else 2.25
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
             cavg = 1e-3 * sum(cms) / len(cms)
             n_conv = 13 if args.denoiser == "ffdnet" else 2       # 64->64 layers per denoiser call (models.py:53-58 / SimpleCNN_models.py:47-53)
             share = cavg * n_conv * f_calls / (elapsed / args.steps)
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            for wname in ("r02_pmc_winograd.json", "r01_pmc_winograd.json"):
+            for wname in (("r02_pmc_winograd44.json",) if kind == "f44" else ("r02_pmc_winograd.json", "r01_pmc_winograd.json")):
                 wfile = os.path.join(ROOT, "profiles", wname)
                 if wtraffic is None and os.path.exists(wfile):
                     with open(wfile) as fh:
                         rec = json.load(fh)
                     if rec.get("shape") == [nimg, 64, ch, cw]:
                         wtraffic = rec["hbm_bytes_per_launch"]
-            out["roofline"] = {"kernel": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)",
-                               "bound": "mfma", "achieved": direct / 2.25 / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": direct / 2.25 / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
-                               "algorithmic_flops_per_launch": direct / 2.25, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
+            kname = ("deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)" if kind == "f44" else
+                     "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)")
+            out["roofline"] = {"kernel": kname,
+                               "bound": "mfma", "achieved": direct / red / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
+                               "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
                                "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3)}
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]

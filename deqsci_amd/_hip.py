@@ -425,6 +425,45 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None):
     return o
 
 
+class Conv64Weights:
+    """The transformed weights of one 64->64 layer for both Winograd kernels."""
+    __slots__ = ("f22", "f44")
+
+    def __init__(self, w):
+        self.f22 = pack_winograd_weights(w)
+        self.f44 = pack_winograd44_weights(w)
+
+
+def pack_conv64_weights(w):
+    return Conv64Weights(w)
+
+
+# launch time of one block tile per CU, us (tools/w44_check.py, profiles/r02_w44_shapes.jsonl): F(4x4,3x3) does 2x the pixels per tile
+_T_TILE_F22, _T_TILE_F44 = 21.5, 35.5
+
+
+FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44": A/B runs and tests; default: the faster one per launch
+
+
+def conv64_kernel_for(n, H, W, device=None):
+    """'f44' or 'f22': the faster kernel for n images of H x W.  Both run one persistent workgroup per CU over block tiles of 16 x 16
+    (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3)) output pixels, so the time is (waves of block tiles) x (time of a tile)."""
+    if FORCE_CONV64 in ("f22", "f44"):
+        return FORCE_CONV64
+    cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    t22 = -(-(n * (-(-H // 16)) * (-(-W // 16))) // cus) * _T_TILE_F22
+    t44 = -(-(n * (-(-H // 16)) * (-(-W // 32))) // cus) * _T_TILE_F44
+    return "f44" if t44 < t22 else "f22"
+
+
+def conv3x3_c64(x, weights, bias=None, relu=True, out=None):
+    """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer with the faster of the two Winograd kernels (`weights` =
+    pack_conv64_weights(w))."""
+    if conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device) == "f44":
+        return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out)
+    return conv3x3_c64_winograd(x, weights.f22, bias, relu, out)
+
+
 # ----------------------------------------------------------------------------- measurement helpers (bench.py)
 class KernelTimer:
     """Per-launch kernel durations from the dispatch's own start/stop timestamps (the *_timed_f32 entry points record
@@ -478,6 +517,21 @@ class KernelTimer:
                                                                 o.data_ptr(), n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]),
                    "conv3x3_c64_winograd_timed")
         return o
+
+    def conv64(self, x, weights, bias=None, relu=True, out=None):
+        """The timed counterpart of conv3x3_c64; returns (output, 'f22' | 'f44')."""
+        kind = conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device)
+        ev = self._pair()
+        if ev is None:
+            return conv3x3_c64(x, weights, bias, relu, out), kind
+        n, c, H, W = x.shape
+        o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+        fn = load().deqsci_conv3x3_c64_winograd44_timed_f32 if kind == "f44" else load().deqsci_conv3x3_c64_winograd_timed_f32
+        u = weights.f44 if kind == "f44" else weights.f22
+        with _dev(x):
+            _check(fn(x.data_ptr(), _p(u, "u_packed"), _p(bias, "bias", True), o.data_ptr(), n, H, W, 1 if relu else 0, _stream(),
+                      ev[0], ev[1]), "conv3x3_c64_timed")
+        return o, kind
 
     def durations_ms(self):
         out = []

@@ -258,6 +258,8 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
     // bias instead of zero.  All arithmetic on register PAIRS (v_pk_add_f32): non-MFMA vector instructions are what
     // bounds this kernel once the matrix pipe is fed (tools/ubench/mfma_valu_mix.hip).
     // D layout of the 16x16 MFMA with the weights as A operand: col = lane&15 (tile), row = 4*(lane>>4) + reg (cout)
+    // (stores are non-temporal: a layer's output is read again only by the next launch, and kept in L2 it evicts the input
+    // lines this launch re-reads for every cin chunk: -3 % here, -9 % in the F(4x4,3x3) kernel)
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int n = wg_div(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = wg_div(r, mg_tx, sh_tx), bx = r - by * tiles_x;
@@ -295,11 +297,11 @@ __global__ __launch_bounds__(WG_TB, 2) void winograd_conv64_kernel(const float* 
             }
             if (in0) {
                 float* oj = o + 16 * j;
-                st4(oj, make_float4(o00[0][0], o00[0][1], o00[1][0], o00[1][1]));
-                if (inx) st4(oj + 64, make_float4(o01[0][0], o01[0][1], o01[1][0], o01[1][1]));
+                st4s(oj, make_float4(o00[0][0], o00[0][1], o00[1][0], o00[1][1]));
+                if (inx) st4s(oj + 64, make_float4(o01[0][0], o01[0][1], o01[1][0], o01[1][1]));
                 if (iny) {
-                    st4(oj + (int64_t)W * 64, make_float4(o10[0][0], o10[0][1], o10[1][0], o10[1][1]));
-                    if (inx) st4(oj + (int64_t)W * 64 + 64, make_float4(o11[0][0], o11[0][1], o11[1][0], o11[1][1]));
+                    st4s(oj + (int64_t)W * 64, make_float4(o10[0][0], o10[0][1], o10[1][0], o10[1][1]));
+                    if (inx) st4s(oj + (int64_t)W * 64 + 64, make_float4(o11[0][0], o11[0][1], o11[1][0], o11[1][1]));
                 }
             }
         }

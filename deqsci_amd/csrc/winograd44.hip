@@ -35,6 +35,9 @@
 #ifndef W44_RAWPOS
 #define W44_RAWPOS 0  // experiment: 1 = raw DMA issued behind X1 (one chunk later) instead of behind X2
 #endif
+#ifndef W44_NT_STORE
+#define W44_NT_STORE 1
+#endif
 #ifndef W44_PF
 #define W44_PF 2      // weight operands are read this many positions ahead
 #endif
@@ -57,7 +60,7 @@ constexpr int OUT_ROWS = 4 * TILE_ROWS, OUT_COLS = 4 * TILE_COLS;
 constexpr int RAW_ROWS = OUT_ROWS + 2, RAW_COLS = OUT_COLS + 2;              // 18 x 34 staged pixels
 constexpr int RAW_HALF_U = RAW_ROWS * RAW_COLS;              // 612 units of 16 bytes per channel half
 constexpr int RAW_DMA = 21;                                  // DMA instructions of 64 units per chunk tile (1224 units used)
-constexpr int RAW_BUF = 3 * TBW * 4;                         // 6144 floats = 24 KB: 1536 units of 16 bytes, 1224 used
+constexpr int RAW_BUF = W44_RAW_DMA ? RAW_DMA * 64 * 4 : 3 * TBW * 4;   // floats: 21 KB (21 DMA instructions of 64 units) / 24 KB (1536 units); 1224 used
 constexpr uint32_t RAW_BIAS = 4096;                          // see set_fetch_tile
 constexpr uint32_t RAW_OOB = 0x80000000u;                    // buffer offset of a pixel outside the image: beyond num_records -> zeros
 constexpr int NSTEP = 18;                                    // positions per wave
@@ -108,6 +111,9 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) float Xs[XCH];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
+#if W44_RAW_DMA
+    __shared__ uint32_t Voff[3 * TBW];
+#endif
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     const int rg = wave & 1, cgp = (wave >> 1) & 1, tg = wave >> 2;
 
@@ -135,7 +141,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // Pixels outside the image get an offset beyond the buffer descriptor's range: the hardware writes zeros for them
     // (tools/ubench/buffer_lds_oob.hip), so the zero padding costs no instruction.
 #if W44_RAW_DMA
-    uint32_t voff[3];
+    // (the three per-lane buffer offsets of a block tile live in LDS, not in registers: the kernel has none to spare, and a
+    // spilled register costs a scratch load AND an s_waitcnt vmcnt(0) - measured at ~80 us per launch)
     i32x4 rsrc;
     auto set_fetch_tile = [&](int t) {
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
@@ -158,7 +165,11 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             const int half = (u & 1) ^ ((row >> 2) & 1);
             const int iy = py0 + row, ix = px0 + col;
             const bool ok = slot < RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            voff[j] = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half + (RAW_BIAS - 1024u * j) : RAW_OOB;
+            uint32_t vo = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half + (RAW_BIAS - 1024u * j) : RAW_OOB;
+#if W44_ABL & 128     // timing experiment (wrong results): the same scatter pattern, folded into the first 64 KB of the image (cache hits)
+            vo = ok ? vo & 0xffffu : RAW_OOB;
+#endif
+            Voff[j * TBW + wave * 64 + el] = vo;
         }
     };
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Raw;
@@ -170,26 +181,13 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         int w = wave;
         asm volatile("" : "+s"(w));                                // recompute the M0 value here (scalar ALU is free; SGPRs are not)
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + 3 * (w < 7 ? w : 6) * 1024));
-#if W44_ABL & 512     // timing experiment (borders wrong): the same fetch with global_load_lds instead of buffer_load ... lds
-        {
-            const uint64_t gb = ((uint64_t)(uint32_t)rsrc.y << 32 | (uint32_t)rsrc.x) + soff;
-            const uint64_t gbu = ((uint64_t)uniform((uint32_t)(gb >> 32)) << 32) | uniform((uint32_t)gb);
-            uint32_t va = voff[0] == RAW_OOB ? 4096u : voff[0], vb = voff[1] == RAW_OOB ? 4096u : voff[1] + 1024u, vc = voff[2] == RAW_OOB ? 4096u : voff[2] + 2048u;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                         "global_load_lds_dwordx4 %1, %4\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\t"
-                         "global_load_lds_dwordx4 %2, %4\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\t"
-                         "global_load_lds_dwordx4 %3, %4"
-                         ::"s"(m0v), "v"(va), "v"(vb), "v"(vc), "s"(gbu) : "memory", "m0", "scc");
-            return;
-        }
-#endif
+        const int vl = w * 64 + lane_id();
+        const uint32_t v0 = Voff[vl], v1 = Voff[TBW + vl], v2 = Voff[2 * TBW + vl];
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                      "buffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
                      "buffer_load_dwordx4 %2, %4, %5 offen offset:1024 lds\n\t"
                      "buffer_load_dwordx4 %3, %4, %5 offen offset:2048 lds"
-                     ::"s"(m0v), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rsrc), "s"(soff) : "memory", "m0");
+                     ::"s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(rsrc), "s"(soff) : "memory", "m0");
     };
 #else
     // (register path) thread handles the LDS units tid + 512 k, k = 0..2 (16 bytes each, 1536 >= 1224: the spare ones are written
@@ -396,7 +394,11 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                             f32x4 val = {keep[rr * 4 + c].x, keep[rr * 4 + c].y, mine[rr * 4 + c].x, mine[rr * 4 + c].y};
                             if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
                             if (!(W44_ABL & 4) && (!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)   // (4096: timing experiment, never stores)
+#if W44_NT_STORE
+                                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64));
+#else
                                 *reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64) = val;
+#endif
                         }
                 }
             }

@@ -123,8 +123,9 @@ class _Denoiser:
                 w = w.contiguous(memory_format=torch.channels_last) if self.channels_last else w.contiguous()
                 layers.append((w, b, relu))
             self.fast = layers
-            # 64->64 layers: Winograd F(2x2,3x3) on the fp32 matrix cores with bias+ReLU fused (csrc/winograd.hip)
-            self.wino = [(_hip.pack_winograd_weights(w) if (self.winograd and self.channels_last and w.is_cuda
+            # 64->64 layers: Winograd on the fp32 matrix cores with bias+ReLU fused: F(4x4,3x3) (csrc/winograd44.hip) when the
+            # launch has more than a wave of block tiles, F(2x2,3x3) (csrc/winograd.hip) below that - _hip.conv3x3_c64 picks
+            self.wino = [(_hip.pack_conv64_weights(w) if (self.winograd and self.channels_last and w.is_cuda
                                                              and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
             self.tail_w = self.head_w = None
@@ -165,7 +166,7 @@ class _Denoiser:
         for i in idx:
             w, b, relu = self.fast[i]
             if self.wino[i] is not None and h.is_cuda and h.is_contiguous(memory_format=torch.channels_last):
-                h = _hip.conv3x3_c64_winograd(h, self.wino[i], b, relu)
+                h = _hip.conv3x3_c64(h, self.wino[i], b, relu)
             elif fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)

@@ -51,6 +51,12 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_conv3x3_c64_winograd_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4      # in place
     assert lib.deqsci_conv3x3_c64_winograd_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
     assert lib.deqsci_conv3x3_c64_winograd_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
+    # the F(4x4,3x3) entry point has the same contract
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 1, 4096, 4096, 1, None) == -4
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4    # in place
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 0, 16, 16, 1, None) == -2
 
 
 def test_gfx950_code_object_present():

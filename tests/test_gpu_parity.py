@@ -555,6 +555,42 @@ def test_winograd_conv64_vs_torch(shape):
     assert float((got2.double() - want2).norm() / want2.norm()) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 32), (8, 128, 128), (3, 40, 56), (1, 18, 14), (2, 17, 23), (1, 1, 1), (70, 64, 80), (33, 50, 46),
+                                   (300, 16, 16), (2, 250, 130)])
+def test_winograd44_conv64_vs_torch(shape):
+    """Winograd F(4x4,3x3) MFMA conv 64->64 (+bias+ReLU) vs conv2d in fp64: random asymmetric weights, block tiles that
+    stick out of the image on every side (tiles are 16 x 32 outputs), single block tiles and runs of many per workgroup
+    crossing image boundaries, with and without bias/ReLU.  Bound: 4e-6 (measured 1.2-1.7e-6; F(2x2,3x3): 2e-7, direct fp32: 3e-7)."""
+    import torch.nn.functional as Fn
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(n, 64, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05
+    b = torch.randn(64, device=DEV, generator=g)
+    U = _hip.pack_winograd44_weights(w)
+    ref = Fn.conv2d(x.double(), w.double(), padding=1)
+    out = torch.full_like(x, float("nan"))
+    got = _hip.conv3x3_c64_winograd44(x, U, None, relu=False, out=out)
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape
+    assert float((got.double() - ref).norm() / ref.norm()) < 4e-6
+    got2 = _hip.conv3x3_c64_winograd44(x, U, b, relu=True)
+    want2 = torch.relu(ref + b.double().view(1, -1, 1, 1))
+    assert float((got2.double() - want2).norm() / want2.norm()) < 4e-6
+    # repeated launches on one stream (the persistent pipeline leaves nothing behind) and the selecting front end
+    got3 = _hip.conv3x3_c64(x, _hip.pack_conv64_weights(w), b, relu=True)
+    assert float((got3.double() - want2).norm() / want2.norm()) < 4e-6
+    assert torch.equal(_hip.conv3x3_c64_winograd44(x, U, b, relu=True), got2)
+
+
+def test_conv64_front_end_picks_the_faster_kernel():
+    """More than one wave of F(2x2,3x3) block tiles -> F(4x4,3x3) (measured: profiles/r02_w44_shapes.jsonl)."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert cus == 256
+    assert _hip.conv64_kernel_for(8, 128, 128) == "f44" and _hip.conv64_kernel_for(64, 128, 128) == "f44"
+    assert _hip.conv64_kernel_for(1, 128, 128) == "f22" and _hip.conv64_kernel_for(4, 128, 128) == "f22"
+    assert _hip.conv64_kernel_for(2, 256, 256) == "f44" and _hip.conv64_kernel_for(1, 256, 256) == "f22"
+
+
 @pytest.mark.parametrize("shape", [(2, 40, 24), (1, 256, 256), (3, 33, 70)])
 def test_plain_edge_kernels_vs_torch(shape):
     """conv3x3 1->64 (+ReLU) planar -> channels_last and conv3x3 64->1 channels_last -> planar (SimpleCNN edges)."""

@@ -181,6 +181,26 @@ def test_weight_packing_layouts_on_cpu():
 
 
 
+
+def test_pack_winograd44_weights_layout():
+    """U = G g G^T of F(4x4,3x3) in the LDS order of csrc/winograd44.hip: element [c][s][rg][cgp][q][i][j][ks] is the weight of
+    transform position (3 rg + s // 6, s % 6), cout 32 cgp + 16 j + i, cin 8 c + 2 q + ks."""
+    import torch
+    from deqsci_amd import _hip
+    g = torch.Generator().manual_seed(4)
+    w = torch.randn(64, 64, 3, 3, generator=g)
+    U = _hip.pack_winograd44_weights(w).reshape(8, 18, 2, 2, 4, 16, 2, 2)
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]],
+                     dtype=torch.float64)
+    full = (G @ w.double() @ G.t()).float()                   # (cout, cin, 6, 6)
+    for (c, s_, rg, cgp, q, i, j, ks) in ((0, 0, 0, 0, 0, 0, 0, 0), (7, 17, 1, 1, 3, 15, 1, 1), (3, 7, 0, 1, 2, 5, 0, 1), (5, 11, 1, 0, 1, 9, 1, 0)):
+        assert U[c, s_, rg, cgp, q, i, j, ks] == full[32 * cgp + 16 * j + i, 8 * c + 2 * q + ks, 3 * rg + s_ // 6, s_ % 6]
+    assert U.numel() == 36 * 64 * 64
+    import pytest
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.pack_winograd44_weights(torch.zeros(64, 32, 3, 3))
+
+
 def test_sigma_restart_survives_address_reuse():
     """a new measurement allocated at the freed address of the previous one must still restart sigma at
     60/255 (solvers/equilibrium_solvers_yaping.py:408-413 compares y.mean(), not tensor identity)."""

@@ -65,8 +65,8 @@ def timeit():
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
     b = torch.randn(64, device="cuda", generator=g)
-    shapes = ((64, 128, 128), (8, 128, 128), (32, 128, 128), (8, 256, 256))
-    for shape in shapes[:int(os.environ.get("W44_SHAPES", "4"))]:
+    shapes = ((64, 128, 128), (8, 128, 128), (32, 128, 128), (8, 256, 256), (1, 128, 128), (2, 128, 128), (4, 128, 128), (6, 128, 128), (16, 128, 128), (1, 256, 256), (2, 256, 256))
+    for shape in shapes[:int(os.environ.get("W44_SHAPES", "11"))]:
         x = torch.randn(shape[0], 64, shape[1], shape[2], device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
         if os.environ.get("W44_ZERO_X"):                 # power experiment: all-zero activations
             x.zero_()
