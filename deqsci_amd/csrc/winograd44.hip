@@ -19,31 +19,36 @@
 //     per stage (positions are consumed in the same order by every wave: after the first 10 of a wave's 18 positions
 //     everyone has passed barrier X1 and the DMA may overwrite them with the next chunk, the other 8 after X2), each half
 //     with half a stage of lead time.  Raw input tiles (18 x 34 pixels x 8 channels) stay double-buffered.
-//   * the 6x6 patch is read from LDS while it is transformed (it would cost 72 registers to hold); pixel stride 10 floats
-//     and a 4-float shift per group of four pixel rows make those reads bank-conflict free.
-// LDS: 72 KB weights + 2 x 25 KB raw + 32 KB exchange + bias = 154.3 KB.  Rounding: 1.2e-6 per layer against fp64
-// (F(2x2,3x3): 2.1e-7); end to end the FFDNet gates do not move (tools/f44_numerics.py, profiles/r02_f44_numerics.jsonl).
+//   * the 6x6 patch is read from LDS while it is transformed (it would cost 72 registers to hold).  Raw tiles reach LDS by
+//     the LDS-DMA path (buffer_load ... lds: lane-linear in LDS, a per-lane offset on the global side, zeros for lanes
+//     outside the buffer), so the layout is chosen by WHICH pixel each lane fetches: the columns of one residue class mod 4
+//     side by side and the channel halves swapped on every other group of four pixel rows - the patch reads of the 16 tiles of
+//     a wave then hit every bank exactly once.
+//   * REGISTERS decide everything here: 144 accumulators + 36 operand registers + the transform leave no room, and one
+//     spilled register costs a scratch load AND an s_waitcnt vmcnt(0) in front of its use, i.e. a full memory round trip
+//     per stage (measured: 330 us with ~20 spilled registers, 262 us without).  Hence: the two row groups run two separate
+//     copies of prologue + loop (rg as a template argument: with a run-time rg hipcc keeps both arms of every rg-dependent
+//     piece alive); the lane index and everything derived from it is recomputed at its use (v_mbcnt, volatile) instead of
+//     being carried; the three per-lane DMA offsets of a block tile live in LDS; the MFMAs are inline asm with the
+//     accumulator tied in place; the last stage of a tile transforms BEHIND the output transform.
+//   * the output stores are 16 bytes per lane (64 contiguous bytes per pixel; 8-byte stores cost +115 us per launch),
+//     non-temporal (kept in L2 they evict the input lines the launch re-reads for every cin chunk: -9 %), and they are
+//     issued between the weight DMA and the raw DMA of the next stage so that no wait in the MFMA loop covers them.
+// LDS: 72 KB weights + 2 x 21 KB raw + 32 KB exchange + 6 KB DMA offsets + bias = 152.3 KB.  Rounding: 1.2-1.7e-6 per layer
+// against fp64 (F(2x2,3x3): 2.1e-7); end to end the FFDNet gates do not move (tools/f44_numerics.py,
+// profiles/r02_f44_numerics.jsonl).  64 images of 128 x 128: 262 us against 314 us for F(2x2,3x3) on the same box; where the
+// rest goes (tools/w44_variants.sh + w44_check.py, profiles/r02_w44_*): MFMA phases alone 158 us, input transform +50,
+// weight DMA +10..25, raw DMA +70 (the scattered 16-byte units of the LDS-DMA path cost ~1.6 cycles each, contiguous ones
+// 0.08), output transform + exchange + stores +35.
 #include "common.hpp"
 #include <hip/hip_ext.h>
 #include <type_traits>
 #pragma clang diagnostic ignored "-Winline-asm"   // m0 is named as a clobber of the LDS-DMA asm below, on purpose
 
-#ifndef W44_RAW_DMA
-#define W44_RAW_DMA 1 // 1 = raw tiles by buffer_load ... lds (no staging registers; measured slower: the scattered 16-byte units cost the
-                      // texture path ~3 cycles per lane), 0 = through registers
-#endif
-#ifndef W44_RAWPOS
-#define W44_RAWPOS 0  // experiment: 1 = raw DMA issued behind X1 (one chunk later) instead of behind X2
-#endif
-#ifndef W44_NT_STORE
-#define W44_NT_STORE 1
-#endif
-#ifndef W44_PF
-#define W44_PF 2      // weight operands are read this many positions ahead
-#endif
 #ifndef W44_ABL
-#define W44_ABL 0     // debugging / timing ablations only: 1 = no raw DMA, 2 = no weight DMA, 4 = no output stores, 16 = no input transform,
-                      // 32 = no output transform at all, 64 = no patch reads (transform of constants)
+#define W44_ABL 0     // timing ablations only (results wrong; tools/w44_variants.sh): 1 = no raw DMA, 2 = no weight DMA, 16 = no input
+                      // transform, 64 = no patch reads, 128 = raw DMA folded into 64 KB (cache hits), 4096 = no output stores (but
+                      // everything in front of them), 8192 = no exchange between the two row groups
 #endif
 
 namespace deqsci {
@@ -60,7 +65,7 @@ constexpr int OUT_ROWS = 4 * TILE_ROWS, OUT_COLS = 4 * TILE_COLS;
 constexpr int RAW_ROWS = OUT_ROWS + 2, RAW_COLS = OUT_COLS + 2;              // 18 x 34 staged pixels
 constexpr int RAW_HALF_U = RAW_ROWS * RAW_COLS;              // 612 units of 16 bytes per channel half
 constexpr int RAW_DMA = 21;                                  // DMA instructions of 64 units per chunk tile (1224 units used)
-constexpr int RAW_BUF = W44_RAW_DMA ? RAW_DMA * 64 * 4 : 3 * TBW * 4;   // floats: 21 KB (21 DMA instructions of 64 units) / 24 KB (1536 units); 1224 used
+constexpr int RAW_BUF = RAW_DMA * 64 * 4;                    // 5376 floats = 21 KB (1224 units used)
 constexpr uint32_t RAW_BIAS = 4096;                          // see set_fetch_tile
 constexpr uint32_t RAW_OOB = 0x80000000u;                    // buffer offset of a pixel outside the image: beyond num_records -> zeros
 constexpr int NSTEP = 18;                                    // positions per wave
@@ -111,9 +116,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) float Xs[XCH];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
-#if W44_RAW_DMA
     __shared__ uint32_t Voff[3 * TBW];
-#endif
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     const int rg = wave & 1, cgp = (wave >> 1) & 1, tg = wave >> 2;
 
@@ -140,7 +143,6 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // channel pairs 0, 1 of the pixels (R + 4 ty, C + 4 tx) of 16 tiles: float offsets 8 tx + 4 ty + 2 q mod 64 - every bank once.
     // Pixels outside the image get an offset beyond the buffer descriptor's range: the hardware writes zeros for them
     // (tools/ubench/buffer_lds_oob.hip), so the zero padding costs no instruction.
-#if W44_RAW_DMA
     // (the three per-lane buffer offsets of a block tile live in LDS, not in registers: the kernel has none to spare, and a
     // spilled register costs a scratch load AND an s_waitcnt vmcnt(0) - measured at ~80 us per launch)
     i32x4 rsrc;
@@ -189,61 +191,6 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                      "buffer_load_dwordx4 %3, %4, %5 offen offset:2048 lds"
                      ::"s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(rsrc), "s"(soff) : "memory", "m0");
     };
-#else
-    // (register path) thread handles the LDS units tid + 512 k, k = 0..2 (16 bytes each, 1536 >= 1224: the spare ones are written
-    // as zeros): unit u = 2 slot + (half ^ swap(row)) as above, so the two lanes of a pixel fetch 32 contiguous bytes and the LDS
-    // address of a thread's unit is 16 (tid + 512 k) - no address registers.  Which pixel that is, is decoded once per block tile.
-    uint32_t roff[3];
-    bool rok[3];
-    bool border = true;
-    const float* xf = x;
-    auto set_fetch_tile = [&](int t) {
-        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
-        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
-        xf = x + (int64_t)n * H * W * 64;
-        const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;
-        border = py0 < 0 || px0 < 0 || py0 + RAW_ROWS > H || px0 + RAW_COLS > W;
-        const int el = wave * 64 + lane_id();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int u = k * TBW + el, slot = u >> 1;
-            const int row = (slot * 1928) >> 16, cu = slot - row * RAW_COLS;      // slot / 34 for slot < 768
-            const int col = cu < 9 ? 4 * cu : (cu < 18 ? 4 * (cu - 9) + 1 : (cu < 26 ? 4 * (cu - 18) + 2 : 4 * (cu - 26) + 3));
-            const int half = (u & 1) ^ ((row >> 2) & 1);
-            const int iy = py0 + row, ix = px0 + col;
-            rok[k] = slot < RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
-            roff[k] = ((uint32_t)(cy * W + cx) * 64u + 4u * (uint32_t)half) * 4u;   // < 2^32: H*W < 2^24 (launcher)
-        }
-        if (!border) {                                             // interior tile: only the spare units are not fetched pixels
-#pragma unroll
-            for (int k = 0; k < 3; ++k) rok[k] = k * TBW + el < 2 * RAW_HALF_U;
-        }
-    };
-    float4 rawv[3];
-    bool rawok[3];
-    auto fetch_raw = [&](int c) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-#if W44_ABL & 2048     // timing experiment: no global fetch at all (stale registers are stored)
-            asm volatile("" : "+v"(rawv[k].x));
-#elif W44_ABL & 1024   // timing experiment: the same fetches folded into 4 KB (cache hits)
-            rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * CK) + (roff[k] & 0xff0u));
-#else
-            rawv[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(xf + c * CK) + roff[k]);
-#endif
-            rawok[k] = rok[k];
-        }
-    };
-    auto store_raw = [&](int buf) {
-        const int el = wave * 64 + lane_id();
-        float* dst = Raw + buf * RAW_BUF + 4 * el;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            *reinterpret_cast<float4*>(dst + 4 * TBW * k) = rawok[k] ? rawv[k] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    };
-    auto raw_landed = [&]() { asm volatile("" ::"v"(rawv[0].x), "v"(rawv[1].x), "v"(rawv[2].x)); };
-#endif
 
     // ---- weight chunk: host-packed in LDS order; half 1 = bytes [0, 40 KiB), half 2 = [40 KiB, 72 KiB); wave w moves a
     // contiguous share of each half by the LDS-DMA path, pieces of 1 KiB that differ only in their immediate offset
@@ -319,6 +266,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         float* yn = y + (int64_t)n * H * W * 64;
+        asm volatile("s_nop 15");                              // (asm MFMAs: the wait states between the last of them and the first vector read of an accumulator)
         stores_in_flight = OUT_ROWS * (by + 1) <= H && OUT_COLS * (bx + 1) <= W;   // every lane stores all 16 values: 16 operations in flight
         // every lane-dependent address of the epilogue is derived from an opaque copy of the lane index: hipcc would otherwise
         // hoist them out of the persistent loop and keep a dozen registers alive through the MFMA stages (= spills there)
@@ -393,12 +341,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                         for (int c = 0; c < 4; ++c) {
                             f32x4 val = {keep[rr * 4 + c].x, keep[rr * 4 + c].y, mine[rr * 4 + c].x, mine[rr * 4 + c].y};
                             if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
-                            if (!(W44_ABL & 4) && (!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)   // (4096: timing experiment, never stores)
-#if W44_NT_STORE
+                            if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)
                                 __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64));
-#else
-                                *reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64) = val;
-#endif
                         }
                 }
             }
@@ -417,10 +361,13 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     int t_fetch = t_first;
 
     // One stage = chunk c of the current tile.  PAR = c&1: Raw[PAR^1] holds raw(c+1), Raw[PAR] is receiving raw(c+2).
-    // Vector memory operations of a wave, in issue order: behind X2 of the previous stage [second half of U(c) x4, raw(c+3)
-    // x3]; behind X1 [first half of U(c+1) x5].  vmcnt(3) in front of X1 = the weights are in (the raw tile may still be
-    // landing: it is needed after X1 of the NEXT stage), vmcnt(0) in front of X2.  (Register spills would be scratch = vector
-    // memory operations in between: the loop must compile without any.)
+    // Vector memory operations of a wave, in issue order: behind X2 of the previous stage [second half of U(c) x4, (last stage
+    // of a tile: the 16 output stores,) raw(c+2) x3]; behind X1 [(first stage of a tile: raw(2) x3,) first half of U(c+1) x5].
+    // vmcnt(3) in front of X1 = the weights are in (the raw tile may still be landing: it is needed behind X1 of the NEXT
+    // stage), vmcnt(0) in front of X2.  A register spill inside the loop would be a scratch access = one more vector memory
+    // operation (the counts stay safe: extra younger operations only make a wait stricter) with a vmcnt(0) in front of its
+    // use - and, between the asm MFMAs, a read of an accumulator without the wait states the compiler gives real MFMAs:
+    // the loop must compile without spill STORES inside the MFMA parts (tools/w44_variants.sh prints the spill count).
     auto stage = [&](auto rg_c, auto par_c, auto first_c, int c, int t_cur) __attribute__((always_inline)) {
         constexpr int RG = decltype(rg_c)::value;
         constexpr int PAR = decltype(par_c)::value;
@@ -435,7 +382,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                 init7[j] = RG == 0 ? bv : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             }
         }
-        constexpr int PF = W44_PF;
+        constexpr int PF = 2;                                 // weight operands are read two positions ahead
         float4 bq[PF + 1];
         const int sl = lane_id();
         const float* ub = Us + ((RG * 2 + cgp) * 64 + sl) * 4;
@@ -470,31 +417,14 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             W44_STEP(s);
         }
         W44_MARK(0);                                          // first MFMA part
-#if W44_RAW_DMA && W44_RAWPOS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         // second half of U(c) in LDS; the raw fetch (3 operations, issued behind it) stays in flight.  Behind a tile that lies
         // inside the image the 16 output stores of its epilogue (issued behind the weights too) may stay in flight as well:
         // waiting for their acknowledgements here was measured at ~50 us per launch.
-#if W44_RAW_DMA
         if (FIRST) { if (stores_in_flight) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#else
-        if (FIRST && stores_in_flight) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-#endif
         lds_barrier();                                        // X1: steps >= SPLIT of U(c) visible; everyone is done with steps < SPLIT
         W44_MARK(1);                                          // wait + X1
-#if W44_RAW_DMA && !W44_RAWPOS
         if (FIRST && t_cur != t_first) dma_raw(2, 0);         // (held back behind the previous tile's last transform: see the end of the stage)
-#endif
-#if W44_RAW_DMA && W44_RAWPOS
-        if (c == 6) {                                         // chunks c+2.. of the fetch stream belong to the next tile
-            if (t_fetch + t_step < t_end) t_fetch += t_step;
-            set_fetch_tile(t_fetch);
-        }
-        dma_raw((c + 2) & 7, PAR);
-#endif
         dma_half((c + 1) & 7, 0);
         // ---- second part: steps [SPLIT, 18)
 #pragma unroll
@@ -506,12 +436,6 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             W44_STEP(s);
         }
         __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise starts the transform above the MFMAs that still read v)
-#if !W44_RAW_DMA
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // raw(c+2) is in registers (the first half of U(c+1) may still be landing)
-        raw_landed();
-        store_raw(PAR);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // (the last stage of a tile transforms BEHIND the epilogue: V would otherwise be live across it, 36 registers too many)
         if (!(W44_ABL & 16) && c != 7) transform(rg_c, PAR ^ 1);    // V(c+1)
         __builtin_amdgcn_sched_barrier(0);
@@ -521,34 +445,18 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         W44_MARK(3);                                          // wait + X2                                        // X2: both visible; everyone is done with U(c) and raw(c+1)
         dma_half((c + 1) & 7, 1);                             // (in front of the epilogue's stores: see the wait in front of X1)
         if (c == 7) {
-            if (!(W44_ABL & 32)) epilogue(rg_c, t_cur);
-#if W44_ABL & 32      // timing experiment: no output transform; one dependent store keeps the accumulators alive
-            else {
-                float sacc = 0.0f;
-#pragma unroll
-                for (int i = 0; i < NSTEP; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) sacc += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-                y[(int64_t)t_cur * TBW + wave * 64 + lane_id()] = sacc;
-            }
-#endif
+            epilogue(rg_c, t_cur);
             __builtin_amdgcn_sched_barrier(0);
             if (!(W44_ABL & 16)) transform(rg_c, PAR ^ 1);   // V(0) of the next tile: the raw buffer is rewritten behind X1 of its stage 0 at the earliest
             __builtin_amdgcn_sched_barrier(0);
         }
-#if !(W44_RAW_DMA && W44_RAWPOS)
         if (c == 5) {                                         // chunks c+3.. of the fetch stream belong to the next tile
             if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
             set_fetch_tile(t_fetch);
         }
-#endif
-#if W44_RAW_DMA
         // raw(c+3) into the buffer raw(c+1) has just been read from - except behind the last stage of a tile, whose transform
         // (behind the epilogue) may still be reading it in a slower wave: that fetch is issued behind X1 of the next stage
         if (c != 7) dma_raw((c + 3) & 7, PAR ^ 1);
-#else
-        fetch_raw((c + 3) & 7);                               // raw(c+3): stored into that buffer behind the MFMAs of the next stage
-#endif
     };
     using std::integral_constant;
     // the two row groups run two separate copies of prologue + loop: with `rg` a run-time value hipcc keeps both arms of every
@@ -560,28 +468,13 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         set_fetch_tile(t_first);
         dma_half(0, 0);
         dma_half(0, 1);
-#if W44_RAW_DMA
         dma_raw(0, 0);
         dma_raw(1, 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         transform(rg_c, 0);
         __syncthreads();                                          // everyone has read raw(0): the fetch of raw(2) may overwrite it
-#if !W44_RAWPOS
         dma_raw(2, 0);
-#endif
-#else
-        fetch_raw(0);
-        store_raw(0);
-        fetch_raw(1);
-        store_raw(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        raw_landed();
-        __syncthreads();
-        transform(rg_c, 0);
-        __syncthreads();
-        fetch_raw(2);                                             // stored to Raw[0] during stage 0
-#endif
 #pragma unroll 1
         for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
             stage(rg_c, integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
