@@ -230,11 +230,11 @@ def run_rank(args):
         _hip.anderson_mix_gap = timed_mix_gap
         orig_wg = _hip.conv3x3_c64
 
-        def timed_conv64(x, weights, bias=None, relu=True, out=None):
+        def timed_conv64(x, weights, bias=None, relu=True, out=None, out_blk=False):
             if not timing_on[0] or conv_timer.full:
-                return orig_wg(x, weights, bias, relu, out)
-            o, kind = conv_timer.conv64(x, weights, bias, relu, out)
-            conv_shape[:] = [x.shape[0], x.shape[2], x.shape[3], kind]
+                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk)
+            o, kind = conv_timer.conv64(x, weights, bias, relu, out, out_blk=out_blk)
+            conv_shape[:] = ([x.n, x.H, x.W] if isinstance(x, _hip.Blk32) else [x.shape[0], x.shape[2], x.shape[3]]) + [kind]
             return o
         _hip.conv3x3_c64 = timed_conv64
 

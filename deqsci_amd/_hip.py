@@ -43,6 +43,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -413,15 +414,67 @@ def pack_winograd44_weights(w):
     return U.permute(3, 7, 8, 6, 0, 4, 2, 1, 5).contiguous().float()   # [c][sr][sc][rg][cgp][q][i][j][ks]
 
 
-def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None):
-    """x (n,64,H,W) channels_last -> relu(conv3x3(x, w, pad=1) + bias), Winograd F(4x4,3x3) (the large-batch kernel)."""
-    n, c, H, W = x.shape
-    if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
+ACT_NHWC, ACT_BLK32 = 0, 1
+
+
+class Blk32:
+    """An activation (n,64,H,W) in the "blk32" layout of csrc/winograd44.hip: planes of 8 channels, blocks of 32 columns in the
+    kernel's staging order - t is (n, 8, H, ceil(W/32), 32, 8) float32.  Only ever exists between two 64->64 layers."""
+    __slots__ = ("t", "n", "H", "W")
+
+    def __init__(self, t, n, H, W):
+        self.t, self.n, self.H, self.W = t, n, H, W
+
+    @staticmethod
+    def empty(n, H, W, device):
+        return Blk32(torch.empty((n, 8, H, -(-W // 32), 32, 8), dtype=torch.float32, device=device), n, H, W)
+
+    @staticmethod
+    def _pos():
+        m1 = torch.arange(32) + 1
+        return 8 * (m1 & 3) + (m1 >> 2) - ((m1 & 3) == 0).long()        # position of column m inside its block
+
+    @staticmethod
+    def from_nchw(x):
+        """(tests / tools) any (n,64,H,W) tensor -> blk32; padding columns are filled with NaN: the kernel must never read them."""
+        n, c, H, W = x.shape
+        Wb = -(-W // 32)
+        xp = torch.full((n, 64, H, Wb * 32), float("nan"), dtype=torch.float32, device=x.device)
+        xp[..., :W] = x
+        t = xp.reshape(n, 8, 8, H, Wb, 32).permute(0, 1, 3, 4, 5, 2)      # (n, chunk, H, Wb, m, ch)
+        out = torch.empty_like(t.contiguous())
+        out[:, :, :, :, Blk32._pos().to(x.device), :] = t
+        return Blk32(out.contiguous(), n, H, W)
+
+    def to_nchw(self):
+        t = self.t[:, :, :, :, Blk32._pos().to(self.t.device), :]          # back to column order
+        x = t.permute(0, 1, 5, 2, 3, 4).reshape(self.n, 64, self.H, -1)
+        return x[..., :self.W].contiguous(memory_format=torch.channels_last)
+
+
+def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=False, events=None):
+    """x (n,64,H,W) channels_last, or a Blk32 -> relu(conv3x3(x, w, pad=1) + bias) as a new channels_last tensor, or a Blk32 with
+    out_blk=True: Winograd F(4x4,3x3), the large-batch kernel.  events: (start, stop) raw hipEvent_t handles (measurement)."""
+    if isinstance(x, Blk32):
+        n, H, W, xt, in_l = x.n, x.H, x.W, x.t, ACT_BLK32
+    else:
+        n, c, H, W = x.shape
+        if c != 64 or not x.is_contiguous(memory_format=torch.channels_last):
+            raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
+        xt, in_l = x, ACT_NHWC
+    if xt.dtype != torch.float32 or not xt.is_cuda:
         raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
-    o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-    with _dev(x):
-        _check(load().deqsci_conv3x3_c64_winograd44_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
-                                                        n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd44")
+    if out_blk:
+        o = out if out is not None else Blk32.empty(n, H, W, xt.device)
+        ot = o.t
+    else:
+        o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=xt.device).contiguous(memory_format=torch.channels_last)
+        ot = o
+    ev = events if events is not None else (None, None)
+    with _dev(xt):
+        _check(load().deqsci_conv3x3_c64_winograd44_layout_f32(xt.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), ot.data_ptr(),
+                                                               n, H, W, 1 if relu else 0, in_l, ACT_BLK32 if out_blk else ACT_NHWC, _stream(),
+                                                               ev[0], ev[1]), "conv3x3_c64_winograd44")
     return o
 
 
@@ -456,11 +509,12 @@ def conv64_kernel_for(n, H, W, device=None):
     return "f44" if t44 < t22 else "f22"
 
 
-def conv3x3_c64(x, weights, bias=None, relu=True, out=None):
+def conv3x3_c64(x, weights, bias=None, relu=True, out=None, out_blk=False):
     """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer with the faster of the two Winograd kernels (`weights` =
-    pack_conv64_weights(w))."""
-    if conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device) == "f44":
-        return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out)
+    pack_conv64_weights(w)).  out_blk=True (only honoured by the F(4x4,3x3) kernel - check with conv64_kernel_for) leaves the
+    result in the blk32 layout for the next 64->64 layer; a Blk32 input is consumed as such."""
+    if isinstance(x, Blk32) or conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device) == "f44":
+        return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk)
     return conv3x3_c64_winograd(x, weights.f22, bias, relu, out)
 
 
@@ -518,19 +572,20 @@ class KernelTimer:
                    "conv3x3_c64_winograd_timed")
         return o
 
-    def conv64(self, x, weights, bias=None, relu=True, out=None):
+    def conv64(self, x, weights, bias=None, relu=True, out=None, out_blk=False):
         """The timed counterpart of conv3x3_c64; returns (output, 'f22' | 'f44')."""
-        kind = conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device)
+        blk = isinstance(x, Blk32)
+        kind = "f44" if blk else conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device)
         ev = self._pair()
         if ev is None:
-            return conv3x3_c64(x, weights, bias, relu, out), kind
+            return conv3x3_c64(x, weights, bias, relu, out, out_blk=out_blk), kind
+        if kind == "f44":
+            return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk, events=ev), kind
         n, c, H, W = x.shape
         o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-        fn = load().deqsci_conv3x3_c64_winograd44_timed_f32 if kind == "f44" else load().deqsci_conv3x3_c64_winograd_timed_f32
-        u = weights.f44 if kind == "f44" else weights.f22
         with _dev(x):
-            _check(fn(x.data_ptr(), _p(u, "u_packed"), _p(bias, "bias", True), o.data_ptr(), n, H, W, 1 if relu else 0, _stream(),
-                      ev[0], ev[1]), "conv3x3_c64_timed")
+            _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(weights.f22, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
+                                                                n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_timed")
         return o, kind
 
     def durations_ms(self):

@@ -108,6 +108,12 @@ __device__ __forceinline__ void bt_hi(const f32x2* x, f32x2& y3, f32x2& y4, f32x
     y5 = fma2(x[3], -5.0f, fma2(x[1], 4.0f, x[5]));
 }
 
+// IN_BLK / OUT_BLK: the activation is not channels_last (n,H,W,64) but "blk32": [n][cin chunk (8)][H][W/32][32][8] - planes of 8
+// channels, and inside every block of 32 columns the pixels in the order this kernel stages them (column m of the block at
+// position 8 ((m+1) & 3) + ((m+1) >> 2) - ((m+1) & 3 == 0)): a staged pixel row is then two contiguous runs of 512 bytes
+// instead of 34 scattered 32-byte pieces, and an output store instruction writes 256 contiguous bytes per tile row instead of
+// 64.  A stack of 64->64 layers runs NHWC -> blk32 -> ... -> blk32 -> NHWC; nothing else ever sees the layout.
+template <int IN_BLK, int OUT_BLK>
 __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* __restrict__ x, const float* __restrict__ Ug,
                                                                    const float* __restrict__ bias, float* __restrict__ y,
                                                                    int H, int W, int relu, int tiles_x, int tiles_y, int n_tiles,
@@ -151,10 +157,11 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         // the descriptor starts RAW_BIAS bytes BELOW the image: a wave's three instructions differ in their immediate offset
         // (which the hardware adds to the LDS and to the global address), the per-lane offsets take it back out
-        const uint64_t base = (uint64_t)(x + (int64_t)n * H * W * 64) - RAW_BIAS;
+        const int64_t img_floats = IN_BLK ? (int64_t)H * tiles_x * 32 * 64 : (int64_t)H * W * 64;
+        const uint64_t base = (uint64_t)(x + (int64_t)n * img_floats) - RAW_BIAS;
         rsrc.x = (int)uniform((uint32_t)base);
         rsrc.y = (int)uniform((uint32_t)(base >> 32));            // stride 0: raw buffer, offsets in bytes
-        rsrc.z = (int)uniform((uint32_t)(H * W) * 256u + RAW_BIAS);   // num_records (< 2^32: launcher)
+        rsrc.z = (int)uniform((uint32_t)img_floats * 4u + RAW_BIAS);   // num_records (< 2^32: launcher)
         rsrc.w = 0x00020000;
         const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;   // image coordinates of staged pixel (0,0)
         const int el = lane_id();
@@ -167,7 +174,14 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             const int half = (u & 1) ^ ((row >> 2) & 1);
             const int iy = py0 + row, ix = px0 + col;
             const bool ok = slot < RAW_HALF_U && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            uint32_t vo = ok ? (uint32_t)(iy * W + ix) * 256u + 16u * (uint32_t)half + (RAW_BIAS - 1024u * j) : RAW_OOB;
+            uint32_t pix_bytes;                                    // of the pixel's 8 channels of chunk 0 inside the image
+            if (IN_BLK) {
+                const int m1 = (ix & 31) + 1;
+                pix_bytes = (uint32_t)((iy * tiles_x + (ix >> 5)) * 32 + 8 * (m1 & 3) + (m1 >> 2) - ((m1 & 3) == 0)) * 32u;
+            } else {
+                pix_bytes = (uint32_t)(iy * W + ix) * 256u;
+            }
+            uint32_t vo = ok ? pix_bytes + 16u * (uint32_t)half + (RAW_BIAS - 1024u * j) : RAW_OOB;
 #if W44_ABL & 128     // timing experiment (wrong results): the same scatter pattern, folded into the first 64 KB of the image (cache hits)
             vo = ok ? vo & 0xffffu : RAW_OOB;
 #endif
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // wave (writing M0 between two LDS-DMA instructions costs ~100 cycles each: measured)
     auto dma_raw = [&](int c, int buf) {
         if (W44_ABL & 1) return;
-        const uint32_t soff = uniform((uint32_t)c * (CK * 4));
+        const uint32_t soff = uniform(IN_BLK ? (uint32_t)c * (uint32_t)(H * tiles_x) * 1024u : (uint32_t)c * (CK * 4));   // chunk plane / channel offset
         int w = wave;
         asm volatile("" : "+s"(w));                                // recompute the M0 value here (scalar ALU is free; SGPRs are not)
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + 3 * (w < 7 ? w : 6) * 1024));
@@ -265,7 +279,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         constexpr int RG = decltype(rg_c)::value;
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
-        float* yn = y + (int64_t)n * H * W * 64;
+        const int64_t plane = (int64_t)H * tiles_x * 256;      // floats of one 8-channel plane of the blk32 layout
+        float* yn = y + (int64_t)n * (OUT_BLK ? 8 * plane : (int64_t)H * W * 64);
         asm volatile("s_nop 15");                              // (asm MFMAs: the wait states between the last of them and the first vector read of an accumulator)
         stores_in_flight = OUT_ROWS * (by + 1) <= H && OUT_COLS * (bx + 1) <= W;   // every lane stores all 16 values: 16 operations in flight
         // every lane-dependent address of the epilogue is derived from an opaque copy of the lane index: hipcc would otherwise
@@ -273,7 +288,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         const int el = lane_id();
         const int ei = el & 15, eq = el >> 4;
         const int oy = OUT_ROWS * by + 4 * (2 * tg + (ei >> 3)) + 2 * RG, ox = OUT_COLS * bx + 4 * (ei & 7);
-        float* o = yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
+        float* o = OUT_BLK ? yn + (4 * cgp + (eq >> 1)) * plane + (((int64_t)oy * tiles_x + bx) * 32 + (ei & 7)) * 8 + 4 * (eq & 1)
+                           : yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
         float* xw = Xs + (wave * 4 * 64 + el) * 4;
         const float* xr = Xs + ((wave ^ 1) * 4 * 64 + el) * 4;
 #pragma unroll
@@ -342,7 +358,9 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                             f32x4 val = {keep[rr * 4 + c].x, keep[rr * 4 + c].y, mine[rr * 4 + c].x, mine[rr * 4 + c].y};
                             if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
                             if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)
-                                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(o + 16 * j + ((int64_t)rr * W + c) * 64));
+                                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(
+                                    OUT_BLK ? o + 2 * j * plane + (int64_t)rr * tiles_x * 256 + 64 * ((c + 1) & 3)      // position 8 ((c+1)&3) + tx of the block
+                                            : o + 16 * j + ((int64_t)rr * W + c) * 64));
                         }
                 }
             }
@@ -508,38 +526,57 @@ static void w44_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
 }
 
 static int winograd44_impl(const float* x, const float* u_packed, const float* bias, float* y, int64_t n, int64_t H, int64_t W,
-                           int relu, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+                           int relu, int in_layout, int out_layout, deqsci_stream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
     if (!x || !u_packed || !y) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if ((in_layout != DEQSCI_ACT_NHWC && in_layout != DEQSCI_ACT_BLK32) || (out_layout != DEQSCI_ACT_NHWC && out_layout != DEQSCI_ACT_BLK32))
+        return DEQSCI_ERR_UNSUPPORTED;
     if (H > (1 << 20) || W > (1 << 20) || x == y) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     const int64_t tiles_x = ceil_div(W, w44::OUT_COLS), tiles_y = ceil_div(H, w44::OUT_ROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
-    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W >= (int64_t)1 << 24) return DEQSCI_ERR_UNSUPPORTED;
+    // 32-bit arithmetic in the kernel: tile indices, and byte offsets inside one image (padded to 32 columns in the blk32 layout)
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * tiles_x * 32 >= (int64_t)1 << 24) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t resident = (int64_t)num_cus();
     const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
     uint32_t mg_img, sh_img, mg_tx, sh_tx;
     w44_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
     w44_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
-    if (ev0 || ev1)
-        hipExtLaunchKernelGGL(w44::winograd44_conv64_kernel, grid, dim3(w44::TBW), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W,
-                              relu, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);
-    else
-        hipLaunchKernelGGL(w44::winograd44_conv64_kernel, grid, dim3(w44::TBW), 0, st, x, u_packed, bias, y, (int)H, (int)W, relu,
-                           (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);
+#define W44_LAUNCH(KERNEL)                                                                                                              \
+    do {                                                                                                                                \
+        if (ev0 || ev1)                                                                                                                 \
+            hipExtLaunchKernelGGL(KERNEL, grid, dim3(w44::TBW), 0, st, ev0, ev1, 0, x, u_packed, bias, y, (int)H, (int)W, relu,        \
+                                  (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);                              \
+        else                                                                                                                            \
+            hipLaunchKernelGGL(KERNEL, grid, dim3(w44::TBW), 0, st, x, u_packed, bias, y, (int)H, (int)W, relu, (int)tiles_x,          \
+                               (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx);                                               \
+    } while (0)
+    if (in_layout == DEQSCI_ACT_NHWC && out_layout == DEQSCI_ACT_NHWC) W44_LAUNCH((w44::winograd44_conv64_kernel<0, 0>));
+    else if (in_layout == DEQSCI_ACT_NHWC) W44_LAUNCH((w44::winograd44_conv64_kernel<0, 1>));
+    else if (out_layout == DEQSCI_ACT_NHWC) W44_LAUNCH((w44::winograd44_conv64_kernel<1, 0>));
+    else W44_LAUNCH((w44::winograd44_conv64_kernel<1, 1>));
+#undef W44_LAUNCH
     return launch_status();
 }
 
 extern "C" int deqsci_conv3x3_c64_winograd44_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
                                                  int64_t H, int64_t W, int relu, deqsci_stream_t stream) {
-    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, stream, nullptr, nullptr);
+    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, DEQSCI_ACT_NHWC, DEQSCI_ACT_NHWC, stream, nullptr, nullptr);
+}
+
+extern "C" int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
+                                                        int64_t H, int64_t W, int relu, int in_layout, int out_layout,
+                                                        deqsci_stream_t stream, void* start_event, void* stop_event) {
+    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
+    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, in_layout, out_layout, stream, static_cast<hipEvent_t>(start_event),
+                           static_cast<hipEvent_t>(stop_event));
 }
 
 extern "C" int deqsci_conv3x3_c64_winograd44_timed_f32(const float* x, const float* u_packed, const float* bias, float* y, int64_t n,
                                                        int64_t H, int64_t W, int relu, deqsci_stream_t stream, void* start_event,
                                                        void* stop_event) {
     if (!start_event || !stop_event) return DEQSCI_ERR_NULL;
-    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, stream, static_cast<hipEvent_t>(start_event),
-                           static_cast<hipEvent_t>(stop_event));
+    return winograd44_impl(x, u_packed, bias, y, n, H, W, relu, DEQSCI_ACT_NHWC, DEQSCI_ACT_NHWC, stream,
+                           static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event));
 }

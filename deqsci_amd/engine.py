@@ -30,6 +30,8 @@ y.mean() changes); the dead second f-call of DEQFixedPoint.forward (:271-272, on
 backward hook) is skipped unless `extra_call=True`.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -66,6 +68,7 @@ class _Denoiser:
         self.net = net
         self.fused_edges = fused_edges
         self.winograd = winograd
+        self.blk32 = os.environ.get("DEQSCI_BLK32", "1") != "0"     # (A/B knob) blk32 activations between F(4x4,3x3) layers
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
         # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
         # 128x128x64 layers, 11 % slower for SimpleCNN's 256x256x64 ones.
@@ -163,10 +166,13 @@ class _Denoiser:
         return self._run_layers(h, idx, fused)
 
     def _run_layers(self, h, idx, fused):
-        for i in idx:
+        for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
-            if self.wino[i] is not None and h.is_cuda and h.is_contiguous(memory_format=torch.channels_last):
-                h = _hip.conv3x3_c64(h, self.wino[i], b, relu)
+            if self.wino[i] is not None and (isinstance(h, _hip.Blk32) or (h.is_cuda and h.is_contiguous(memory_format=torch.channels_last))):
+                # between two 64->64 layers that run on the F(4x4,3x3) kernel the activation stays in that kernel's own layout
+                f44 = isinstance(h, _hip.Blk32) or _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device) == "f44"
+                nxt = idx[pos + 1] if pos + 1 < len(idx) else None
+                h = _hip.conv3x3_c64(h, self.wino[i], b, relu, out_blk=bool(f44 and self.blk32 and nxt is not None and self.wino[nxt] is not None))
             elif fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)

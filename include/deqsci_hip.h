@@ -171,6 +171,19 @@ int deqsci_conv3x3_c64_winograd_f32(const float* x, const float* u_packed, const
 int deqsci_conv3x3_c64_winograd44_f32(const float* x, const float* u_packed, const float* bias, float* y,
                                       int64_t n, int64_t H, int64_t W, int relu, deqsci_stream_t stream);
 
+/* The same kernel between the layers of a stack (FFDNet: 13 of them in a row): activations in "blk32" instead of channels_last -
+ *     [n][channel chunk (8)][H][ceil(W/32)][32][8]: planes of 8 channels; inside every block of 32 columns, column m at position
+ *     8 ((m+1) & 3) + ((m+1) >> 2) - ((m+1) & 3 == 0), i.e. in the order the kernel stages them (its input fetch becomes two
+ *     contiguous 512-byte runs per pixel row, its output stores 256 contiguous bytes per tile row).  in_layout / out_layout:
+ *     DEQSCI_ACT_NHWC or DEQSCI_ACT_BLK32, independently (first layer NHWC -> BLK32, last BLK32 -> NHWC); the blk32 buffer holds
+ *     n * 8 * H * ceil(W/32) * 256 floats, columns >= W are never read or written.  start_event / stop_event: both NULL, or both
+ *     raw hipEvent_t handles that receive the dispatch's begin / end (measurement). */
+#define DEQSCI_ACT_NHWC 0
+#define DEQSCI_ACT_BLK32 1
+int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_packed, const float* bias, float* y,
+                                             int64_t n, int64_t H, int64_t W, int relu, int in_layout, int out_layout,
+                                             deqsci_stream_t stream, void* start_event, void* stop_event);
+
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
  * without the marker-packet overhead of events recorded around a launch. */

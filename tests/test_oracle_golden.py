@@ -265,3 +265,22 @@ def test_config2_spread_file():
         assert abs(m["variants"]["base"]["psnr"] - base[mid]["psnr"]) < 1e-9
         assert len([k for k in m["variants"] if k.startswith("seed")]) >= 8 and "gram_fp64" in m["variants"]
         assert m["psnr_min"] <= base[mid]["psnr"] <= m["psnr_max"]
+
+
+def test_config2_exact_gram_spread_file():
+    """The second reference ensemble of the config-2 gate: the same runs with the Gram matrix of :178 computed in float64
+    (make_golden g10 gram64=1).  Every traffic measurement has base + 8 seeds; where both ensembles exist the exact-Gram one is
+    not a subset of the fp32 one (that is the point of having it)."""
+    fn = os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json")
+    with open(fn) as fh:
+        g = json.load(fh)
+    with open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")) as fh:
+        a = json.load(fh)
+    assert g["and_maxiters"] == 180 and g["denoiser"] == "ffdnet"
+    traffic = [m for m in a["measurements"] if m.startswith("traffic")]
+    assert len(traffic) == 6 and set(traffic) <= set(g["measurements"])
+    for mid, m in g["measurements"].items():
+        assert "g64_base" in m["variants"] and len([k for k in m["variants"] if k.startswith("g64_seed")]) >= 8
+        assert m["f_calls"] == 182 and m["psnr_min"] <= m["variants"]["g64_base"]["psnr"] <= m["psnr_max"]
+    m2a, m2g = a["measurements"]["traffic_cacti.mat:2"], g["measurements"]["traffic_cacti.mat:2"]
+    assert m2g["psnr_max"] < min(v["psnr"] for k, v in m2a["variants"].items() if k != "gram_fp64")   # disjoint from the fp32 runs

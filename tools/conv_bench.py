@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""64->64 3x3 conv layer (+bias+ReLU): MIOpen (channels_last igemm + HIP epilogue) vs the Winograd MFMA kernel."""
+"""64->64 3x3 conv layer (+bias+ReLU): MIOpen (channels_last igemm + HIP epilogue) vs the two Winograd MFMA kernels."""
 import json
 import os
 import sys
@@ -34,10 +34,14 @@ for (N, H, W) in SHAPES:
     wcl = w.contiguous(memory_format=torch.channels_last)
     b = torch.randn(64, device="cuda")
     U = _hip.pack_winograd_weights(w)
+    U44 = _hip.pack_winograd44_weights(w)
     out = torch.empty_like(x, memory_format=torch.channels_last)
     fl = 2 * 64 * 64 * 9 * H * W * N
     t_mi = timeit(lambda: _hip.bias_relu_(F.conv2d(x, wcl, None, padding=1), b, True))
     t_wg = timeit(lambda: _hip.conv3x3_c64_winograd(x, U, b, True, out=out))
-    print(json.dumps({"images": N, "HxW": f"{H}x{W}", "miopen_igemm_plus_epilogue_us": round(t_mi, 1), "winograd_mfma_fused_us": round(t_wg, 1),
-                      "speedup": round(t_mi / t_wg, 2), "winograd_direct_equiv_TFLOPs": round(fl / t_wg / 1e6, 1),
-                      "winograd_mfma_util": round((fl / 2.25) / t_wg / 1e6 / 157.3, 3)}), flush=True)
+    t_44 = timeit(lambda: _hip.conv3x3_c64_winograd44(x, U44, b, True, out=out))
+    print(json.dumps({"images": N, "HxW": f"{H}x{W}", "miopen_igemm_plus_epilogue_us": round(t_mi, 1), "winograd_f22_us": round(t_wg, 1),
+                      "winograd_f44_us": round(t_44, 1), "front_end_picks": _hip.conv64_kernel_for(N, H, W),
+                      "speedup_vs_miopen": round(t_mi / min(t_wg, t_44), 2),
+                      "f22_direct_equiv_TFLOPs": round(fl / t_wg / 1e6, 1), "f22_mfma_util": round((fl / 2.25) / t_wg / 1e6 / 157.3, 3),
+                      "f44_direct_equiv_TFLOPs": round(fl / t_44 / 1e6, 1), "f44_mfma_util": round((fl / 4.0) / t_44 / 1e6 / 157.3, 3)}), flush=True)

@@ -23,6 +23,7 @@ cp $(find $R/gpurun_out/prof_bsz1 -name "*kernel_stats.csv" | head -1) $O/r02_be
 cd $R
 bash tools/pmc_winograd.sh > /dev/null 2>&1
 cp gpurun_out/pmc_winograd.json $O/r02_pmc_winograd.json
+cp gpurun_out/pmc_winograd44.json $O/r02_pmc_winograd44.json
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   for B in 64 8; do
@@ -32,4 +33,6 @@ done
 cd $R
 python tools/pmc_summarize.py gpurun_out/pmc 64 8 > $O/r02_pmc_hbm_traffic.json
 ls -la $O; head -c 600 $O/r02_bench_n1.json; echo; cat $O/parity_report.log | tail -9; python -c "
-import json; d=json.load(open('$O/r02_pmc_winograd.json')); print({k: d[k] for k in ('mfma_busy_fraction','non_mfma_valu_per_mfma','traffic_over_algorithmic')})"
+import json; 
+for f in ('r02_pmc_winograd.json', 'r02_pmc_winograd44.json'):
+    d=json.load(open('$O/' + f)); print(f, {k: d[k] for k in ('mfma_busy_fraction','non_mfma_valu_per_mfma','traffic_over_algorithmic')})"
