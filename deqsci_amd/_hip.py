@@ -468,7 +468,7 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
         o = out if out is not None else Blk32.empty(n, H, W, xt.device)
         ot = o.t
     else:
-        o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=xt.device).contiguous(memory_format=torch.channels_last)
+        o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=xt.device, memory_format=torch.channels_last)
         ot = o
     ev = events if events is not None else (None, None)
     with _dev(xt):
@@ -498,12 +498,22 @@ _T_TILE_F22, _T_TILE_F44 = 21.5, 35.5
 FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44": A/B runs and tests; default: the faster one per launch
 
 
+_CUS = {}
+
+
+def _cus(device):
+    idx = torch.cuda.current_device() if device is None or getattr(device, "index", None) is None else device.index
+    if idx not in _CUS:                                  # (get_device_properties costs tens of microseconds: not once per layer call)
+        _CUS[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _CUS[idx]
+
+
 def conv64_kernel_for(n, H, W, device=None):
     """'f44' or 'f22': the faster kernel for n images of H x W.  Both run one persistent workgroup per CU over block tiles of 16 x 16
     (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3)) output pixels, so the time is (waves of block tiles) x (time of a tile)."""
     if FORCE_CONV64 in ("f22", "f44"):
         return FORCE_CONV64
-    cus = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device()).multi_processor_count
+    cus = _cus(device)
     t22 = -(-(n * (-(-H // 16)) * (-(-W // 16))) // cus) * _T_TILE_F22
     t44 = -(-(n * (-(-H // 16)) * (-(-W // 32))) // cus) * _T_TILE_F44
     return "f44" if t44 < t22 else "f22"
