@@ -408,7 +408,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         // out of place (a copy chain through spare registers) and runs out of registers.  Hazards: an accumulator is touched by
         // every second MFMA (64 cycles apart) and read by vector code only in the epilogue, behind a barrier.
 #define W44_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
-#define W44_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "v"(B))
+#define W44_MFMA0(ACC, A, B) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
 #define W44_STEP(S)                                                                                                                   \
         {                                                                                                                             \
             const float4 b = bq[(S) % (PF + 1)];                                                                                      \
