@@ -14,7 +14,9 @@
 //     three rows of B^T is exactly half the work (column pass 6 x 6 ops, row pass 3 x 12) - so a wave spends ONE packed
 //     vector instruction per MFMA on it (72 : 72), as F(2x2,3x3) does with its two cout halves.
 //   * the output transform needs all 6 rows: each wave reduces ITS rows to the 4x4 partial result, keeps two output rows
-//     and hands the other two to its partner wave through LDS (4 rounds of 32 KB per block tile, 7 barriers).
+//     and hands the other two to its partner wave through LDS (4 rounds of 32 KB per block tile, 7 barriers; a round is one
+//     cout group and one PAIR of output columns, so that what is exchanged and stored per pixel is the float4 of four
+//     consecutive couts and nothing is carried from round to round).
 //   * one weight chunk is 36 x 64 x 8 floats = 72 KB: it is SINGLE-buffered and refilled in two halves behind two barriers
 //     per stage (positions are consumed in the same order by every wave: after the first 10 of a wave's 18 positions
 //     everyone has passed barrier X1 and the DMA may overwrite them with the next chunk, the other 8 after X2), each half
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
 #if W44_ABL & 128     // timing experiment (wrong results): the same scatter pattern, folded into the first 64 KB of the image (cache hits)
             vo = ok ? vo & 0xffffu : RAW_OOB;
 #endif
-            Voff[j * TBW + wave * 64 + el] = vo;
+            if (!(W44_ABL & 1)) Voff[j * TBW + wave * 64 + el] = vo;
         }
     };
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Raw;
@@ -292,77 +294,71 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                            : yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
         float* xw = Xs + (wave * 4 * 64 + el) * 4;
         const float* xr = Xs + ((wave ^ 1) * 4 * 64 + el) * 4;
+        // one round = one cout group j and one PAIR of output columns cp, both register pairs h of the accumulators: what a lane
+        // sends / keeps per output pixel is then the float4 of 4 consecutive couts it stores (16-byte stores: the four lanes of a
+        // pixel write 64 contiguous bytes; 8-byte stores were measured at +115 us per launch), and nothing has to be kept
+        // across rounds.  The price: the row sums a, b, cc, d are computed in both rounds of a j (+12 packed operations).
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            f32x2 keep[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x2 Wm[3][4];
+            for (int cp = 0; cp < 2; ++cp) {
+                __builtin_amdgcn_sched_barrier(0);            // one round at a time
+                f32x4 mine[4], send[4];                       // [output row of the half (2)][column of the pair (2)]
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr) {
-                    f32x2 m[6];
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 Wm[3][2];
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) m[c] = (f32x2){acc[rr * 6 + c][j][2 * h], acc[rr * 6 + c][j][2 * h + 1]};
-                    const f32x2 a = m[1] + m[2], b = m[1] - m[2], cc = m[3] + m[4], d = m[3] - m[4];
-                    Wm[rr][0] = (m[0] + a) + cc;
-                    Wm[rr][1] = fma2(d, 2.0f, b);
-                    Wm[rr][2] = fma2(cc, 4.0f, a);
-                    Wm[rr][3] = fma2(d, 8.0f, b) + m[5];
-                }
-                f32x2 mine[8], send[8];
-                if (RG == 0) {
+                    for (int rr = 0; rr < 3; ++rr) {
+                        f32x2 m[6];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f32x2 s = Wm[1][c] + Wm[2][c], dd = Wm[1][c] - Wm[2][c];
-                        mine[c] = Wm[0][c] + s;
-                        mine[4 + c] = dd;
-                        send[c] = s;
-                        send[4 + c] = dd;
+                        for (int c = 0; c < 6; ++c) m[c] = (f32x2){acc[rr * 6 + c][j][2 * h], acc[rr * 6 + c][j][2 * h + 1]};
+                        const f32x2 a = m[1] + m[2], b = m[1] - m[2], cc = m[3] + m[4], d = m[3] - m[4];
+                        if (cp == 0) {
+                            Wm[rr][0] = (m[0] + a) + cc;
+                            Wm[rr][1] = fma2(d, 2.0f, b);
+                        } else {
+                            Wm[rr][0] = fma2(cc, 4.0f, a);
+                            Wm[rr][1] = fma2(d, 8.0f, b) + m[5];
+                        }
                     }
-                } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f32x2 s = Wm[0][c] + Wm[1][c], dd = Wm[0][c] - Wm[1][c];
-                        send[c] = s;
-                        send[4 + c] = dd + dd;
-                        mine[c] = s * 4.0f;
-                        mine[4 + c] = fma2(dd, 8.0f, Wm[2][c]);
+                    for (int c = 0; c < 2; ++c) {
+                        f32x2 k0, k1, s0, s1;                 // kept rows (2), sent rows (2) of this column
+                        if (RG == 0) {
+                            const f32x2 s = Wm[1][c] + Wm[2][c], dd = Wm[1][c] - Wm[2][c];
+                            k0 = Wm[0][c] + s; k1 = dd; s0 = s; s1 = dd;
+                        } else {
+                            const f32x2 s = Wm[0][c] + Wm[1][c], dd = Wm[0][c] - Wm[1][c];
+                            s0 = s; s1 = dd + dd; k0 = s * 4.0f; k1 = fma2(dd, 8.0f, Wm[2][c]);
+                        }
+                        mine[c][2 * h] = k0.x; mine[c][2 * h + 1] = k0.y;
+                        mine[2 + c][2 * h] = k1.x; mine[2 + c][2 * h + 1] = k1.y;
+                        send[c][2 * h] = s0.x; send[c][2 * h + 1] = s0.y;
+                        send[2 + c][2 * h] = s1.x; send[2 + c][2 * h + 1] = s1.y;
                     }
                 }
 #if W44_ABL & 8192     // timing experiment: no exchange
 #pragma unroll
-                for (int q = 0; q < 8; ++q) mine[q] += send[q];
+                for (int q = 0; q < 4; ++q) mine[q] += send[q];
 #else
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<f32x4*>(xw + q * 256) = (f32x4){send[2 * q].x, send[2 * q].y, send[2 * q + 1].x, send[2 * q + 1].y};
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(xw + q * 256) = send[q];
                 lds_barrier();
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 got = *reinterpret_cast<const f32x4*>(xr + q * 256);
-                    mine[2 * q] += (f32x2){got.x, got.y};
-                    mine[2 * q + 1] += (f32x2){got.z, got.w};
-                }
-                if (!(j == 1 && h == 1)) lds_barrier();               // the partner has read before the next round overwrites
+                for (int q = 0; q < 4; ++q) mine[q] += *reinterpret_cast<const f32x4*>(xr + q * 256);
+                if (!(j == 1 && cp == 1)) lds_barrier();              // the partner has read before the next round overwrites
 #endif
-                if (h == 0) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) keep[e] = mine[e];
-                } else {
-                    // 16-byte stores: the four lanes of a pixel (mq) write 64 contiguous bytes.  (8-byte stores of each half
-                    // as soon as it is ready were measured at +115 us per launch: half-sector writes.)
+                for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            f32x4 val = {keep[rr * 4 + c].x, keep[rr * 4 + c].y, mine[rr * 4 + c].x, mine[rr * 4 + c].y};
-                            if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
-                            if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + c < W)
-                                __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(
-                                    OUT_BLK ? o + 2 * j * plane + (int64_t)rr * tiles_x * 256 + 64 * ((c + 1) & 3)      // position 8 ((c+1)&3) + tx of the block
-                                            : o + 16 * j + ((int64_t)rr * W + c) * 64));
-                        }
-                }
+                    for (int c = 0; c < 2; ++c) {
+                        f32x4 val = mine[rr * 2 + c];
+                        if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
+                        if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + 2 * cp + c < W)
+                            __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(
+                                OUT_BLK ? o + 2 * j * plane + (int64_t)rr * tiles_x * 256 + 64 * ((2 * cp + c + 1) & 3)  // position 8 ((col+1)&3) + tx of the block
+                                        : o + 16 * j + ((int64_t)rr * W + 2 * cp + c) * 64));
+                    }
             }
         }
     };
