@@ -40,8 +40,9 @@
 // against fp64 (F(2x2,3x3): 2.1e-7); end to end the FFDNet gates do not move (tools/f44_numerics.py,
 // profiles/r02_f44_numerics.jsonl).  64 images of 128 x 128: 262 us against 314 us for F(2x2,3x3) on the same box; where the
 // rest goes (tools/w44_variants.sh + w44_check.py, profiles/r02_w44_*): MFMA phases alone 158 us, input transform +50,
-// weight DMA +10..25, raw DMA +70 (the scattered 16-byte units of the LDS-DMA path cost ~1.6 cycles each, contiguous ones
-// 0.08), output transform + exchange + stores +35.
+// weight DMA +10, raw DMA +15, output transform + exchange + stores +25.  (W44_ABL=1, "no raw DMA", once measured 190 us:
+// hipcc had deleted the input transform together with it - a shared array that nothing writes.  Count the instructions of a
+// stage before believing an ablation.)
 #include "common.hpp"
 #include <hip/hip_ext.h>
 #include <type_traits>
