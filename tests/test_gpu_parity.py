@@ -876,6 +876,31 @@ def test_config2_ffdnet_anderson_180_all_measurements():
     assert avg_band[0] <= avg <= avg_band[1], (avg, avg_band)
 
 
+def test_engine_conv_layout_and_kernel_choice():
+    """The engine's 64->64 layers: with the activations kept in the F(4x4,3x3) kernel's own layout between layers (the
+    default) the reconstruction is BIT-identical to the same kernel on channels_last tensors (same arithmetic, other
+    addresses); with the F(2x2,3x3) kernel forced it agrees to the rounding of the two algorithms."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)[:2]            # 2 measurements = 16 images of 128x128: F(4x4) territory
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 6)[0].nonlinear_op
+    assert _hip.conv64_kernel_for(16, 128, 128) == "f44"
+    eng = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    assert eng.den.blk32
+    a = eng.reconstruct(ys, Phi).clone()
+    eng.den.blk32 = False
+    b = eng.reconstruct(ys, Phi).clone()
+    eng.den.blk32 = True
+    assert torch.equal(a, b)
+    old = _hip.FORCE_CONV64
+    try:
+        _hip.FORCE_CONV64 = "f22"
+        c = eng.reconstruct(ys, Phi).clone()
+    finally:
+        _hip.FORCE_CONV64 = old
+    assert not torch.equal(a, c) and rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 2e-5
+
+
 def test_engine_graph_replay_is_bit_identical_to_eager():
     """The hipGraph path replays the same kernels with the same arguments: first call of a shape eager, second captured,
     later ones replayed with new inputs - all bit-identical to an engine that never uses a graph; and when the tolerance
