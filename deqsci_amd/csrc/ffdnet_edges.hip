@@ -226,6 +226,82 @@ __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict
     }
 }
 
+// The same head on the fp32 matrix cores (large launches): per group of 16 neighbouring positions a 64 x 48 x 16 product
+//   D[cout][position] = sum_k W[cout][k] * P[k][position],   k = 9 sigma taps (+3 empty) | 4 sub-pixel channels x 9 taps,
+// i.e. 48 v_mfma_f32_16x16x4_f32 (4 cout groups x 12 k-steps) instead of 90 packed FMAs per position and lane: the vector ALU is
+// left with one LDS gather per k-step (the P operand: lane (k, position) reads ITS tap of ITS position from the patch), the
+// ReLU and the 16-byte stores.  A wave keeps all 48 weight operands in registers and walks 16 groups of its 32 x 32 tile.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+#ifndef HEAD_ST
+#define HEAD_ST st4
+#endif
+__global__ __launch_bounds__(TB) void ffdnet_head_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wq,
+                                                              const float* __restrict__ sigma, int sigma_stride,
+                                                              float* __restrict__ h, int H, int W) {
+    constexpr int T = 32, P = 2 * T + 4, PS = P + 2, SS = T + 3;
+    constexpr int SGM = P * PS;                                   // the sigma plane sits behind the patch in one LDS array
+    __shared__ __attribute__((aligned(16))) float lds[P * PS + (T + 2) * SS];
+    const int n = blockIdx.z;
+    const int r0 = blockIdx.y * T, c0 = blockIdx.x * T;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* xn = x + (int64_t)n * H2 * W2;
+    for (int e = threadIdx.x; e < P * P; e += TB) {
+        const int pr = e / P, pc = e % P;
+        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
+        lds[pr * PS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
+    }
+    const float sig = sigma[(int64_t)n * sigma_stride];
+    for (int e = threadIdx.x; e < (T + 2) * (T + 2); e += TB) {
+        const int pr = e / (T + 2), pc = e % (T + 2);
+        const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
+        lds[SGM + pr * SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pn = lane & 15, kq = lane >> 4;
+    // weight operands (A: row = cout 16 cg + pn, column = k-slot 4 ks + kq) and the LDS offset of this lane's tap per k-step
+    float wa[4][12];
+    int off[12];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) {
+        const int slot = 4 * ks + kq;
+        const bool sg = ks < 3;
+        const int korig = sg ? slot : 9 + (slot - 12);             // index into the packed [ch*9+tap] weights
+        const bool valid = !sg || slot < 9;
+        const int tap = sg ? (valid ? slot : 0) : (slot - 12) % 9, ch = sg ? 0 : 1 + (slot - 12) / 9;
+        const int dr = tap / 3, dc = tap % 3;
+        off[ks] = sg ? SGM + dr * SS + dc + pn : (2 * dr + ((ch - 1) >> 1)) * PS + 2 * dc + ((ch - 1) & 1) + 2 * pn;
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) {
+            const int cout = 16 * cg + pn;
+            wa[cg][ks] = valid ? wq[(korig * 16 + (cout >> 2)) * 4 + (cout & 3)] : 0.0f;
+        }
+    }
+    __syncthreads();
+    float* hn = h + (int64_t)n * H * W * 64;
+#pragma unroll 1
+    for (int g = wave; g < T * T / 16; g += TB / 64) {
+        const int lr = g >> 1, lc0 = 16 * (g & 1);                 // 16 positions of row lr, columns lc0 .. lc0 + 15
+        const int gs = lr * SS + lc0, gp = 2 * lr * PS + 2 * lc0;  // (uniform) group offsets in the sigma plane / the patch
+        float pv[12];
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) pv[ks] = lds[off[ks] + (ks < 3 ? gs : gp)];
+        f32x4m acc[4];
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) acc[cg] = (f32x4m){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cg][ks], pv[ks], acc[cg], 0, 0, 0);
+        const int r = r0 + lr, c = c0 + lc0 + pn;
+        if (r < H && c < W) {
+            float* o = hn + ((int64_t)r * W + c) * 64 + 4 * kq;    // D: column = position pn, rows 4 kq .. 4 kq + 3 of the cout group
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg)
+                HEAD_ST(o + 16 * cg, make_float4(fmaxf(acc[cg][0], 0.0f), fmaxf(acc[cg][1], 0.0f), fmaxf(acc[cg][2], 0.0f), fmaxf(acc[cg][3], 0.0f)));
+        }
+    }
+}
+
 }  // namespace deqsci
 
 using namespace deqsci;
@@ -237,7 +313,11 @@ extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, con
     if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus()) {
+    static const int head_vector_only = [] { const char* e = getenv("DEQSCI_HEAD_VALU"); return e ? atoi(e) : 0; }();   // (A/B knob)
+    if (!head_vector_only && ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus()) {
+        const dim3 grid((unsigned)ceil_div(W, 32), (unsigned)ceil_div(H, 32), (unsigned)n);
+        hipLaunchKernelGGL(ffdnet_head_mfma_kernel, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
+    } else if (ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus()) {
         const dim3 grid((unsigned)ceil_div(W, 32), (unsigned)ceil_div(H, 32), (unsigned)n);
         hipLaunchKernelGGL(ffdnet_head_kernel<32>, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);
     } else {

@@ -442,10 +442,11 @@ def test_ffdnet_tail_kernel_vs_torch(shape):
     assert float((got_b.double() - want_b).norm() / want_b.norm()) < 1e-6
 
 
-@pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96), (130, 128, 128)])   # last: the 32 x 32 tile variant
+@pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96), (130, 128, 128), (140, 100, 124), (64, 256, 256)])   # last three: the matrix-core variant (>= 512 tiles of 32 x 32), ragged and not
 def test_ffdnet_head_kernel_vs_torch(shape):
     """sigma map + pixel_unshuffle + conv3x3(5->64) + ReLU as one HIP kernel vs the torch ops (incl. ragged
-    tiles, per-image sigma and the zero-padded sigma ring at the border)."""
+    tiles, per-image sigma and the zero-padded sigma ring at the border); small launches run the vector-ALU stencil,
+    large ones the MFMA formulation of the same sum."""
     import torch.nn.functional as Fn
     n, H2, W2 = shape
     g = torch.Generator(device=DEV).manual_seed(5)
