@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""BASELINE config 2 (FFDNet + Anderson @180) as ENSEMBLES on the HIP path: unperturbed x0 and x0 (1 + 1e-7 randn), seeds 1..8 (the
+recipe of the reference ensembles in tests/golden), for several engine configurations; prints the ensemble mean per measurement next
+to the two reference ensemble means.  `python tools/config2_ensemble.py [name=key:value,...] ...`"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import deqsci_amd  # noqa: E402
+from deqsci_amd import _hip, checkpoint  # noqa: E402
+from deqsci_amd.cli import build_pipeline  # noqa: E402
+from deqsci_amd.engine import DEQSCIEngine  # noqa: E402
+from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(ROOT, "data", "test_gray")
+
+
+def ensemble(eng):
+    out = {}
+    for clip in (as_clip(c) for c in SCITestDataset(DATA)):
+        Phi = clip["mask"].to("cuda")[None].contiguous()
+        for fi in scored_measurements(clip["file"], clip["meas"].shape[-1]):
+            y = clip["meas"][..., fi].to("cuda")[None].contiguous()
+            gt = clip["gt"][..., 8 * fi:8 * fi + 8].numpy()
+            x0 = deqsci_amd.initial_point(y, Phi, None, None)
+            ps = []
+            for seed in range(9):
+                xs = x0 if seed == 0 else x0 * (1 + 1e-7 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(seed))).to("cuda")
+                ps.append(psnr(eng.reconstruct(y, Phi, initial_point=xs).clamp(0, 1).cpu().numpy()[0], gt))
+            out[f"{clip['file']}:{fi}"] = ps
+    return out
+
+
+def main():
+    a = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")))["measurements"]
+    b = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json")))["measurements"]
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
+    configs = {"default (F(4x4) conv)": {}, "F(2x2) conv": {"force": "f22"}, "MIOpen direct conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}}
+    res = {}
+    for name, c in configs.items():
+        _hip.FORCE_CONV64 = c.get("force")
+        eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, **c.get("kw", {}))
+        res[name] = ensemble(eng)
+        _hip.FORCE_CONV64 = None
+    rows = {}
+    for mid in a:
+        ra = [v["psnr"] for v in a[mid]["variants"].values()]
+        rb = [v["psnr"] for v in b[mid]["variants"].values()]
+        rows[mid] = {"reference fp32 Gram mean": round(float(np.mean(ra)), 4), "reference exact Gram mean": round(float(np.mean(rb)), 4),
+                     **{k: {"mean": round(float(np.mean(v[mid])), 4), "min": round(min(v[mid]), 4), "max": round(max(v[mid]), 4)} for k, v in res.items()}}
+        print(mid, json.dumps(rows[mid]))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "config2_ensemble.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
