@@ -457,6 +457,8 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
     out_blk=True: Winograd F(4x4,3x3), the large-batch kernel.  events: (start, stop) raw hipEvent_t handles (measurement)."""
     if isinstance(x, Blk32):
         n, H, W, xt, in_l = x.n, x.H, x.W, x.t, ACT_BLK32
+        if tuple(xt.shape) != (n, 8, H, -(-W // 32), 32, 8) or not xt.is_contiguous():
+            raise DeqsciHipError(f"conv3x3_c64_winograd44: malformed Blk32 {tuple(xt.shape)} for (n, H, W) = {(n, H, W)}")
     else:
         n, c, H, W = x.shape
         if c != 64 or not x.is_contiguous(memory_format=torch.channels_last):
@@ -466,9 +468,14 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
         raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
     if out_blk:
         o = out if out is not None else Blk32.empty(n, H, W, xt.device)
+        if not isinstance(o, Blk32) or (o.n, o.H, o.W) != (n, H, W) or o.t.device != xt.device or not o.t.is_contiguous():
+            raise DeqsciHipError("conv3x3_c64_winograd44: out must be a Blk32 of the input's (n, H, W) on its device")
         ot = o.t
     else:
         o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=xt.device, memory_format=torch.channels_last)
+        if (isinstance(o, Blk32) or tuple(o.shape) != (n, 64, H, W) or o.dtype != torch.float32 or o.device != xt.device
+                or not o.is_contiguous(memory_format=torch.channels_last)):
+            raise DeqsciHipError("conv3x3_c64_winograd44: out must be a fp32 channels_last (n,64,H,W) tensor on the input's device")
         ot = o
     ev = events if events is not None else (None, None)
     with _dev(xt):

@@ -257,3 +257,18 @@ def test_cli_accepts_every_reference_flag():
     assert a.and_maxiters == 180 and a.and_m == 4 and a.etainit == 0.9 and a.sigma == 10 and a.gpu_ids == "0,1"
     with pytest.raises(NotImplementedError):
         cli_main(["--denoiser", "unet"])
+
+
+def test_blk32_layout_helpers():
+    """Blk32 (the F(4x4,3x3) kernel's own activation layout): host-side conversion both ways, padding columns, position table."""
+    import torch
+    from deqsci_amd import _hip
+    x = torch.randn(2, 64, 5, 45)
+    b = _hip.Blk32.from_nchw(x)
+    assert tuple(b.t.shape) == (2, 8, 5, 2, 32, 8) and (b.n, b.H, b.W) == (2, 5, 45)
+    assert torch.equal(b.to_nchw(), x.contiguous(memory_format=torch.channels_last))
+    pos = _hip.Blk32._pos()
+    assert sorted(pos.tolist()) == list(range(32)) and pos[:5].tolist() == [8, 16, 24, 0, 9]      # column m -> 8 ((m+1)&3) + ((m+1)>>2) - [(m+1)&3 == 0]
+    # pixel (n=1, channel 13, row 3, column 37) -> chunk 1, channel 5 of the chunk, block 1, column 5 of the block
+    assert float(b.t[1, 1, 3, 1, int(pos[5]), 5]) == float(x[1, 13, 3, 37])
+    assert bool(torch.isnan(b.t[:, :, :, 1][:, :, :, pos][:, :, :, 13:]).all())                    # columns >= 45 of the last block: padding
