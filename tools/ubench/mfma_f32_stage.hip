@@ -2,6 +2,7 @@
 // streamed from LDS by one ds_read_b128 per position (PF positions ahead), optional patch reads (ds_read_b64) and optional
 // LDS-DMA pieces, in several instruction orders.  One or two waves per SIMD.  Prints cycles per MFMA.
 //   ORDER 0: reads + wait clustered before the four MFMAs (round-1 order)     ORDER 1: one instruction per MFMA gap
+//   ORDER 4 / 5: the operand reads issued in pairs / quads (every 8 / 16 MFMAs)
 //   ORDER 2: no LDS traffic at all (A operands constant)                      ORDER 3: as 1 but the wait right after the b128 of 2 positions ago
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256 * WAVES, 1) void k(float* out, unsigned long lo
     const float* pp = R + (threadIdx.x & 63) * 2;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
-        float4 bq[PF + 1];
+        float4 bq[PF + 4];
         if (ORDER != 2) {
 #pragma unroll
             for (int i = 0; i < PF; ++i) bq[i] = *reinterpret_cast<const float4*>(ub + i * 1024);
@@ -37,11 +38,20 @@ __global__ __launch_bounds__(256 * WAVES, 1) void k(float* out, unsigned long lo
         SB();
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
+            if (ORDER == 4 && (xi & 1) == 0) {                       // two positions' operands at once, PF positions ahead
+                if (xi + PF < 16) bq[(xi + PF) % (PF + 2)] = *reinterpret_cast<const float4*>(ub + (xi + PF) * 1024);
+                if (xi + PF + 1 < 16) bq[(xi + PF + 1) % (PF + 2)] = *reinterpret_cast<const float4*>(ub + (xi + PF + 1) * 1024);
+            }
+            if (ORDER == 5 && (xi & 3) == 0) {                       // four at once
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (xi + PF + u < 16) bq[(xi + PF + u) % (PF + 4)] = *reinterpret_cast<const float4*>(ub + (xi + PF + u) * 1024);
+            }
             if (ORDER == 0) {
                 if (xi + PF < 16) bq[(xi + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (xi + PF) * 1024);
                 if (PATCH && (xi & 1) == 0) { v[(xi + 14) & 15] = *reinterpret_cast<const f32x2*>(pp + xi * 128); v[(xi + 15) & 15] = *reinterpret_cast<const f32x2*>(pp + xi * 128 + 400); }
             }
-            const float4 b = bq[xi % (PF + 1)];
+            const float4 b = bq[xi % (ORDER == 4 ? PF + 2 : ORDER == 5 ? PF + 4 : PF + 1)];
             SB();
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, v[xi].x, acc[xi][0], 0, 0, 0);
             SB();
@@ -77,6 +87,7 @@ template <int ORDER, int PATCH, int WAVES, int PF> int run() {
 int main() {
     CK(hipMalloc(&g_out, 256 * 512 * 4)); CK(hipMalloc(&g_cyc, 256 * 8 * 8));
     run<2, 0, 1, 2>(); run<0, 0, 1, 2>(); run<0, 1, 1, 2>(); run<1, 0, 1, 2>(); run<1, 1, 1, 2>(); run<1, 1, 1, 3>(); run<0, 1, 1, 4>();
+    run<4, 0, 1, 2>(); run<5, 0, 1, 4>(); run<4, 0, 2, 2>(); run<5, 0, 2, 4>();
     run<2, 0, 2, 2>(); run<0, 0, 2, 2>(); run<0, 1, 2, 2>(); run<1, 0, 2, 2>(); run<1, 1, 2, 2>(); run<1, 1, 2, 3>(); run<0, 1, 2, 4>();
     return 0;
 }
