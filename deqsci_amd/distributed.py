@@ -17,7 +17,6 @@ the end assembles the (M,H,W,B) result on every rank.  One process per GPU.
 import os
 import socket
 import subprocess
-import sys
 import time
 
 import torch

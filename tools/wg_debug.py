@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where is a Winograd variant wrong?  Error map by image / row / column / channel for small shapes."""
-import ctypes, os, sys
+import os, sys
 import torch
 import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
