@@ -194,19 +194,29 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Raw;
     // chunk c of the fetch tile -> Raw[buf]: the scalar offset selects the 8 channels (32 bytes) of the chunk; ONE M0 value per
     // wave (writing M0 between two LDS-DMA instructions costs ~100 cycles each: measured)
-    auto dma_raw = [&](int c, int buf) {
-        if (W44_ABL & 1) return;
-        const uint32_t soff = uniform(IN_BLK ? (uint32_t)c * (uint32_t)(H * tiles_x) * 1024u : (uint32_t)c * (CK * 4));   // chunk plane / channel offset
+    // One chunk tile = three instructions per wave.  Inside the pipeline they are issued ONE AT A TIME from within an MFMA part
+    // (raw_begin, then raw_piece(j) between MFMAs): all eight waves issuing their three right behind a barrier kept every wave
+    // waiting at the memory pipeline's door for ~1000 cycles per stage with the matrix pipe idle (tools/w44_stamps.py).
+    struct RawDma { uint32_t soff, m0v, v[3]; };
+    auto raw_begin = [&](int c, int buf) -> RawDma {
+        RawDma d;
+        d.soff = uniform(IN_BLK ? (uint32_t)c * (uint32_t)(H * tiles_x) * 1024u : (uint32_t)c * (CK * 4));   // chunk plane / channel offset
         int w = wave;
         asm volatile("" : "+s"(w));                                // recompute the M0 value here (scalar ALU is free; SGPRs are not)
-        const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + 3 * (w < 7 ? w : 6) * 1024));
+        d.m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF * 4 + 3 * (w < 7 ? w : 6) * 1024));
         const int vl = w * 64 + lane_id();
-        const uint32_t v0 = Voff[vl], v1 = Voff[TBW + vl], v2 = Voff[2 * TBW + vl];
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
-                     "buffer_load_dwordx4 %1, %4, %5 offen lds\n\t"
-                     "buffer_load_dwordx4 %2, %4, %5 offen offset:1024 lds\n\t"
-                     "buffer_load_dwordx4 %3, %4, %5 offen offset:2048 lds"
-                     ::"s"(m0v), "v"(v0), "v"(v1), "v"(v2), "s"(rsrc), "s"(soff) : "memory", "m0");
+        d.v[0] = Voff[vl]; d.v[1] = Voff[TBW + vl]; d.v[2] = Voff[2 * TBW + vl];
+        return d;
+    };
+    auto raw_piece = [&](const RawDma& d, int j) __attribute__((always_inline)) {
+        if (W44_ABL & 1) return;
+        if (j == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(d.m0v), "v"(d.v[0]), "s"(rsrc), "s"(d.soff) : "memory", "m0");
+        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(d.m0v), "v"(d.v[1]), "s"(rsrc), "s"(d.soff) : "memory", "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(d.m0v), "v"(d.v[2]), "s"(rsrc), "s"(d.soff) : "memory", "m0");
+    };
+    auto dma_raw = [&](int c, int buf) {                           // (prologue: all three at once)
+        const RawDma d = raw_begin(c, buf);
+        raw_piece(d, 0); raw_piece(d, 1); raw_piece(d, 2);
     };
 
     // ---- weight chunk: host-packed in LDS order; half 1 = bytes [0, 40 KiB), half 2 = [40 KiB, 72 KiB); wave w moves a
@@ -377,7 +387,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
 
     // One stage = chunk c of the current tile.  PAR = c&1: Raw[PAR^1] holds raw(c+1), Raw[PAR] is receiving raw(c+2).
     // Vector memory operations of a wave, in issue order: behind X2 of the previous stage [second half of U(c) x4, (last stage
-    // of a tile: the 16 output stores,) raw(c+2) x3]; behind X1 [(first stage of a tile: raw(2) x3,) first half of U(c+1) x5].
+    // of a tile: the 16 output stores)]; from inside the first MFMA part [raw(c+2) x3]; behind X1 [first half of U(c+1) x5];
+    // (first stage of a tile: raw(2) x3 from inside the second MFMA part instead).
     // vmcnt(3) in front of X1 = the weights are in (the raw tile may still be landing: it is needed behind X1 of the NEXT
     // stage), vmcnt(0) in front of X2.  A register spill inside the loop would be a scratch access = one more vector memory
     // operation (the counts stay safe: extra younger operations only make a wait stricter) with a vmcnt(0) in front of its
@@ -426,10 +437,16 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
 #pragma unroll
         for (int i = 0; i < PF; ++i) bq[i] = *reinterpret_cast<const float4*>(ub + i * U_STEP);
         __builtin_amdgcn_sched_barrier(0);
+        // raw(c+2) -> Raw[PAR] (free since X2 of the previous stage; read behind X1 of the next one), one instruction every other
+        // position.  Not in the first stage of a tile: there the previous tile's last transform may still be reading Raw[PAR] in
+        // a slower wave - it is issued from the second part, behind X1.
+        RawDma rd;
+        if (!FIRST) rd = raw_begin((c + 2) & 7, PAR);
 #pragma unroll
         for (int s = 0; s < SPLIT; ++s) {
             if (s + PF < SPLIT) bq[(s + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (s + PF) * U_STEP);
             W44_STEP(s);
+            if (!FIRST && (s == 1 || s == 3 || s == 5)) raw_piece(rd, s >> 1);
         }
         W44_MARK(0);                                          // first MFMA part
         // second half of U(c) in LDS; the raw fetch (3 operations, issued behind it) stays in flight.  Behind a tile that lies
@@ -439,8 +456,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         lds_barrier();                                        // X1: steps >= SPLIT of U(c) visible; everyone is done with steps < SPLIT
         W44_MARK(1);                                          // wait + X1
-        if (FIRST && t_cur != t_first) dma_raw(2, 0);         // (held back behind the previous tile's last transform: see the end of the stage)
         dma_half((c + 1) & 7, 0);
+        if (FIRST) rd = raw_begin(2, 0);
         // ---- second part: steps [SPLIT, 18)
 #pragma unroll
         for (int i = 0; i < PF; ++i) bq[(SPLIT + i) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (SPLIT + i) * U_STEP);
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         for (int s = SPLIT; s < NSTEP; ++s) {
             if (s + PF < NSTEP) bq[(s + PF) % (PF + 1)] = *reinterpret_cast<const float4*>(ub + (s + PF) * U_STEP);
             W44_STEP(s);
+            if (FIRST && (s == SPLIT + 1 || s == SPLIT + 3 || s == SPLIT + 5)) raw_piece(rd, (s - SPLIT) >> 1);
         }
         __builtin_amdgcn_sched_barrier(0);                    // (hipcc otherwise starts the transform above the MFMAs that still read v)
         // (the last stage of a tile transforms BEHIND the epilogue: V would otherwise be live across it, 36 registers too many)
@@ -469,9 +487,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             if (t_fetch + t_step < t_end) t_fetch += t_step;  // (past the end of the run: stay, the fetches are dummies)
             set_fetch_tile(t_fetch);
         }
-        // raw(c+3) into the buffer raw(c+1) has just been read from - except behind the last stage of a tile, whose transform
-        // (behind the epilogue) may still be reading it in a slower wave: that fetch is issued behind X1 of the next stage
-        if (c != 7) dma_raw((c + 3) & 7, PAR ^ 1);
+
+        W44_MARK(4);                                          // DMA issue, tile switch, once per tile: output transform + last input transform
     };
     using std::integral_constant;
     // the two row groups run two separate copies of prologue + loop: with `rg` a run-time value hipcc keeps both arms of every
@@ -489,7 +506,6 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         __syncthreads();
         transform(rg_c, 0);
         __syncthreads();                                          // everyone has read raw(0): the fetch of raw(2) may overwrite it
-        dma_raw(2, 0);
 #pragma unroll 1
         for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
             stage(rg_c, integral_constant<int, 0>{}, integral_constant<bool, true>{}, 0, t_cur);
@@ -504,7 +520,6 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     if (rg == 0) run(integral_constant<int, 0>{}); else run(integral_constant<int, 1>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef W44_STAMP
-    W44_MARK(4);                                              // (everything else: epilogue, DMA issue, tile switch)
     if (lane_id() == 0)
         for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
 #endif

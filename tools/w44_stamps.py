@@ -21,7 +21,7 @@ for _ in range(3):
     _hip.conv3x3_c64_winograd44(x, U, stamps.view(torch.float32), True, out=out)
 torch.cuda.synchronize()
 s = stamps.view(256, 8, 5).double().cpu()
-names = ["mfma part 1", "wait + X1", "mfma part 2 + transform", "wait + X2", "rest (epilogue, DMA issue)"]
+names = ["mfma part 1", "wait + X1", "mfma part 2 + transform", "wait + X2", "DMA issue + (1 stage in 8) output transform, last input transform"]
 tot = s.sum(-1)
 print("cycles per wave over the launch: mean %.0f (min %.0f max %.0f); 64 stages per workgroup" % (tot.mean(), tot.min(), tot.max()))
 for i, nme in enumerate(names):
