@@ -38,7 +38,7 @@
 //     issued between the weight DMA and the raw DMA of the next stage so that no wait in the MFMA loop covers them.
 // LDS: 72 KB weights + 2 x 21 KB raw + 32 KB exchange + 6 KB DMA offsets + bias = 152.3 KB.  Rounding: 1.2-1.7e-6 per layer
 // against fp64 (F(2x2,3x3): 2.1e-7); end to end the FFDNet gates do not move (tools/f44_numerics.py,
-// profiles/r02_f44_numerics.jsonl).  64 images of 128 x 128: 262 us against 314 us for F(2x2,3x3) on the same box; where the
+// profiles/r02_f44_numerics.jsonl).  64 images of 128 x 128: 242-245 us against 303-314 us for F(2x2,3x3) on the same box; where the
 // rest goes (tools/w44_variants.sh + w44_check.py, profiles/r02_w44_*): MFMA phases alone 158 us, input transform +50,
 // weight DMA +10, raw DMA +15, output transform + exchange + stores +25.  (W44_ABL=1, "no raw DMA", once measured 190 us:
 // hipcc had deleted the input transform together with it - a shared array that nothing writes.  Count the instructions of a
