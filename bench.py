@@ -332,7 +332,11 @@ def run_rank(args):
                                "bound": "mfma", "achieved": direct / red / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
                                "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
-                               "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3)}
+                               "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3),
+                               "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer (round 1: F(2x2,3x3), frac 0.70-0.72 at "
+                                        "306-314 us per launch of this shape): frac prices executed MFMA work, avg_launch_us and "
+                                        "direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
+                                        "F(2x2,3x3): the launcher's choice below one wave of F(4x4,3x3) block tiles")}
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]
         if timing:
