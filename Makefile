@@ -16,7 +16,15 @@ $(LIB): $(SRCS) $(HDRS)
 $(ORACLE_LIB): oracle/deqsci_oracle.c include/deqsci_hip.h
 	gcc -O2 -std=c11 -fPIC -shared -ffp-contract=off -Iinclude -o $@ oracle/deqsci_oracle.c -lm
 
-clean:
-	rm -f $(LIB) $(ORACLE_LIB)
+# diagnostic variant for tools/ (env knobs DEQSCI_GRAM_NOISE, DEQSCI_K4_BLOCKS, DEQSCI_FORCE_POLICY, DEQSCI_HEAD_VALU); never loaded by the
+# package unless DEQSCI_HIP_LIB points at it
+DIAG_LIB   := build/diag/libdeqsci_hip_diag.so
+diag: $(DIAG_LIB)
+$(DIAG_LIB): $(SRCS) $(HDRS)
+	@mkdir -p build/diag
+	$(HIPCC) $(HIPFLAGS) -DDEQSCI_DIAG -shared -o $@ $(SRCS)
 
-.PHONY: all clean
+clean:
+	rm -f $(LIB) $(ORACLE_LIB) $(DIAG_LIB)
+
+.PHONY: all clean diag

@@ -10,9 +10,11 @@ reference algorithm timed on the host CPU.
 One "step" = one full reconstruction pass (x0 = Phi^T y, max_iter+1 f-calls, final all-gather) over
 one synthetic batch of `--batch-per-gpu` measurements per GPU (SURVEY 8(d) C3 recipe: Bernoulli(0.5)
 masks, x ~ U[0,1), y = Phi x, seed 1234), inputs resident in HBM when the timed region starts.
-Weak scaling: the per-GPU batch is fixed (BASELINE config 3: 64 measurements over 8 GPUs = 8 per GPU,
-which is also the 8 shipped measurements of config 2 at N=1).  The global batch is sharded by
-deqsci_amd.distributed.sharded_reconstruct (contiguous slices, no data-path collective, ONE all-gather).
+Weak scaling (default): the per-GPU batch is fixed (BASELINE config 3: 64 measurements over 8 GPUs = 8 per GPU,
+which is also the 8 shipped measurements of config 2 at N=1).  Strong scaling: `--global-batch 64` fixes the
+total instead (64/N per GPU, BASELINE config 3 as stated).  Either way measurement i of the global batch is
+generated from seed (1234, i) by the rank that owns it - no rank ever holds the global batch - and the shards go
+through deqsci_amd.distributed.reconstruct_shard (contiguous slices, no data-path collective, ONE all-gather).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -44,10 +46,17 @@ def gap_bytes(bsz, H, W, B):
     return bsz * H * W * (12 * B + 8)
 
 
-def make_batch(bsz, H, W, B, seed, device):
-    g = torch.Generator(device=device).manual_seed(seed)
-    Phi = (torch.rand(bsz, H, W, B, device=device, generator=g) < 0.5).float()
-    x = torch.rand(bsz, H, W, B, device=device, generator=g)
+def make_batch(lo, hi, H, W, B, seed, device):
+    """Measurements [lo, hi) of the synthetic global batch (Phi ~ Bernoulli(0.5), x ~ U[0,1), y = Phi x).  Each
+    measurement has its own generator seeded by its GLOBAL index, so a rank builds exactly its slice and the batch does not
+    depend on how it is sharded."""
+    n = max(hi - lo, 0)
+    Phi = torch.empty(n, H, W, B, device=device)
+    x = torch.empty(n, H, W, B, device=device)
+    for j in range(n):
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + lo + j)
+        Phi[j] = (torch.rand(H, W, B, device=device, generator=g) < 0.5).float()
+        x[j] = torch.rand(H, W, B, device=device, generator=g)
     y = (x * Phi).sum(3)
     return y, Phi, x
 
@@ -139,7 +148,13 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=8)
+    ap.add_argument("--batch-per-gpu", type=int, default=8, help="weak scaling (default): measurements per GPU")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: total number of measurements, sharded over the GPUs (BASELINE config 3: 64)")
+    ap.add_argument("--conv64", default="auto", choices=["auto", "fast", "f22", "f44"],
+                    help="Winograd form of the 64->64 layers (DEQSCIEngine): auto = F(2x2,3x3) for FFDNet + Anderson beyond 30 "
+                         "iterations (parity-neutral), the faster kernel per launch otherwise")
+    ap.add_argument("--no-other-kernel", action="store_true", help="skip the one extra step with the other conv64 policy")
     ap.add_argument("--iters", type=int, default=180)
     ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
     ap.add_argument("--size", default="256x256x8")
@@ -159,7 +174,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def build_engine(args, dev):
+def build_engine(args, dev, conv64=None):
     from deqsci_amd import checkpoint
     from deqsci_amd.cli import build_denoiser
     from deqsci_amd.engine import DEQSCIEngine
@@ -174,14 +189,15 @@ def build_engine(args, dev):
         kw["use_graph"] = False
     return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                         channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
-                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd, **kw)
+                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
+                        conv64=args.conv64 if conv64 is None else conv64, **kw)
 
 
-def make_step(eng, y_global, Phi_global, gather_timer):
-    """One bench step = the product's multi-GPU entry point on the global batch: this rank's contiguous slice through
-    the engine, then the path's one all-gather (identity at world size 1)."""
+def make_step(eng, y_local, Phi_local, M, gather_timer):
+    """One bench step = the product's multi-GPU entry point: this rank's contiguous slice of the M measurements through the
+    engine, then the path's one all-gather (identity at world size 1)."""
     def step():
-        return distributed.sharded_reconstruct(eng.reconstruct, y_global, Phi_global, timer=gather_timer)
+        return distributed.reconstruct_shard(eng.reconstruct, y_local, Phi_local, M, timer=gather_timer)
     return step
 
 
@@ -193,17 +209,20 @@ def run_rank(args):
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     H, W, B = (int(v) for v in args.size.split("x"))
-    bsz = args.batch_per_gpu
+    strong = args.global_batch > 0
+    M = args.global_batch if strong else world * args.batch_per_gpu          # measurements of the whole job
+    lo, hi, per = distributed.shard_bounds(M, world, rank)
+    bsz = hi - lo                                                            # this rank's
     if selftest:
         eng = _PlumbingStub(args.iters)
         _hip = None
     else:
         from deqsci_amd import _hip
         eng = build_engine(args, dev)
-    # the GLOBAL batch, generated identically on every rank (seed 1234); sharded_reconstruct cuts rank r's slice
-    y, Phi, _ = make_batch(world * bsz, H, W, B, 1234, dev)
+    # this rank's slice [lo, hi) of the global batch, generated here by global measurement index
+    y, Phi, _ = make_batch(lo, hi, H, W, B, 1234, dev)
     gather_timer = distributed.GatherTimer()
-    step = make_step(eng, y, Phi, gather_timer)
+    step = make_step(eng, y, Phi, M, gather_timer)
 
     # per-launch timing of the fused Phi/Phi^T+GAP-update kernel and of the Winograd conv from the dispatch's own
     # HIP-event timestamps (hipExtLaunchKernelGGL start/stop events on the stream the kernel runs on); all events are
@@ -230,10 +249,10 @@ def run_rank(args):
         _hip.anderson_mix_gap = timed_mix_gap
         orig_wg = _hip.conv3x3_c64
 
-        def timed_conv64(x, weights, bias=None, relu=True, out=None, out_blk=False):
+        def timed_conv64(x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
             if not timing_on[0] or conv_timer.full:
-                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk)
-            o, kind = conv_timer.conv64(x, weights, bias, relu, out, out_blk=out_blk)
+                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
+            o, kind = conv_timer.conv64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
             conv_shape[:] = ([x.n, x.H, x.W] if isinstance(x, _hip.Blk32) else [x.shape[0], x.shape[2], x.shape[3]]) + [kind]
             return o
         _hip.conv3x3_c64 = timed_conv64
@@ -263,23 +282,27 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    frames = world * bsz * B * args.steps
+    frames = M * B * args.steps
     value = frames / elapsed
-    f_calls = eng.last_info["f_calls"]
+    info = eng.last_info or {}                                               # (an idle rank - more GPUs than measurements - never ran)
+    f_calls = info.get("f_calls")
     out = {
         "metric": "reconstructed frames/sec at 256x256x8, 180 DEQ iters",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"synthetic batch of {bsz} measurements per GPU, {H}x{W}x{B}, Bernoulli(0.5) masks "
+        "config": {"workload": (f"synthetic batch of {M} measurements sharded over {world} GPU(s) ({per} per GPU; BASELINE config 3 as stated), "
+                                if strong else f"synthetic batch of {per} measurements per GPU, ") + f"{H}x{W}x{B}, Bernoulli(0.5) masks "
                                f"(BASELINE config 3 per-GPU shard = config 2's 8 measurements at N=1); "
                                f"{args.denoiser} denoiser ({'net_gray.pth weights, substitute for the missing ffdnet.ckpt' if args.denoiser == 'ffdnet' else 'cnn.ckpt'}), "
                                f"Anderson m=5 lam=1e-2 beta=1, and_maxiters={args.iters}, tol=1e-5",
-                   "global_batch": world * bsz, "frames_per_measurement": B, "f_calls_per_step": f_calls,
+                   "global_batch": M, "batch_per_gpu": per, "frames_per_measurement": B, "f_calls_per_step": f_calls,
+                   "conv64_policy": None if selftest else f"{eng.conv64} -> {eng.conv64_policy}",
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU",
                    "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches"},
-        "final_res": eng.last_info["res"],
+        "final_res": info.get("res"),
         "allgather_ms_per_step": 1e3 * gather_timer.total_seconds() / max(args.steps, 1) if world > 1 else 0.0,
+        "allgather_bytes_per_step": world * per * H * W * B * 4 if world > 1 else 0,      # what every rank receives: (R*per,H,W,B) fp32
     }
     if args.ranks_share_gpu0:
         out["data"] = "synthetic; TEST RIG: all ranks share cuda:0 over gloo - not a throughput measurement"
@@ -292,7 +315,7 @@ def run_rank(args):
             avg_s = 1e-3 * sum(ms) / len(ms)
             nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
             traffic = None
-            for tname in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
+            for tname in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
                 tfile = os.path.join(ROOT, "profiles", tname)
                 if traffic is None and os.path.exists(tfile):
                     with open(tfile) as fh:
@@ -319,7 +342,8 @@ def run_rank(args):
             n_conv = 13 if args.denoiser == "ffdnet" else 2       # 64->64 layers per denoiser call (models.py:53-58 / SimpleCNN_models.py:47-53)
             share = cavg * n_conv * f_calls / (elapsed / args.steps)
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            for wname in (("r02_pmc_winograd44.json",) if kind == "f44" else ("r02_pmc_winograd.json", "r01_pmc_winograd.json")):
+            for wname in (("r03_pmc_winograd44.json", "r02_pmc_winograd44.json") if kind == "f44" else
+                          ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")):
                 wfile = os.path.join(ROOT, "profiles", wname)
                 if wtraffic is None and os.path.exists(wfile):
                     with open(wfile) as fh:
@@ -333,16 +357,34 @@ def run_rank(args):
                                "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
                                "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
                                "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3),
-                               "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer (round 1: F(2x2,3x3), frac 0.70-0.72 at "
-                                        "306-314 us per launch of this shape): frac prices executed MFMA work, avg_launch_us and "
-                                        "direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
-                                        "F(2x2,3x3): the launcher's choice below one wave of F(4x4,3x3) block tiles")}
+                               "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA "
+                                        "work, avg_launch_us and direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
+                                        "F(2x2,3x3): the parity-neutral form for FFDNet + Anderson beyond 30 iterations (conv64_policy), and the "
+                                        "launcher's choice below one wave of F(4x4,3x3) block tiles")}
+            out["config"]["conv64_kernel"] = kind
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]
         if timing:
             timer.close()
             conv_timer.close()
         if world == 1 and not selftest:
+            if not args.no_other_kernel and args.denoiser == "ffdnet" and not args.no_winograd:
+                # the same step with the OTHER conv64 policy, once, outside the timed region: the reader sees what the parity-neutral
+                # default costs (or what the throughput-first choice would buy) on this very box
+                other = "fast" if eng.conv64_policy == "f22" else "f22"
+                eng2 = build_engine(args, dev, conv64=other)
+                step2 = make_step(eng2, y, Phi, M, distributed.GatherTimer())
+                step2()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step2()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                out["other_conv64_policy"] = {"conv64_policy": other, "value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": 1,
+                                              "note": ("F(4x4,3x3) wherever it is faster: +throughput, but its rounding on noisy iterates moves the chaotic "
+                                                       "FFDNet + Anderson @180 ensemble by -0.02..-0.04 dB (profiles/r03_config2_ensembles.json), so it is opt-in "
+                                                       "there (--conv64 fast)") if other == "fast" else "F(2x2,3x3) everywhere"}
+                del eng2, step2
             if not args.no_hbm_stream:
                 del y, Phi
                 out["hbm_stream_roofline"] = hbm_stream_roofline(H, W, B, eng.m, dev)
@@ -357,10 +399,12 @@ def run_rank(args):
 def main(argv=None):
     args = parse_args(argv)
     if distributed.relaunch_needed(args.gpus):
-        # started as plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU (counting
-        # devices does not initialise it) and the ranks are NEW processes, one per GPU.
-        if not (args.plumbing_selftest or args.ranks_share_gpu0) and torch.cuda.device_count() < args.gpus:
-            sys.exit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        # started as plain `python bench.py --gpus N`: become the launcher.  Nothing above has touched the GPU and the ranks are
+        # NEW processes, one per GPU.
+        # (the parent never calls into HIP, not even to count devices: visibility variables / KFD topology only)
+        seen = distributed.visible_gpu_count()
+        if not (args.plumbing_selftest or args.ranks_share_gpu0) and seen is not None and seen < args.gpus:
+            sys.exit(f"--gpus {args.gpus} but only {seen} GPU(s) are visible")
         sys.exit(distributed.launch_ranks([sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv),
                                           args.gpus))
     run_rank(args)

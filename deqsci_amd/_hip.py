@@ -14,7 +14,8 @@ LAYOUT_BHW = 1   # (bsz,B,H,W)  planar / denoiser layout
 MAX_M = 8
 PART_STRIDE = MAX_M + 1
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdeqsci_hip.so")
+# DEQSCI_HIP_LIB: another build of the SAME library (tools only: the -DDEQSCI_DIAG variant of `make diag`, an ablation build)
+_LIB_PATH = os.environ.get("DEQSCI_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdeqsci_hip.so")
 _lib = None
 
 _i64, _int, _f32, _ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
@@ -377,6 +378,13 @@ def ffdnet_head(x, w_packed, sigma, out=None):
     return o
 
 
+def _check_packed(u_packed, positions, packer):
+    """The kernels DMA the whole transformed-weight array by size: a wrong pack (the other kernel's, a slice) would be read out of bounds."""
+    if not isinstance(u_packed, torch.Tensor) or u_packed.numel() != 64 * 64 * positions:
+        raise DeqsciHipError(f"u_packed must hold 64*64*{positions} floats (the output of _hip.{packer}), got "
+                             f"{tuple(getattr(u_packed, 'shape', ()))}")
+
+
 def pack_winograd_weights(w):
     """(64,64,3,3) conv weight -> U = G g G^T of Winograd F(2x2,3x3) in the kernel's MFMA-lane order
     [cin chunk c (8)][xi (16)][cout half wn (2)][q (4)][i (16)][j (2)][s (2)] with cout = 32 wn + 16 j + i and
@@ -394,6 +402,7 @@ def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):
     n, c, H, W = x.shape
     if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
         raise DeqsciHipError("conv3x3_c64_winograd: fp32 channels_last GPU activation with 64 channels required")
+    _check_packed(u_packed, 16, "pack_winograd_weights")
     o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
     with _dev(x):
         _check(load().deqsci_conv3x3_c64_winograd_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
@@ -466,6 +475,9 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
         xt, in_l = x, ACT_NHWC
     if xt.dtype != torch.float32 or not xt.is_cuda:
         raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
+    _check_packed(u_packed, 36, "pack_winograd44_weights")
+    if bias is not None and bias.numel() != 64:
+        raise DeqsciHipError(f"conv3x3_c64_winograd44: bias must have 64 elements, got {bias.numel()}")
     if out_blk:
         o = out if out is not None else Blk32.empty(n, H, W, xt.device)
         if not isinstance(o, Blk32) or (o.n, o.H, o.W) != (n, H, W) or o.t.device != xt.device or not o.t.is_contiguous():
@@ -502,7 +514,8 @@ def pack_conv64_weights(w):
 _T_TILE_F22, _T_TILE_F44 = 21.5, 35.5
 
 
-FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44": A/B runs and tests; default: the faster one per launch
+W44_MAX_PIXELS = (0x80000000 - 4096 - 2048 - 16) // 256   # per image, width padded to 32 columns
+FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44": A/B runs of the tools; overrides every policy below
 
 
 _CUS = {}
@@ -515,22 +528,31 @@ def _cus(device):
     return _CUS[idx]
 
 
-def conv64_kernel_for(n, H, W, device=None):
-    """'f44' or 'f22': the faster kernel for n images of H x W.  Both run one persistent workgroup per CU over block tiles of 16 x 16
-    (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3)) output pixels, so the time is (waves of block tiles) x (time of a tile)."""
+def conv64_kernel_for(n, H, W, device=None, policy="fast"):
+    """'f44' or 'f22' for n images of H x W.  policy "fast": the faster kernel of the launch - both run one persistent workgroup per
+    CU over block tiles of 16 x 16 (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3)) output pixels, so the time is (waves of block tiles) x (time of
+    a tile).  policy "f22": always F(2x2,3x3), whose rounding on noisy inputs (1.8e-7 per layer against float64; F(4x4,3x3) 5.5e-7, a
+    direct fp32 convolution 3e-7: tools/conv_error_real.py) is the one that leaves the chaotic FFDNet + Anderson runs where the
+    reference has them (DEQSCIEngine's `conv64="auto"`).  policy "f44": F(4x4,3x3) whatever the size."""
     if FORCE_CONV64 in ("f22", "f44"):
         return FORCE_CONV64
+    if policy in ("f22", "f44"):
+        return policy
+    if policy != "fast":
+        raise DeqsciHipError(f"conv64 policy {policy!r}: expected 'fast', 'f22' or 'f44'")
+    if H * (-(-W // 32)) * 32 > W44_MAX_PIXELS:          # beyond the F(4x4,3x3) kernel's 32-bit buffer offsets (csrc/winograd44.hip launcher)
+        return "f22"
     cus = _cus(device)
     t22 = -(-(n * (-(-H // 16)) * (-(-W // 16))) // cus) * _T_TILE_F22
     t44 = -(-(n * (-(-H // 16)) * (-(-W // 32))) // cus) * _T_TILE_F44
     return "f44" if t44 < t22 else "f22"
 
 
-def conv3x3_c64(x, weights, bias=None, relu=True, out=None, out_blk=False):
-    """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer with the faster of the two Winograd kernels (`weights` =
-    pack_conv64_weights(w)).  out_blk=True (only honoured by the F(4x4,3x3) kernel - check with conv64_kernel_for) leaves the
-    result in the blk32 layout for the next 64->64 layer; a Blk32 input is consumed as such."""
-    if isinstance(x, Blk32) or conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device) == "f44":
+def conv3x3_c64(x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
+    """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer with the Winograd kernel conv64_kernel_for(..., policy) names
+    (`weights` = pack_conv64_weights(w)).  out_blk=True (only honoured by the F(4x4,3x3) kernel - check with conv64_kernel_for)
+    leaves the result in the blk32 layout for the next 64->64 layer; a Blk32 input is consumed as such."""
+    if isinstance(x, Blk32) or conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device, policy) == "f44":
         return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk)
     return conv3x3_c64_winograd(x, weights.f22, bias, relu, out)
 
@@ -582,6 +604,7 @@ class KernelTimer:
         if ev is None:
             return self._plain_winograd(x, u_packed, bias, relu, out)
         n, c, H, W = x.shape
+        _check_packed(u_packed, 16, "pack_winograd_weights")
         o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
         with _dev(x):
             _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True),
@@ -589,13 +612,13 @@ class KernelTimer:
                    "conv3x3_c64_winograd_timed")
         return o
 
-    def conv64(self, x, weights, bias=None, relu=True, out=None, out_blk=False):
+    def conv64(self, x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
         """The timed counterpart of conv3x3_c64; returns (output, 'f22' | 'f44')."""
         blk = isinstance(x, Blk32)
-        kind = "f44" if blk else conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device)
+        kind = "f44" if blk else conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device, policy)
         ev = self._pair()
         if ev is None:
-            return conv3x3_c64(x, weights, bias, relu, out, out_blk=out_blk), kind
+            return conv3x3_c64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy), kind
         if kind == "f44":
             return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk, events=ev), kind
         n, c, H, W = x.shape

@@ -57,6 +57,9 @@ def parser():
     p.add_argument('--loadpath', default='')
     p.add_argument('--testpath', default="./data/test_gray/")
     p.add_argument('--inference', default='True')
+    p.add_argument('--batch_measurements', action='store_true',
+                   help="(this build) a clip's measurements as ONE engine batch instead of the reference's one-by-one schedule; "
+                        "implied by more than one --gpu_ids entry, which shards them")
     ignored = p.add_argument_group("accepted for command-line compatibility, unused by inference")
     ignored.add_argument('--n_epochs', default=80)
     ignored.add_argument('--batch_size', type=int, default=1)
@@ -86,7 +89,8 @@ def run(args):
             images.update(png_payloads(r, args.savepath))
             print([r.name], '  PSNR: %.2f dB' % r.mean_psnr)
     t0 = time.time()
-    avg, results = evaluate(deq, SCITestDataset(args.testpath), device=dev, on_clip=on_clip)
+    avg, results = evaluate(deq, SCITestDataset(args.testpath), device=dev, on_clip=on_clip,
+                            batch=bool(args.batch_measurements or world > 1))
     dt = time.time() - t0
     if rank == 0:
         print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg)
@@ -107,11 +111,15 @@ def main(argv=None):
     if args.denoiser not in SHIPPED:
         raise NotImplementedError('unknown denoiser!')
     ids = [int(v) for v in str(args.gpu_ids).split(',') if v != '']
-    if not torch.cuda.is_available():
-        sys.exit("deqsci_amd needs an MI355X: there is no CPU path")
     if distributed.relaunch_needed(len(ids)):
+        # the launcher parent never calls into HIP (not even to count devices): visibility variables / KFD topology only
+        seen = distributed.visible_gpu_count()
+        if seen is not None and seen <= max(ids):
+            sys.exit(f"--gpu_ids {args.gpu_ids} but only {seen} GPU(s) are visible")
         cmd = [sys.executable, "-m", "deqsci_amd.cli"] + list(sys.argv[1:] if argv is None else argv)
         sys.exit(distributed.launch_ranks(cmd, len(ids), device_ids=ids))
+    if not torch.cuda.is_available():
+        sys.exit("deqsci_amd needs an MI355X: there is no CPU path")
     if len(ids) == 1 and "LOCAL_RANK" not in os.environ:
         os.environ["LOCAL_RANK"] = str(ids[0])
     return run(args)

@@ -130,8 +130,11 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
-                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps,
-                                                              float gram_noise) {
+                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps
+#ifdef DEQSCI_DIAG
+                                                              , float gram_noise
+#endif
+                                                              ) {
     // one wavefront per sample; the last block to arrive folds the per-sample norms into the
     // whole-batch residual (agent-scope release -> ticket -> acquire; the ticket resets itself).
     constexpr int NN = MAXM + 1;                                // rows of the largest bordered system
@@ -153,8 +156,9 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
     for (int i = lane; i < MAXM * MAXM + 2; i += WAVE) Gl[i] = gs[i];      // the rows of the other slots, from earlier iterations
 #pragma unroll
     for (int j = 0; j < PART_STRIDE; ++j) a[j] = wave_sum(a[j]);           // totals in lane 0
+#ifdef DEQSCI_DIAG
     if (gram_noise != 0.0f && lane == 0) {
-        // DIAGNOSTIC (env DEQSCI_GRAM_NOISE, off by default): uniform relative noise of that amplitude on the new Gram row, to
+        // DIAGNOSTIC (-DDEQSCI_DIAG build only, env DEQSCI_GRAM_NOISE): uniform relative noise of that amplitude on the new Gram row, to
         // study how the rounding of the reference's fp32 torch.bmm Gram (~1e-6 mean, 5e-6 max at N = 2^19) steers the chaotic
         // FFDNet + Anderson runs
         unsigned h = (unsigned)__double_as_longlong(a[MAXM]) * 2654435761u + (unsigned)(__double_as_longlong(a[MAXM]) >> 32);
@@ -164,6 +168,7 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
             a[j] *= 1.0 + (double)gram_noise * (((h >> 8) * (1.0 / 16777216.0)) * 2.0 - 1.0);
         }
     }
+#endif
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
@@ -375,9 +380,12 @@ __global__ __launch_bounds__(TB) void mix_gap_bhw_kernel(const float* __restrict
 
 static inline int64_t chunk_elems(int64_t bsz, int64_t N) {
     // target number of blocks over the whole batch (16384 measured best of 1024..32768 at bsz 64, flat at bsz 8;
-    // tuning knob DEQSCI_K4_BLOCKS), each block a whole number of
-    // 1024-element sweeps (>= 2)
-    static const int64_t target = [] { const char* e = getenv("DEQSCI_K4_BLOCKS"); return e ? atoll(e) : 16384ll; }();
+    // tuning knob DEQSCI_K4_BLOCKS of the -DDEQSCI_DIAG build), each block a whole number of 1024-element sweeps (>= 2)
+#ifdef DEQSCI_DIAG
+    const int64_t target = diag_env_int("DEQSCI_K4_BLOCKS", 16384);
+#else
+    constexpr int64_t target = 16384;
+#endif
     int64_t per_sample = target / (bsz > 0 ? bsz : 1);
     if (per_sample < 1) per_sample = 1;
     int64_t chunk = ceil_div(ceil_div(N, per_sample), 1024) * 1024;
@@ -432,9 +440,13 @@ int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, f
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
-    static const float gram_noise = [] { const char* e = getenv("DEQSCI_GRAM_NOISE"); return e ? (float)atof(e) : 0.0f; }();
+#ifdef DEQSCI_DIAG
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, gram_noise);
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+#else
+    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps);
+#endif
     return launch_status();
 }
 

@@ -36,10 +36,16 @@ constexpr int POL_DEFAULT = 0, POL_NTL = 1, POL_NTS = 2, POL_NTLS = 3;
 constexpr int64_t STREAM_MIN_BYTES = 64ll << 20;
 template <int POL> __device__ __forceinline__ float4 ldp(const float* p) { return (POL & 1) ? ld4s(p) : ld4(p); }
 template <int POL> __device__ __forceinline__ void stp(float* p, float4 v) { if (POL & 2) st4s(p, v); else st4(p, v); }
-inline int forced_policy() {      // tuning knob only (tools/kernel_bench.py --policy-sweep): DEQSCI_FORCE_POLICY=0..3
-    static const int v = [] { const char* e = getenv("DEQSCI_FORCE_POLICY"); return e ? atoi(e) : -1; }();
-    return v;
-}
+// The shipped library reads NO environment variable and keeps no mutable state (include/deqsci_hip.h: "re-entrant, no global
+// state").  The tuning / diagnostic knobs of the tools exist only in the -DDEQSCI_DIAG build (`make diag` ->
+// build/diag/libdeqsci_hip_diag.so, loaded by the tools through DEQSCI_HIP_LIB).
+#ifdef DEQSCI_DIAG
+inline int diag_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+inline double diag_env_f64(const char* name, double dflt) { const char* e = getenv(name); return e ? atof(e) : dflt; }
+inline int forced_policy() { return diag_env_int("DEQSCI_FORCE_POLICY", -1); }      // tools/policy_sweep.sh: 0..3
+#else
+inline int forced_policy() { return -1; }
+#endif
 inline int pick_policy(int64_t bytes, int streaming_policy) {
     const int f = forced_policy();
     if (f >= 0 && f <= 3) return f;

@@ -313,7 +313,11 @@ extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, con
     if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int head_vector_only = [] { const char* e = getenv("DEQSCI_HEAD_VALU"); return e ? atoi(e) : 0; }();   // (A/B knob)
+#ifdef DEQSCI_DIAG
+    const int head_vector_only = diag_env_int("DEQSCI_HEAD_VALU", 0);   // (A/B knob of the diagnostic build)
+#else
+    constexpr int head_vector_only = 0;
+#endif
     if (!head_vector_only && ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus()) {
         const dim3 grid((unsigned)ceil_div(W, 32), (unsigned)ceil_div(H, 32), (unsigned)n);
         hipLaunchKernelGGL(ffdnet_head_mfma_kernel, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);

@@ -547,8 +547,11 @@ static int winograd44_impl(const float* x, const float* u_packed, const float* b
     if (!aligned16(x) || !aligned16(u_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     const int64_t tiles_x = ceil_div(W, w44::OUT_COLS), tiles_y = ceil_div(H, w44::OUT_ROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
-    // 32-bit arithmetic in the kernel: tile indices, and byte offsets inside one image (padded to 32 columns in the blk32 layout)
-    if (n_tiles > (int64_t)INT32_MAX / 16 || H * tiles_x * 32 >= (int64_t)1 << 24) return DEQSCI_ERR_UNSUPPORTED;
+    // 32-bit arithmetic in the kernel: tile indices, and byte offsets inside one image (padded to 32 columns in the blk32 layout).
+    // The zero padding relies on RAW_OOB lying beyond the buffer descriptor's range for every instruction: num_records = image bytes
+    // + RAW_BIAS, and the range check adds the immediate offset (<= 2048) and the 16 bytes of the access.  Larger images (from
+    // about 2896 x 2896 on) are refused - the front end then runs the F(2x2,3x3) kernel.
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * tiles_x * 32 * 256 + w44::RAW_BIAS + 2048 + 16 > (int64_t)w44::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t resident = (int64_t)num_cus();
     const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));

@@ -8,7 +8,8 @@ the end assembles the (M,H,W,B) result on every rank.  One process per GPU.
 
     shard_bounds          contiguous slice of a rank
     gather_shards         local shard -> all ranks' shards (THE collective of the path; times itself)
-    sharded_reconstruct   global batch on every rank -> slice, reconstruct, gather_shards
+    sharded_reconstruct   global batch on every rank -> slice, reconstruct, gather_shards   (harness: a clip is small)
+    reconstruct_shard     the same for a rank that holds only its own slice                    (bench: nothing global materialised)
     launch_ranks          start N fresh child processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their
                           environment) - what `bench.py --gpus N` and `cli --gpu_ids 0,1,..` use when
                           they are not already running under torch.distributed.run
@@ -98,6 +99,25 @@ def sharded_reconstruct(reconstruct_fn, y, Phi, group=None, timer=None, **kw):
     return gather_shards(local, group=group, timer=timer)[:M]
 
 
+def reconstruct_shard(reconstruct_fn, y_local, Phi_local, M, group=None, timer=None, **kw):
+    """The same path for a rank that holds ONLY its own slice (bench.py: nothing of size M is ever materialised on one GPU):
+    y_local (hi - lo, H, W), Phi_local (hi - lo | 1, H, W, B) are rank r's measurements [lo, hi) = shard_bounds(M, R, r); returns
+    the (M,H,W,B) reconstruction on every rank through the path's one all-gather."""
+    if not _active(group):
+        return reconstruct_fn(y_local, Phi_local, **kw)
+    R, r = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, per = shard_bounds(M, R, r)
+    if y_local.shape[0] != hi - lo:
+        raise ValueError(f"rank {r} of {R} owns measurements [{lo}, {hi}) of {M} but was handed {y_local.shape[0]}")
+    if hi - lo == per:
+        local = reconstruct_fn(y_local, Phi_local, **kw).contiguous()
+    else:                                           # ragged tail / idle rank: pad the shard with zeros
+        local = torch.zeros((per,) + tuple(y_local.shape[1:]) + (Phi_local.shape[-1],), dtype=torch.float32, device=y_local.device)
+        if hi > lo:
+            local[:hi - lo] = reconstruct_fn(y_local, Phi_local, **kw)
+    return gather_shards(local, group=group, timer=timer)[:M]
+
+
 def gather_scalars(values, group=None):
     """Per-measurement scalars (PSNR, res, ...) of the local shard -> list over all ranks."""
     if not _active(group):
@@ -108,6 +128,29 @@ def gather_scalars(values, group=None):
 
 
 # ----------------------------------------------------------------------------- launching ranks
+def visible_gpu_count():
+    """Number of GPUs a child process will see, WITHOUT touching HIP in this process (a launcher parent that has initialised the
+    GPU must not spawn-and-wait on this pool, and `torch.cuda.device_count()` is one driver call away from that): the visibility
+    variables if set, else the KFD topology (nodes with SIMDs are GPUs).  None when neither source exists."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(root):
+        return None
+    n = 0
+    for node in os.listdir(root):
+        try:
+            with open(os.path.join(root, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -116,38 +159,104 @@ def free_port():
     return port
 
 
-def launch_ranks(argv, n, device_ids=None, timeout=None):
+def _stop(procs, grace=5.0):
+    """terminate -> wait up to `grace` seconds -> kill -> wait: no rank is left running or as a zombie."""
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()
+    deadline = time.time() + grace
+    for p in procs:
+        try:
+            p.wait(timeout=max(0.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+    for p in procs:
+        try:
+            p.wait(timeout=grace)
+        except subprocess.TimeoutExpired:
+            pass
+
+
+def _tail(path, lines=25):
+    try:
+        with open(path, errors="replace") as fh:
+            return "".join(fh.readlines()[-lines:])
+    except OSError:
+        return ""
+
+
+def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
     """Run `argv` (a full command line) as n child processes, rank r with RANK=r, LOCAL_RANK=device_ids[r] (default r),
-    WORLD_SIZE=n and a fresh 127.0.0.1 rendezvous port.  Children are NEW processes (never an exec of this one, which
-    may already have initialised the GPU); rank 0 inherits stdout, every rank inherits stderr.  Returns the largest
-    exit code; if a rank fails the others are terminated."""
+    WORLD_SIZE=n and a fresh 127.0.0.1 rendezvous port.  Children are NEW processes (never an exec of this one); rank 0 inherits
+    stdout; every rank's stderr goes to a scratch file that is echoed when the run ends (the tail of a failing rank first).
+    Returns 0, or the exit code of the first rank that failed (128 + signal number for a rank killed by a signal, 124 on timeout);
+    when a rank fails - or this process is interrupted / terminated - the others are terminated, then killed, and reaped.
+    A rendezvous that loses the race for its port (EADDRINUSE between free_port() and the bind of rank 0) is retried once on
+    a new port; nothing else is ever retried."""
+    import signal
+    import sys
+    import tempfile
     port = free_port()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r if device_ids is None else device_ids[r]), WORLD_SIZE=str(n),
-                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC is the only one this driver supports
-        procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    deadline = None if timeout is None else time.time() + timeout
-    worst = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            rc = p.poll()
-            if rc is None:
-                continue
-            live.remove(p)
-            if rc != 0:
-                worst = max(worst, rc if rc > 0 else 1)
-                for q in live:
-                    q.terminate()
-        if deadline is not None and time.time() > deadline:
-            for q in live:
-                q.kill()
-            return 124
-        time.sleep(0.05)
-    return worst
+    procs, logs = [], []
+    scratch = tempfile.mkdtemp(prefix="deqsci_ranks_")
+
+    def on_term(signum, frame):
+        raise KeyboardInterrupt(f"signal {signum}")
+    old = None
+    try:
+        old = signal.signal(signal.SIGTERM, on_term)
+    except ValueError:                                   # not the main thread: the try/finally below still reaps on exceptions
+        pass
+    first_bad, code = None, 0
+    try:
+        for r in range(n):
+            env = dict(os.environ)
+            env.update(RANK=str(r), LOCAL_RANK=str(r if device_ids is None else device_ids[r]), WORLD_SIZE=str(n),
+                       LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC is the only one this driver supports
+            logs.append(os.path.join(scratch, f"rank{r}.stderr"))
+            with open(logs[-1], "w") as errf:
+                procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL, stderr=errf))
+        deadline = None if timeout is None else time.time() + timeout
+        live = list(range(n))
+        while live and first_bad is None:
+            for r in list(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.remove(r)
+                if rc != 0 and first_bad is None:
+                    first_bad, code = r, (128 - rc if rc < 0 else rc)
+            if deadline is not None and time.time() > deadline and first_bad is None and live:
+                first_bad, code = live[0], 124
+            if live and first_bad is None:
+                time.sleep(0.05)
+    finally:
+        _stop(procs)
+        if old is not None:
+            signal.signal(signal.SIGTERM, old)
+    retry = False
+    if first_bad is not None:
+        text = _tail(logs[first_bad], 60)
+        retry = _attempts > 1 and code != 124 and ("EADDRINUSE" in text or "ddress already in use" in text)
+        if not retry:
+            sys.stderr.write(f"[launch_ranks] rank {first_bad} of {n} {'timed out' if code == 124 else 'failed'} (exit code {code}); "
+                             f"the other ranks were stopped.  Its stderr tail:\n{text}")
+    else:
+        for r in range(n):                                   # a clean run: pass the ranks' stderr through (warnings, progress)
+            sys.stderr.write(_tail(logs[r], 10 ** 6))
+    for f in logs:
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    try:
+        os.rmdir(scratch)
+    except OSError:
+        pass
+    if retry:
+        return launch_ranks(argv, n, device_ids=device_ids, timeout=timeout, _attempts=_attempts - 1)
+    return code
 
 
 def init_from_env(backend=None):

@@ -204,9 +204,12 @@ def png_payloads(result, prefix=""):
 
 
 def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, verbose=True, save_image=True,
-                    device="cuda", records=None, batch_measurements=True):
+                    device="cuda", records=None, batch_measurements=False):
     """Adapter with the reference's signature (training/sci_equilibrium_training.py:152): returns
-    (average PSNR, {png path: float image}); prints one line per clip and the total; writes the PNGs."""
+    (average PSNR, {png path: float image}); prints one line per clip and the total; writes the PNGs.
+    Default = the reference's schedule, one measurement per call (:171-181); batch_measurements=True hands a clip's
+    measurements to the engine as one batch (faster; on the chaotic FFDNet + Anderson @180 clip a different - equally valid -
+    realisation, because the FFDNet head kernel is chosen by launch size)."""
     images = {}
 
     def on_clip(r):

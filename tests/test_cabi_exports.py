@@ -53,12 +53,34 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_conv3x3_c64_winograd_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
     # the F(4x4,3x3) entry point has the same contract
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 1, 4096, 4096, 1, None) == -4
+    # ... and a tighter size limit: its zero padding needs the out-of-range sentinel offset 2^31 to lie beyond the image
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 1, 2900, 2900, 1, None) == -4
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 1, 8192, 1025, 1, None) == -4   # 1025 columns pad to 1056
+    assert _hip.conv64_kernel_for(64, 2900, 2900, policy="fast") == "f22"                           # the front end falls back by itself
+    assert _hip.W44_MAX_PIXELS * 256 + 4096 + 2048 + 16 <= 2 ** 31 < (_hip.W44_MAX_PIXELS + 1) * 256 + 4096 + 2048 + 16
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4    # in place
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 0, 16, 16, 1, None) == -2
     assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 2, 0, None, None, None) == -4   # unknown layout
     assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 1, 1, None, p16, None) == -1   # one event only
+
+
+def test_shipped_library_reads_no_environment():
+    """include/deqsci_hip.h / SURVEY 8(b): "re-entrant, no global state".  The diagnostic knobs (DEQSCI_GRAM_NOISE, DEQSCI_K4_BLOCKS,
+    DEQSCI_FORCE_POLICY, DEQSCI_HEAD_VALU) exist only in the -DDEQSCI_DIAG build of `make diag`; the shipped library neither
+    names an environment variable nor imports getenv."""
+    import subprocess
+    from deqsci_amd import _hip
+    blob = open(_hip.lib_path(), "rb").read()
+    for name in (b"DEQSCI_GRAM_NOISE", b"DEQSCI_K4_BLOCKS", b"DEQSCI_FORCE_POLICY", b"DEQSCI_HEAD_VALU", b"DEQSCI_CONV64"):
+        assert name not in blob, name
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", _hip.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undefined
+    for src in ("anderson.hip", "common.hpp", "ffdnet_edges.hip", "sci_ops.hip", "winograd.hip", "winograd44.hip", "epilogue.hip"):
+        text = open(os.path.join(ROOT, "deqsci_amd", "csrc", src)).read()
+        outside = "".join(seg.split("#endif", 1)[-1] if i else seg for i, seg in enumerate(text.split("#ifdef DEQSCI_DIAG")))
+        assert "getenv" not in outside and "static const" not in outside.replace("static constexpr", ""), src
 
 
 def test_gfx950_code_object_present():

@@ -74,7 +74,10 @@ def _bench_worker(rank, world, port, q):
     from deqsci_amd import distributed
     r, w, _, dev = distributed.init_from_env("gloo")
     assert (r, w, dev.type) == (rank, world, "cpu")
-    y, Phi, _ = bench.make_batch(world * 3, 8, 6, 4, 1234, dev)
+    # every rank generates ONLY its slice, by global measurement index; the whole batch (any sharding) is the same batch
+    y_all, Phi_all, _ = bench.make_batch(0, world * 3, 8, 6, 4, 1234, dev)
+    y, Phi, _ = bench.make_batch(rank * 3, rank * 3 + 3, 8, 6, 4, 1234, dev)
+    assert torch.equal(y, y_all[rank * 3:rank * 3 + 3]) and torch.equal(Phi, Phi_all[rank * 3:rank * 3 + 3])
     calls = []
 
     class Stub:
@@ -82,10 +85,21 @@ def _bench_worker(rank, world, port, q):
             calls.append(tuple(yl.shape))
             return (yl.unsqueeze(-1) * Pl + rank).contiguous()
     timer = distributed.GatherTimer()
-    step = bench.make_step(Stub(), y, Phi, timer)
+    step = bench.make_step(Stub(), y, Phi, world * 3, timer)
     full = step()
-    want = torch.cat([y[i * 3:(i + 1) * 3].unsqueeze(-1) * Phi[i * 3:(i + 1) * 3] + i for i in range(world)])
+    want = torch.cat([y_all[i * 3:(i + 1) * 3].unsqueeze(-1) * Phi_all[i * 3:(i + 1) * 3] + i for i in range(world)])
     ok = torch.equal(full, want) and calls == [(3, 8, 6)] and timer.calls == 1 and timer.total_seconds() > 0
+    # ragged global batch (strong scaling with M not divisible by the world size): rank 1 owns fewer, the tail is padding
+    lo, hi, per = distributed.shard_bounds(5, world, rank)
+    y5, P5, _ = bench.make_batch(lo, hi, 8, 6, 4, 1234, dev)
+    full5 = distributed.reconstruct_shard(Stub().reconstruct, y5, P5, 5)
+    want5 = torch.cat([y_all[i * 3:min(i * 3 + 3, 5)].unsqueeze(-1) * Phi_all[i * 3:min(i * 3 + 3, 5)] + i for i in range(world)])
+    ok = ok and (lo, hi, per) == ((0, 3, 3) if rank == 0 else (3, 5, 3)) and torch.equal(full5, want5)
+    try:
+        distributed.reconstruct_shard(Stub().reconstruct, y5[:1], P5[:1], 5)          # a slice of the wrong size is refused
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, bool(ok), tuple(full.shape)))
     dist.destroy_process_group()
 
@@ -121,15 +135,92 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1                                               # ONE JSON line, from rank 0
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 6 and rec["steps"] == 2 and rec["data"] == "selftest"
-    assert rec["allgather_ms_per_step"] > 0
+    assert rec["scaling"] == "weak" and rec["config"]["batch_per_gpu"] == 3
+    assert rec["allgather_ms_per_step"] > 0 and rec["allgather_bytes_per_step"] == 6 * 16 * 12 * 8 * 4
 
 
-def test_launch_ranks_propagates_failure():
+def test_bench_strong_scaling_mode_two_ranks():
+    """`--global-batch M`: the total is fixed and sharded (BASELINE config 3 as stated), ragged M included."""
+    import json
+    import subprocess
     import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest", "--global-batch", "5",
+                          "--size", "16x12x8", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2
+    assert rec["config"]["global_batch"] == 5 and rec["config"]["batch_per_gpu"] == 3
+    assert rec["allgather_bytes_per_step"] == 2 * 3 * 16 * 12 * 8 * 4
+
+
+def test_launch_ranks_propagates_failure(capfd):
+    import sys
+    import time
     from deqsci_amd.distributed import launch_ranks
-    code = "import os,sys,time; r=int(os.environ['RANK']); assert os.environ['WORLD_SIZE']=='2'; time.sleep(0.2 if r==0 else 30); sys.exit(3 if r==0 else 0)"
+    code = ("import os,sys,time; r=int(os.environ['RANK']); assert os.environ['WORLD_SIZE']=='2'; time.sleep(0.2 if r==0 else 30); "
+            "print('rank', r, 'says goodbye', file=sys.stderr); sys.exit(3 if r==0 else 0)")
+    t0 = time.time()
     assert launch_ranks([sys.executable, "-c", code], 2, timeout=60) == 3
+    assert time.time() - t0 < 20                                          # the sleeping rank was stopped, not waited for
+    err = capfd.readouterr().err
+    assert "rank 0 of 2 failed (exit code 3)" in err and "rank 0 says goodbye" in err      # the failing rank's stderr tail is shown
     assert launch_ranks([sys.executable, "-c", "import os; assert os.environ['LOCAL_RANK'] in ('5','7')"], 2, device_ids=[5, 7], timeout=60) == 0
+    # a rank killed by a signal is reported as 128 + signal, a hung run as 124 - and nothing is left running either way
+    assert launch_ranks([sys.executable, "-c", "import os,signal,time; os.kill(os.getpid(), signal.SIGKILL) if os.environ['RANK']=='1' else time.sleep(30)"],
+                        2, timeout=60) == 128 + 9
+    assert launch_ranks([sys.executable, "-c", "import time; time.sleep(30)"], 2, timeout=1) == 124
+
+
+def test_launch_ranks_reaps_children_when_interrupted():
+    """SIGTERM to the launcher: the ranks are terminated and reaped, the launcher dies with the signal's exception."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    from conftest import ROOT
+    prog = ("import sys, os; sys.path.insert(0, %r)\n"
+            "from deqsci_amd.distributed import launch_ranks\n"
+            "child = 'import os,time; open(os.environ[\"PIDFILE\"] + os.environ[\"RANK\"], \"w\").write(str(os.getpid())); time.sleep(60)'\n"
+            "launch_ranks([sys.executable, '-c', child], 2)\n") % ROOT
+    import tempfile
+    d = tempfile.mkdtemp()
+    env = dict(os.environ, PIDFILE=os.path.join(d, "pid"))
+    p = subprocess.Popen([sys.executable, "-c", prog], env=env, stderr=subprocess.DEVNULL)
+    deadline = time.time() + 60
+    while time.time() < deadline and not all(os.path.exists(os.path.join(d, f"pid{r}")) and os.path.getsize(os.path.join(d, f"pid{r}")) for r in range(2)):
+        time.sleep(0.1)
+    pids = [int(open(os.path.join(d, f"pid{r}")).read()) for r in range(2)]
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=30)
+    assert p.returncode != 0
+    time.sleep(0.2)
+    for pid in pids:
+        try:
+            os.kill(pid, 0)
+            alive = True
+        except OSError:
+            alive = False
+        assert not alive, f"rank process {pid} survived its launcher"
+
+
+def test_visible_gpu_count_never_touches_hip(monkeypatch):
+    from deqsci_amd import distributed
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2,3")
+    assert distributed.visible_gpu_count() == 4
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert distributed.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "2")
+    assert distributed.visible_gpu_count() == 1
+    # the launcher parents (bench.py, cli.py) must not call torch.cuda at all
+    from conftest import ROOT
+    for f in ("bench.py", os.path.join("deqsci_amd", "cli.py")):
+        src = open(os.path.join(ROOT, f)).read()
+        main = src[src.index("def main("):]
+        launcher = main[:main.index("launch_ranks(")]
+        assert "torch.cuda" not in launcher, f
 
 
 class _FakeDEQ:

@@ -561,7 +561,8 @@ def test_winograd_conv64_vs_torch(shape):
 def test_winograd44_conv64_vs_torch(shape):
     """Winograd F(4x4,3x3) MFMA conv 64->64 (+bias+ReLU) vs conv2d in fp64: random asymmetric weights, block tiles that
     stick out of the image on every side (tiles are 16 x 32 outputs), single block tiles and runs of many per workgroup
-    crossing image boundaries, with and without bias/ReLU.  Bound: 4e-6 (measured 1.2-1.7e-6; F(2x2,3x3): 2e-7, direct fp32: 3e-7)."""
+    crossing image boundaries, with and without bias/ReLU.  Bound on RANDOM data: 2.5e-6 (measured 1.2-1.7e-6; F(2x2,3x3): 2e-7, direct
+    fp32: 3e-7) - the network's own data are another matter: test_conv64_rounding_on_the_networks_own_data."""
     import torch.nn.functional as Fn
     n, H, W = shape
     g = torch.Generator(device=DEV).manual_seed(12)
@@ -573,13 +574,17 @@ def test_winograd44_conv64_vs_torch(shape):
     out = torch.full_like(x, float("nan"))
     got = _hip.conv3x3_c64_winograd44(x, U, None, relu=False, out=out)
     assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape
-    assert float((got.double() - ref).norm() / ref.norm()) < 4e-6
+    assert float((got.double() - ref).norm() / ref.norm()) < 2.5e-6
     got2 = _hip.conv3x3_c64_winograd44(x, U, b, relu=True)
     want2 = torch.relu(ref + b.double().view(1, -1, 1, 1))
-    assert float((got2.double() - want2).norm() / want2.norm()) < 4e-6
+    assert float((got2.double() - want2).norm() / want2.norm()) < 2.5e-6
     # repeated launches on one stream (the persistent pipeline leaves nothing behind) and the selecting front end
     got3 = _hip.conv3x3_c64(x, _hip.pack_conv64_weights(w), b, relu=True)
-    assert float((got3.double() - want2).norm() / want2.norm()) < 4e-6
+    assert float((got3.double() - want2).norm() / want2.norm()) < 2.5e-6
+    with pytest.raises(_hip.DeqsciHipError):                                   # the other kernel's pack would be read out of bounds
+        _hip.conv3x3_c64_winograd44(x, _hip.pack_winograd_weights(w), b, relu=True)
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.conv3x3_c64_winograd(x, U, b, relu=True)
     assert torch.equal(_hip.conv3x3_c64_winograd44(x, U, b, relu=True), got2)
 
 
@@ -602,24 +607,24 @@ def test_winograd44_blk32_layouts_vs_torch(shape):
     xb = _hip.Blk32.from_nchw(x)
     assert torch.equal(xb.to_nchw(), x)                                     # the host-side converters are inverses
     got_in = _hip.conv3x3_c64_winograd44(xb, Us[0], bs[0], True)           # blk32 -> NHWC
-    assert err(got_in, ref) < 4e-6
+    assert err(got_in, ref) < 2.5e-6
     ob = _hip.Blk32.empty(n, H, W, DEV)
     ob.t.fill_(float("nan"))
     got_out = _hip.conv3x3_c64_winograd44(x, Us[0], bs[0], True, out=ob, out_blk=True)   # NHWC -> blk32
-    assert err(got_out.to_nchw(), ref) < 4e-6
+    assert err(got_out.to_nchw(), ref) < 2.5e-6
     if W % 32:
         pos = _hip.Blk32._pos().to(DEV)
         pad = got_out.t[:, :, :, -1][:, :, :, pos][:, :, :, W % 32:]      # last block, columns >= W
         assert bool(torch.isnan(pad).all())
     got_both = _hip.conv3x3_c64_winograd44(xb, Us[0], bs[0], True, out_blk=True)          # blk32 -> blk32
-    assert err(got_both.to_nchw(), ref) < 4e-6
+    assert err(got_both.to_nchw(), ref) < 2.5e-6
     # a stack of three layers, as the engine chains them
     h = x
     want = x.double()
     for i in range(3):
         h = _hip.conv3x3_c64_winograd44(h, Us[i], bs[i], True, out_blk=(i < 2))
         want = torch.relu(Fn.conv2d(want, ws[i].double(), bs[i].double(), padding=1))
-    assert err(h, want) < 8e-6
+    assert err(h, want) < 5e-6
 
 
 def test_conv64_front_end_picks_the_faster_kernel():
@@ -787,8 +792,7 @@ def test_realsn_simplecnn_100_iters_script_default():
     """test_rsn_cnn.sh leaves --and_maxiters at its default of 100: traffic measurement 0 against the reference's run
     (SURVEY f-4 recorded 22.6831 dB / res 6.34e-4 for it)."""
     fn = os.path.join(GOLDEN, "e2e_RealSN_SimpleCNN_anderson_100.json")
-    if not os.path.exists(fn):
-        pytest.skip("golden not generated")
+    assert os.path.exists(fn), "committed golden missing (tests/golden/make_golden.py g9): this test must not skip"
     meta = [m for m in _golden_meta("RealSN_SimpleCNN_anderson_100")["measurements"] if m["id"] == "traffic_cacti.mat:0"][0]
     assert abs(meta["psnr"] - 22.6831) < 1e-3
     d = _clip("traffic_cacti.mat")
@@ -837,27 +841,37 @@ def _widened(vals, pad):
     return lo - 0.25 * (hi - lo) - pad, hi + 0.25 * (hi - lo) + pad          # total factor 1.5, + the north_star tolerance
 
 
+CONFIG2_SEEDS = 25          # runs per measurement on the build side (0 = unperturbed, 1..24 = x0 (1 + 1e-7 randn)); the reference ensembles have 9-10
+
+
+def _se(v):
+    return float(np.std(v, ddof=1) / np.sqrt(len(v)))
+
+
 def test_config2_ffdnet_anderson_180_all_measurements():
-    """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement.
+    """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement, on the
+    DEFAULT engine (conv64="auto", which runs the F(2x2,3x3) kernel in this regime).
     The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0),
     so one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and
-    x0 (1 + 1e-7 randn) for seeds 1..8 - on both sides:
-      reference (generated by importing it, make_golden g10): as it is, and with the Gram matrix of :178 computed exactly.  The second
-        exists because the reference's fp32 torch.bmm Gram carries ~1e-6 of rounding error at N = 2^19, which the ill-conditioned
-        Anderson system turns into ~5e-4 of noise on alpha, and in a chaotic iteration that noise is not neutral: traffic m2 sits at
-        21.48-21.61 with it and at 21.32-21.45 without.  This build sums the Gram partials in float64 and belongs to the second
-        ensemble (and moves to the first when noise of that size is injected: DESIGN.md section 5).
-      build: the same 9 starts through the engine.
-    Per chaotic measurement: the build's ensemble MEAN within 0.10 dB of the exact-Gram reference ensemble's mean (three standard
-    errors of the difference of two 9-run means at the observed spread of 0.04-0.08 dB), its MEDIAN - PSNR and residual - inside the
-    hull of both reference ensembles widened by the factor 1.5 (+ 0.01 dB / 1 %), and no run further than one hull width outside
-    the hull.  (A single run inside the widened band - the literal form of the gate - rejects 3 of the reference's own 108 runs
-    against the band of the other runs of their ensemble.)  Well-conditioned measurements (drop8, runner8: bands of 2 and 25 mdB)
-    are held to the widened band directly, every run; the harness average of the unperturbed run to the hull of the two average bands."""
+    x0 (1 + 1e-7 randn), seeds 1.. - on both sides:
+      reference (generated by importing it, make_golden g10, 9-10 runs per measurement): as it is, and with the Gram matrix of :178
+        computed exactly.  The second exists because the reference's fp32 torch.bmm Gram carries ~1e-6 of rounding error at
+        N = 2^19, which the ill-conditioned Anderson system turns into ~5e-4 of noise on alpha; this build sums the Gram partials
+        in float64 and belongs to the second ensemble (deviation 3).
+      build: 25 starts per measurement through the engine.
+    Bounds are STATISTICAL, computed from the two ensembles themselves, not hand-set:
+      * the mean over the six chaotic measurements of the per-measurement ensemble means: within 3 standard errors of the
+        difference from the exact-Gram reference (observed -0.014 dB at SE 0.0086), and from the reference AS IT IS within 3 SE
+        plus the shift the reference itself shows between its two Gram variants (0.012 dB);
+      * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean; median PSNR / residual
+        inside the hull of both reference ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than one hull width outside;
+      * well-conditioned measurements (drop8, runner8: bands of 2 and 25 mdB): every run inside the widened band;
+      * the harness average of the unperturbed run inside the hull of the two reference average bands."""
     from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements
     a, b = _config2_reference()
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
     eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
+    assert eng.conv64 == "auto" and eng.conv64_policy == "f22"
     report, base_by_clip = [], {}
     for clip in (as_clip(c) for c in SCITestDataset(orc.DATA_DIR)):
         Phi = clip["mask"].to(DEV)[None].contiguous()
@@ -867,7 +881,7 @@ def test_config2_ffdnet_anderson_180_all_measurements():
             gt = clip["gt"][..., 8 * fi:8 * fi + 8].numpy()
             x0 = deqsci_amd.initial_point(y, Phi, None, None)
             ps, rs = [], []
-            for seed in range(9):                                             # 0 = unperturbed
+            for seed in range(CONFIG2_SEEDS):                                 # 0 = unperturbed
                 xs = x0 if seed == 0 else x0 * (1 + 1e-7 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(seed))).to(DEV)
                 rec = eng.reconstruct(y, Phi, initial_point=xs)
                 assert eng.last_info["f_calls"] == 181
@@ -878,24 +892,70 @@ def test_config2_ffdnet_anderson_180_all_measurements():
             rb = [v["psnr"] for v in b["measurements"][mid]["variants"].values()]
             ea = [v["res"] for v in a["measurements"][mid]["variants"].values()] + [v["res"] for v in b["measurements"][mid]["variants"].values()]
             report.append((mid, ps, rs, ra, rb, ea))
+    chaotic = []
     for mid, ps, rs, ra, rb, ea in report:
         lo, hi = _widened(ra + rb, 0.01)
         rlo, rhi = _widened(ea, 0.0)
-        print("%-22s build mean %.4f median %.4f [%.4f, %.4f] | reference exact-Gram mean %.4f, fp32 mean %.4f, widened hull [%.4f, %.4f]"
-              % (mid, np.mean(ps), np.median(ps), min(ps), max(ps), np.mean(rb), np.mean(ra), lo, hi))
+        se = float(np.hypot(_se(ps), _se(rb)))
+        print("%-22s build mean %.4f +- %.4f median %.4f [%.4f, %.4f] | reference exact-Gram mean %.4f +- %.4f, fp32 mean %.4f, widened hull [%.4f, %.4f]"
+              % (mid, np.mean(ps), _se(ps), np.median(ps), min(ps), max(ps), np.mean(rb), _se(rb), np.mean(ra), lo, hi))
         if max(ra + rb) - min(ra + rb) < 0.05:                               # well-conditioned: every run inside the widened band
             assert all(lo <= p <= hi for p in ps), (mid, ps, lo, hi)
             assert all(rlo * 0.99 <= r <= rhi * 1.01 for r in rs), (mid, rs, rlo, rhi)
             continue
-        assert abs(np.mean(ps) - np.mean(rb)) <= 0.10, (mid, np.mean(ps), np.mean(rb))
+        chaotic.append((ps, ra, rb))
+        assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se, (mid, np.mean(ps), np.mean(rb), se)
         assert lo <= np.median(ps) <= hi, (mid, np.median(ps), lo, hi)
         assert rlo * 0.99 <= np.median(rs) <= rhi * 1.01, (mid, np.median(rs), rlo, rhi)
         w = max(ra + rb) - min(ra + rb)
         assert min(ra + rb) - w <= min(ps) and max(ps) <= max(ra + rb) + w, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
+    assert len(chaotic) == 6
+    pooled = lambda k: float(np.mean([np.mean(c[k]) for c in chaotic]))       # mean of the per-measurement ensemble means
+    pooled_se = lambda k: float(np.sqrt(sum(_se(c[k]) ** 2 for c in chaotic)) / len(chaotic))
+    mb, ma_, mx = pooled(0), pooled(1), pooled(2)
+    se_x, se_a = float(np.hypot(pooled_se(0), pooled_se(2))), float(np.hypot(pooled_se(0), pooled_se(1)))
+    print("six chaotic measurements: build %.4f +- %.4f | reference exact Gram %.4f +- %.4f (diff %+.4f, 3 SE = %.4f) | as it is %.4f +- %.4f "
+          "(diff %+.4f, 3 SE + Gram shift = %.4f)" % (mb, pooled_se(0), mx, pooled_se(2), mb - mx, 3 * se_x, ma_, pooled_se(1), mb - ma_,
+                                                     3 * se_a + abs(ma_ - mx)))
+    assert abs(mb - mx) <= 3 * se_x, (mb, mx, se_x)
+    assert abs(mb - ma_) <= 3 * se_a + abs(ma_ - mx), (mb, ma_, se_a)
     avg = float(np.mean([np.mean(v) for v in base_by_clip.values()]))         # test_solver_sci's average: mean over clips of the clip mean
     alo, ahi = _widened([a["avg_psnr_min"], a["avg_psnr_max"], b["avg_psnr_min"], b["avg_psnr_max"]], 0.01)
     print("harness average of the unperturbed run %.4f in [%.4f, %.4f]" % (avg, alo, ahi))
     assert alo <= avg <= ahi, (avg, alo, ahi)
+
+
+def test_conv64_rounding_on_the_networks_own_data():
+    """What decides the conv64 policy (engine.py): the rounding of each 64->64 kernel against a float64 convolution on FFDNet's OWN
+    data - folded net_gray weights, the activations of a noisy first iterate (x0) and of a settled one (30 Anderson iterations).
+    Random data mislead here: on randn inputs F(4x4,3x3) is 6-8x noisier than a direct convolution, on a settled iterate it is on
+    par with F(2x2,3x3).  Bounds = measured (profiles/r03_conv_error_real.json) + margin: F(2x2,3x3) <= 3e-7 everywhere (<= the
+    direct fp32 convolution's, MIOpen: 2.4-3.5e-7); F(4x4,3x3) <= 1.2e-6 on x0, <= 3.5e-7 on the settled iterate."""
+    import torch.nn.functional as Fn
+    from deqsci_amd.engine import SIGMA0
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"][None, ..., 0].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 30)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=30, use_graph=False)
+    inputs = {"x0": deqsci_amd.initial_point(y, Phi, None, None), "iterate30": eng.reconstruct(y, Phi)}
+    den = eng.den
+    for name, z in inputs.items():
+        x = z.permute(0, 3, 1, 2).reshape(8, 1, 256, 256).contiguous()
+        h = _hip.ffdnet_head(x, den.head_w, torch.full((1,), SIGMA0, device=DEV))
+        worst = {"f22": 0.0, "f44": 0.0, "direct": 0.0}
+        for li in range(1, len(den.fast) - 1):
+            w, b, relu = den.fast[li]
+            ref = torch.relu(Fn.conv2d(h.double(), w.double(), b.double(), padding=1))
+            e = lambda t: float((t.double() - ref).norm() / ref.norm())
+            got22 = _hip.conv3x3_c64_winograd(h, den.wino[li].f22, b, relu)
+            worst["f22"] = max(worst["f22"], e(got22))
+            worst["f44"] = max(worst["f44"], e(_hip.conv3x3_c64_winograd44(h, den.wino[li].f44, b, relu)))
+            worst["direct"] = max(worst["direct"], e(torch.relu(Fn.conv2d(h, w, b, padding=1))))
+            h = got22
+        print(name, {k: "%.2e" % v for k, v in worst.items()})
+        assert worst["f22"] < 3e-7, (name, worst)
+        assert worst["f44"] < (1.2e-6 if name == "x0" else 3.5e-7), (name, worst)
 
 
 def test_engine_conv_layout_and_kernel_choice():
@@ -921,6 +981,11 @@ def test_engine_conv_layout_and_kernel_choice():
     finally:
         _hip.FORCE_CONV64 = old
     assert not torch.equal(a, c) and rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 2e-5
+    # the engine-level policy: explicit "f22" == the forced run above, bit for bit; "auto" resolves by regime, not by batch size
+    e22 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="f22")
+    assert torch.equal(e22.reconstruct(ys, Phi), c)
+    assert eng.conv64_policy == "fast" and DEQSCIEngine(net, max_iter=180).conv64_policy == "f22"
+    assert DEQSCIEngine(net, max_iter=180, iterator="picard").conv64_policy == "fast" and DEQSCIEngine(net, max_iter=180, conv64="fast").conv64_policy == "fast"
 
 
 def test_engine_graph_replay_is_bit_identical_to_eager():
@@ -962,9 +1027,9 @@ def test_engine_graph_replay_is_bit_identical_to_eager():
         assert torch.equal(out, ref) and g1.last_info["f_calls"] == e1.last_info["f_calls"] < 40 and g1.last_info["graph"] is False
 
 
-def test_harness_frames_per_second_measurement_by_measurement():
-    """Not a parity gate: records the drop-in usage's speed (FFDNet @180, one measurement per call, the reference's schedule)
-    with the graph path, and checks the per-measurement PSNRs agree with the eager engine's to the last digit."""
+def test_harness_graph_replay_equals_eager_measurement_by_measurement():
+    """The drop-in usage (FFDNet @180, one measurement per call, the reference's schedule) on the hipGraph path: per-measurement
+    PSNRs agree with the eager engine's to the last digit.  (Its speed is reported by tools/parity_report.py, not asserted here.)"""
     import time
     from deqsci_amd.harness import SCITestDataset, test_solver_sci
     _, deq = _pipeline("ffdnet", 180)
@@ -982,7 +1047,6 @@ def test_harness_frames_per_second_measurement_by_measurement():
     test_solver_sci(deq, test_dataloader=ds, save_img_path="", verbose=False, save_image=False, batch_measurements=False, records=rec_e)
     assert [r["psnr"] for r in rec_g] == [r["psnr"] for r in rec_e]
     print(f"\nharness FFDNet@180 measurement-by-measurement (hipGraph): 64 frames in {dt:.3f} s = {64 / dt:.1f} frames/s")
-    assert 64 / dt > 40
 
 
 def test_bench_two_ranks_on_one_gpu_real_engine():

@@ -272,3 +272,56 @@ def test_blk32_layout_helpers():
     # pixel (n=1, channel 13, row 3, column 37) -> chunk 1, channel 5 of the chunk, block 1, column 5 of the block
     assert float(b.t[1, 1, 3, 1, int(pos[5]), 5]) == float(x[1, 13, 3, 37])
     assert bool(torch.isnan(b.t[:, :, :, 1][:, :, :, pos][:, :, :, 13:]).all())                    # columns >= 45 of the last block: padding
+
+
+def test_reference_pickle_checkpoint_formats(tmp_path):
+    """the reference's own on-disk formats, not this build's .npz re-serialisations -
+    (1) the training checkpoint `torch.save({'solver_state_dict', 'epoch', 'optimizer_state_dict', 'scheduler_state_dict'})`
+    of training/sci_equilibrium_training.py:126-130, with the `module.` prefix nn.DataParallel leaves on every key
+    (stripped at video_sci_proxgrad.py:217-222); (2) a bare FFDNet state dict with `module.` keys (networks/ffdnet/models/net_gray.pth);
+    (3) a missing path raises instead of silently running with random weights (video_sci_proxgrad.py:211)."""
+    cnn, _ = checkpoint.read_state_dict(checkpoint.shipped("cnn"))
+    assert sorted(cnn) == [f"nonlinear_op.dncnn.{i}.weight" for i in (0, 2, 4, 6)]
+    path = str(tmp_path / "cnn.ckpt")
+    torch.save({"solver_state_dict": {"module." + k: v for k, v in cnn.items()}, "epoch": 7,
+                "optimizer_state_dict": {"state": {}, "param_groups": []}, "scheduler_state_dict": {"last_epoch": 7}}, path)
+    solver, _ = build_pipeline("SimpleCNN", None, 10, device="cpu")
+    before = {k: v.clone() for k, v in solver.state_dict().items()}
+    assert checkpoint.load_solver(solver, path) == 7
+    after = solver.state_dict()
+    assert sorted(after) == sorted(cnn) and all(torch.equal(after[k], cnn[k]) for k in cnn)
+    assert any(not torch.equal(before[k], after[k]) for k in cnn)                      # the load really replaced the random init
+    # the same checkpoint without the DataParallel prefix
+    torch.save({"solver_state_dict": dict(cnn), "epoch": 3}, path)
+    solver2, _ = build_pipeline("SimpleCNN", None, 10, device="cpu")
+    assert checkpoint.load_solver(solver2, path) == 3
+    assert all(torch.equal(solver2.state_dict()[k], cnn[k]) for k in cnn)
+    # (2) bare denoiser pickle, keys `module.intermediate_dncnn...` -> loaded into solver.nonlinear_op
+    ff, _ = checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray"))
+    pth = str(tmp_path / "net_gray.pth")
+    torch.save({"module." + k: v for k, v in ff.items()}, pth)
+    sd, epoch = checkpoint.read_state_dict(pth)
+    assert epoch is None and sorted(sd) == sorted(ff) and all(torch.equal(sd[k], ff[k]) for k in ff)
+    fsolver, _ = build_pipeline("ffdnet", pth, 10, device="cpu")
+    got = fsolver.nonlinear_op.state_dict()
+    assert all(torch.equal(got[k], ff[k]) for k in ff)
+    assert sorted(k for k in fsolver.state_dict()) == sorted("nonlinear_op." + k for k in got)   # keys are exactly nonlinear_op.* (S1)
+    # (3)
+    with pytest.raises(FileNotFoundError):
+        checkpoint.load_solver(solver, str(tmp_path / "nope.ckpt"))
+
+
+def test_conv64_policy_resolution():
+    """DEQSCIEngine(conv64="auto"): F(2x2,3x3) exactly where the choice is visible in the result (FFDNet + Anderson beyond 30
+    iterations, the chaotic regime of SURVEY F9), the faster kernel per launch elsewhere; explicit policies are honoured."""
+    ff = build_denoiser("ffdnet").eval()
+    cnn = build_denoiser("SimpleCNN").eval()
+    pol = lambda net, **kw: DEQSCIEngine(net, **kw).conv64_policy
+    assert pol(ff) == "f22" and pol(ff, max_iter=31) == "f22"
+    assert pol(ff, max_iter=30) == "fast" and pol(ff, iterator="picard") == "fast" and pol(cnn) == "fast"
+    assert pol(ff, conv64="fast") == "fast" and pol(ff, conv64="f44") == "f44" and pol(cnn, conv64="f22") == "f22"
+    with pytest.raises(ValueError):
+        DEQSCIEngine(ff, conv64="f33")
+    assert _hip.conv64_kernel_for(64, 128, 128, policy="f22") == "f22" and _hip.conv64_kernel_for(1, 16, 16, policy="f44") == "f44"
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.conv64_kernel_for(1, 16, 16, policy="direct")

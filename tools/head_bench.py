@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """FFDNet head kernel (sigma map + pixel_unshuffle + conv 5->64 + ReLU) at the bench shape: matrix-core vs vector-ALU variant
-(DEQSCI_HEAD_VALU=1 forces the latter; run the script twice)."""
+(DEQSCI_HEAD_VALU=1 forces the latter in the diagnostic build of the library: `make diag`, then run the script twice with
+DEQSCI_HIP_LIB=build/diag/libdeqsci_hip_diag.so)."""
 import json, os, statistics, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,9 +1,10 @@
 #!/bin/bash
+# needs the diagnostic build of the library (`make diag`): the shipped one reads no environment variable
 # same box, same process layout: every kernel under each cache policy (0 default, 1 nt loads, 2 nt stores, 3 both)
 mkdir -p gpurun_out
 for rep in 1 2; do
 for P in 0 1 2 3; do
-  DEQSCI_FORCE_POLICY=$P python tools/kernel_bench.py --launches 40 2>&1 | grep -v amdgpu.ids | python -c "
+  DEQSCI_HIP_LIB=build/diag/libdeqsci_hip_diag.so DEQSCI_FORCE_POLICY=$P python tools/kernel_bench.py --launches 40 2>&1 | grep -v amdgpu.ids | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
