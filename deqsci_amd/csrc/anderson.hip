@@ -128,9 +128,68 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ float readlane_t(float v, int src_lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane)); }
+__device__ __forceinline__ double readlane_t(double v, int src_lane) { return readlane_f64(v, src_lane); }
+
+// bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180), augmented with the right-hand side as
+// column nn; lane c holds column c.  S = float: the system is formed and factorised in fp32, as the reference does it (H is an
+// fp32 tensor and torch.solve = LAPACK sgesv: LU with partial pivoting) - the Gram entries come from the float64 sums, rounded once.
+// S = double: the same elimination in float64 (cond(H) ~ 500: alpha to 1e-13 instead of ~3e-5).
+template <typename S>
+__device__ __forceinline__ void bordered_solve(const double* Gl, double (*M)[MAXM + 2], float* __restrict__ alpha, int s, int lane, int n, float lam) {
+    constexpr int NN = MAXM + 1;
+    const int nn = n + 1;
+    S col[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) {
+        S v = 0;
+        if (i < nn && lane <= nn) {
+            if (lane == nn) v = (i == 0) ? S(1) : S(0);
+            else if (i == 0 && lane == 0) v = 0;
+            else if (i == 0 || lane == 0) v = 1;
+            else v = (S)Gl[(i - 1) * MAXM + (lane - 1)] + (i == lane ? (S)lam : S(0));
+        }
+        col[i] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NN; ++k) {                          // LU, partial pivoting (as LAPACK gesv)
+        if (k < nn) {
+            int piv = k;
+            S best = col[k] < 0 ? -col[k] : col[k];
+#pragma unroll
+            for (int i = k + 1; i < NN; ++i)
+                if (i < nn) { const S v = col[i] < 0 ? -col[i] : col[i]; if (v > best) { best = v; piv = i; } }
+            piv = __builtin_amdgcn_readlane(piv, k);        // column k lives in lane k
+#pragma unroll
+            for (int i = k + 1; i < NN; ++i)
+                if (i == piv) { const S t = col[k]; col[k] = col[i]; col[i] = t; }
+            const S inv = S(1) / col[k];                    // (meaningful in lane k)
+#pragma unroll
+            for (int i = k + 1; i < NN; ++i)
+                if (i < nn) {
+                    const S f = readlane_t(col[i] * inv, k);
+                    col[i] -= f * col[k];
+                }
+        }
+    }
+    if (lane <= nn) {
+#pragma unroll
+        for (int i = 0; i < NN; ++i) M[i][lane] = (double)col[i];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (int i = nn - 1; i >= 0; --i) {
+            S v = (S)M[i][nn];
+            for (int j = i + 1; j < nn; ++j) v -= (S)M[i][j] * (S)M[j][nn];
+            M[i][nn] = (double)(v / (S)M[i][i]);
+        }
+        for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
+    }
+}
+
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
-                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps
+                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32
 #ifdef DEQSCI_DIAG
                                                               , float gram_noise
 #endif
@@ -184,55 +243,8 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
         res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
     }
     if (n > 0) {
-        // bordered system  [[0, 1^T], [1, G G^T + lam I]] [nu; alpha] = e0   (:169-172,:178-180), augmented with the right-hand
-        // side as column nn; lane c holds column c
-        const int nn = n + 1;
-        double col[NN];
-#pragma unroll
-        for (int i = 0; i < NN; ++i) {
-            double v = 0.0;
-            if (i < nn && lane <= nn) {
-                if (lane == nn) v = (i == 0) ? 1.0 : 0.0;
-                else if (i == 0 && lane == 0) v = 0.0;
-                else if (i == 0 || lane == 0) v = 1.0;
-                else v = Gl[(i - 1) * MAXM + (lane - 1)] + (i == lane ? (double)lam : 0.0);
-            }
-            col[i] = v;
-        }
-#pragma unroll
-        for (int k = 0; k < NN; ++k) {                          // LU, partial pivoting (as LAPACK gesv)
-            if (k < nn) {
-                int piv = k;
-                double best = fabs(col[k]);
-#pragma unroll
-                for (int i = k + 1; i < NN; ++i)
-                    if (i < nn) { const double v = fabs(col[i]); if (v > best) { best = v; piv = i; } }
-                piv = __builtin_amdgcn_readlane(piv, k);        // column k lives in lane k
-#pragma unroll
-                for (int i = k + 1; i < NN; ++i)
-                    if (i == piv) { const double t = col[k]; col[k] = col[i]; col[i] = t; }
-                const double inv = 1.0 / col[k];                // (meaningful in lane k)
-#pragma unroll
-                for (int i = k + 1; i < NN; ++i)
-                    if (i < nn) {
-                        const double f = readlane_f64(col[i] * inv, k);
-                        col[i] -= f * col[k];
-                    }
-            }
-        }
-        if (lane <= nn) {
-#pragma unroll
-            for (int i = 0; i < NN; ++i) M[i][lane] = col[i];
-        }
-        __syncthreads();
-        if (lane == 0) {
-            for (int i = nn - 1; i >= 0; --i) {
-                double v = M[i][nn];
-                for (int j = i + 1; j < nn; ++j) v -= M[i][j] * M[j][nn];
-                M[i][nn] = v / M[i][i];
-            }
-            for (int i = 0; i < MAXM; ++i) alpha[(int64_t)s * MAXM + i] = i < n ? (float)M[i + 1][nn] : 0.0f;
-        }
+        if (solve_f32) bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
+        else bordered_solve<double>(Gl, M, alpha, s, lane, n, lam);
     }
     if (lane != 0) return;
     if (bsz == 1) { res[0] = res[1]; return; }
@@ -442,10 +454,10 @@ int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, f
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
 #ifdef DEQSCI_DIAG
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
 #else
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps);
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0);
 #endif
     return launch_status();
 }

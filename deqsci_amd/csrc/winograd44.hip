@@ -97,6 +97,19 @@ __device__ __forceinline__ constexpr int patch_off(int pr, int pc) {
     return (pr * RAW_COLS + ((pc & 3) == 0 ? 0 : (pc & 3) == 1 ? 9 : (pc & 3) == 2 ? 18 : 26) + (pc >> 2)) * 8;
 }
 
+// One 16-byte non-temporal output store through a buffer descriptor: per-lane byte offset + scalar offset + immediate 64 k bytes
+// (k is a constant after unrolling; the chain below folds to one instruction).  s_nop: the wait states between a 16-byte store and the
+// next write of its data registers, which the compiler cannot see into the asm to insert.
+#define W44_ST(K) asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen offset:" #K " nt\n\ts_nop 1" ::"v"(val), "v"(vo), "s"(rsrc), "s"(so) : "memory")
+__device__ __forceinline__ void store_out(f32x4 val, uint32_t vo, i32x4 rsrc, uint32_t so, int k) {
+    switch (k) {
+        case 0: W44_ST(0); break;      case 1: W44_ST(64); break;    case 4: W44_ST(256); break;   case 5: W44_ST(320); break;
+        case 8: W44_ST(512); break;    case 9: W44_ST(576); break;   case 12: W44_ST(768); break;  case 13: W44_ST(832); break;
+        default: __builtin_trap();
+    }
+}
+#undef W44_ST
+
 // 1-D input transform of F(4,3): y = B^T x, B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void bt_lo(const f32x2* x, f32x2& y0, f32x2& y1, f32x2& y2) {
     y0 = fma2(x[2], -5.0f, fma2(x[0], 4.0f, x[4]));
@@ -127,7 +140,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     __shared__ uint32_t Voff[3 * TBW];
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
-    const int rg = wave & 1, cgp = (wave >> 1) & 1, tg = wave >> 2;
+    const int rg = wave & 1;
+    int cgp, tg;                                              // (set inside each row group's code copy: see run())
 
     int t_first, t_step, t_end;
     {
@@ -292,8 +306,19 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         constexpr int RG = decltype(rg_c)::value;
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
-        const int64_t plane = (int64_t)H * tiles_x * 256;      // floats of one 8-channel plane of the blk32 layout
-        float* yn = y + (int64_t)n * (OUT_BLK ? 8 * plane : (int64_t)H * W * 64);
+        // Output stores go through a raw buffer descriptor of image n: a lane's address is then ONE 32-bit offset (image bytes < 2^31:
+        // launcher) instead of a 64-bit pointer plus the temporaries of its arithmetic, and everything wave-uniform (cout group,
+        // channel plane, output row of the pair) rides in the scalar offset - the 64-bit form spilled 8 registers per lane here.
+        const uint32_t plane_b = (uint32_t)(H * tiles_x) * 1024u;      // bytes of one 8-channel plane of the blk32 layout
+        const int64_t oimg = OUT_BLK ? (int64_t)H * tiles_x * 2048 : (int64_t)H * W * 64;     // floats per image
+        i32x4 orsrc;
+        {
+            const uint64_t ob = (uint64_t)(y + (int64_t)n * oimg);
+            orsrc.x = (int)uniform((uint32_t)ob);
+            orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+            orsrc.z = (int)uniform((uint32_t)oimg * 4u);
+            orsrc.w = 0x00020000;
+        }
         asm volatile("s_nop 15");                              // (asm MFMAs: the wait states between the last of them and the first vector read of an accumulator)
         stores_in_flight = OUT_ROWS * (by + 1) <= H && OUT_COLS * (bx + 1) <= W;   // every lane stores all 16 values: 16 operations in flight
         // every lane-dependent address of the epilogue is derived from an opaque copy of the lane index: hipcc would otherwise
@@ -301,8 +326,9 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         const int el = lane_id();
         const int ei = el & 15, eq = el >> 4;
         const int oy = OUT_ROWS * by + 4 * (2 * tg + (ei >> 3)) + 2 * RG, ox = OUT_COLS * bx + 4 * (ei & 7);
-        float* o = OUT_BLK ? yn + (4 * cgp + (eq >> 1)) * plane + (((int64_t)oy * tiles_x + bx) * 32 + (ei & 7)) * 8 + 4 * (eq & 1)
-                           : yn + ((int64_t)oy * W + ox) * 64 + 32 * cgp + 4 * eq;
+        const uint32_t ovo = OUT_BLK ? (uint32_t)(eq >> 1) * plane_b + (uint32_t)(((oy * tiles_x + bx) * 32 + (ei & 7)) * 32 + 16 * (eq & 1))
+                                     : (uint32_t)((oy * W + ox) * 256 + 16 * eq);
+        const uint32_t osb = OUT_BLK ? (uint32_t)(4 * cgp) * plane_b : 128u * (uint32_t)cgp;
         float* xw = Xs + (wave * 4 * 64 + el) * 4;
         const float* xr = Xs + ((wave ^ 1) * 4 * 64 + el) * 4;
         // one round = one cout group j and one PAIR of output columns cp, both register pairs h of the accumulators: what a lane
@@ -365,10 +391,13 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
                     for (int c = 0; c < 2; ++c) {
                         f32x4 val = mine[rr * 2 + c];
                         if (relu) { val.x = fmaxf(val.x, 0.0f); val.y = fmaxf(val.y, 0.0f); val.z = fmaxf(val.z, 0.0f); val.w = fmaxf(val.w, 0.0f); }
-                        if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + 2 * cp + c < W)
-                            __builtin_nontemporal_store(val, reinterpret_cast<f32x4*>(
-                                OUT_BLK ? o + 2 * j * plane + (int64_t)rr * tiles_x * 256 + 64 * ((2 * cp + c + 1) & 3)  // position 8 ((col+1)&3) + tx of the block
-                                        : o + 16 * j + ((int64_t)rr * W + 2 * cp + c) * 64));
+                        if ((!(W44_ABL & 4096) || relu == 77) && oy + rr < H && ox + 2 * cp + c < W) {
+                            // blk32: position 8 ((col+1)&3) + tx of the block.  Non-temporal; (s_nop: the wait states between a 16-byte
+                            // store and the next write of its data registers, which the compiler cannot see into the asm to insert)
+                            const uint32_t so = uniform(OUT_BLK ? osb + (uint32_t)(2 * j) * plane_b + (uint32_t)(rr * tiles_x) * 1024u
+                                                                : osb + (uint32_t)(rr * W) * 256u);
+                            store_out(val, ovo, orsrc, so, OUT_BLK ? 4 * ((2 * cp + c + 1) & 3) : j + 4 * (2 * cp + c));
+                        }
                     }
             }
         }
@@ -399,14 +428,12 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         constexpr int PAR = decltype(par_c)::value;
         constexpr bool FIRST = decltype(first_c)::value;
         // entry: Us = U(c) (steps >= SPLIT still landing), Raw[PAR^1] = raw(c+1) visible, v = V(c), raw(c+2) landing in Raw[PAR]
-        f32x4 init7[2];
-        if (FIRST) {
+        // the bias is the initial value of the accumulators of position (1,1) (row group 0, step 7): read straight into them - in the
+        // first stage of a tile they are dead until that step (a separate copy was spilled)
+        if (FIRST && RG == 0) {
             const int el = lane_id();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + 32 * cgp + 16 * j + 4 * (el >> 4));
-                init7[j] = RG == 0 ? bv : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            }
+            for (int j = 0; j < 2; ++j) acc[7][j] = *reinterpret_cast<const f32x4*>(bias_s + 32 * cgp + 16 * j + 4 * (el >> 4));
         }
         constexpr int PF = 2;                                 // weight operands are read two positions ahead
         float4 bq[PF + 1];
@@ -421,11 +448,10 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
         {                                                                                                                             \
             const float4 b = bq[(S) % (PF + 1)];                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                                        \
-            if (FIRST && (S) != 7) {                                                                                                  \
+            if (FIRST && ((S) != 7 || RG != 0)) {                                                                                     \
                 W44_MFMA0(acc[S][0], b.x, v[S].x);                                                                                    \
                 W44_MFMA0(acc[S][1], b.z, v[S].x);                                                                                    \
             } else {                                                                                                                  \
-                if (FIRST) { acc[S][0] = init7[0]; acc[S][1] = init7[1]; }                                                            \
                 W44_MFMA(acc[S][0], b.x, v[S].x);                                                                                     \
                 W44_MFMA(acc[S][1], b.z, v[S].x);                                                                                     \
             }                                                                                                                         \
@@ -495,6 +521,13 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // rg-dependent piece (input transform, output transform) live at once, and whatever is computed in front of the two copies
     // is kept alive THROUGH the first copy for the second one - either way it spills
     auto run = [&](auto rg_c) __attribute__((always_inline)) {
+        {   // the wave's cout group / tile group, derived again inside each copy from an opaque copy of the wave index: computed once in
+            // front of the two copies they are kept alive through the first copy for the second one (an SGPR spill)
+            int w = wave;
+            asm volatile("" : "+s"(w));
+            cgp = (w >> 1) & 1;
+            tg = w >> 2;
+        }
         // ---- prologue (once per workgroup): bias, U(0) whole, raw(0), raw(1) staged; V(0) computed; raw(2) on its way
         if (wave == 0) { const int bl = lane_id(); bias_s[bl] = bias ? bias[bl] : 0.0f; }
         set_fetch_tile(t_first);

@@ -69,6 +69,8 @@ class _Denoiser:
         self.fused_edges = fused_edges
         self.winograd = winograd
         self.conv64 = conv64                                        # _hip.conv64_kernel_for policy: "fast" | "f22" | "f44"
+        self.f22_calls = None                                       # with policy "fast": f-calls [0, f22_calls) still run F(2x2,3x3) (DEQSCIEngine)
+        self._policy = conv64
         self.blk32 = os.environ.get("DEQSCI_BLK32", "1") != "0"     # (A/B knob) blk32 activations between F(4x4,3x3) layers
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
         # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
@@ -171,10 +173,10 @@ class _Denoiser:
             w, b, relu = self.fast[i]
             if self.wino[i] is not None and (isinstance(h, _hip.Blk32) or (h.is_cuda and h.is_contiguous(memory_format=torch.channels_last))):
                 # between two 64->64 layers that run on the F(4x4,3x3) kernel the activation stays in that kernel's own layout
-                f44 = isinstance(h, _hip.Blk32) or _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device, self.conv64) == "f44"
+                f44 = isinstance(h, _hip.Blk32) or _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device, self._policy) == "f44"
                 nxt = idx[pos + 1] if pos + 1 < len(idx) else None
                 h = _hip.conv3x3_c64(h, self.wino[i], b, relu, out_blk=bool(f44 and self.blk32 and nxt is not None and self.wino[nxt] is not None),
-                                     policy=self.conv64)
+                                     policy=self._policy)
             elif fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
@@ -195,6 +197,7 @@ class _Denoiser:
     def run(self, z1, call):
         bsz, B, H, W = z1.shape
         x = z1.view(bsz * B, 1, H, W)
+        self._policy = "f22" if (self.f22_calls is not None and call < self.f22_calls) else self.conv64
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:

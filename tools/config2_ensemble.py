@@ -48,13 +48,18 @@ def main():
     a = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")))["measurements"]
     b = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json")))["measurements"]
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
-    configs = {"default (F(4x4) conv)": {}, "F(2x2) conv": {"force": "f22"}, "MIOpen direct conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}}
+    configs = {"F(4x4) conv wherever faster (conv64='fast')": {"kw": dict(conv64="fast")}, "F(2x2) conv (conv64='f22')": {"kw": dict(conv64="f22")},
+               "MIOpen direct conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}, "engine default (conv64='auto')": {}}
+    for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID", "").split(",") if v]:
+        configs[f"hybrid: F(2x2) for f-calls < {k}, then fast"] = {"kw": dict(conv64="fast"), "f22_calls": k}
     res = {}
     if ONLY:
         configs = {k: v for k, v in configs.items() if any(o in k for o in ONLY.split(","))}
     for name, c in configs.items():
         _hip.FORCE_CONV64 = c.get("force")
         eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, **c.get("kw", {}))
+        if "f22_calls" in c:
+            eng.den.f22_calls = c["f22_calls"]
         res[name] = ensemble(eng)
         _hip.FORCE_CONV64 = None
     rows = {}
@@ -72,7 +77,8 @@ def main():
     for k, v in res.items():
         means = [np.mean(v[m]) for m in tr]
         se = np.sqrt(sum(np.var(v[m], ddof=1) / len(v[m]) for m in tr)) / len(tr)
-        summary[k] = {"traffic_mean": round(float(np.mean(means)), 4), "se": round(float(se), 4), "runs_per_measurement": N_SEEDS}
+        summary[k] = {"traffic_mean": round(float(np.mean(means)), 4), "se": round(float(se), 4), "runs_per_measurement": N_SEEDS,
+                      "per_measurement": {m: [round(float(np.mean(v[m])), 4), round(float(np.std(v[m], ddof=1) / np.sqrt(len(v[m]))), 4)] for m in tr}}
     for tag, ref in (("reference fp32 Gram", a), ("reference exact Gram", b)):
         vals = {m: [x["psnr"] for x in ref[m]["variants"].values()] for m in tr}
         se = np.sqrt(sum(np.var(vals[m], ddof=1) / len(vals[m]) for m in tr)) / len(tr)

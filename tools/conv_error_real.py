@@ -36,10 +36,14 @@ def main():
     x0 = deqsci_amd.initial_point(y, Phi, None, None)
     rec = eng.reconstruct(y, Phi)                                        # a 30-iteration iterate
     inputs = {"x0": x0, "iterate30": rec}
+    for k in (3, 5, 10, 20, 60, 120):                                    # how the rounding of each form moves as the iterate settles
+        e = DEQSCIEngine(net, max_iter=k, use_graph=False, conv64="f22")
+        inputs[f"iterate{k}"] = e.reconstruct(y, Phi)
     out = []
     for name, z in inputs.items():
         x = z.permute(0, 3, 1, 2).reshape(8, 1, 256, 256).contiguous()
-        sig = torch.full((1,), SIGMA0, device="cuda")
+        k_it = 0 if name == "x0" else int(name[7:])
+        sig = torch.full((1,), SIGMA0 * 0.971 ** k_it, device="cuda")   # (the sigma the loop would hand FFDNet at that call)
         h = _hip.ffdnet_head(x, den.head_w, sig)                         # (8,64,128,128) channels_last
         for li in range(1, len(den.fast) - 1):
             w, b, relu = den.fast[li]
