@@ -234,11 +234,11 @@ def run_rank(args):
         for _ in range(2):
             step()
     timing = not (selftest or args.no_kernel_timing or graph_mode) and rank == 0
-    timer = conv_timer = None
-    conv_shape = []
+    timer = None
+    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0}
     if timing:
         timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
-        conv_timer = _hip.KernelTimer(capacity=400)                 # a sample of launches is enough
+        conv_timers = {"f22": _hip.KernelTimer(capacity=400), "f44": _hip.KernelTimer(capacity=400)}   # a sample of launches of each form is enough
         timing_on = [False]
         orig = _hip.anderson_mix_gap
 
@@ -250,11 +250,16 @@ def run_rank(args):
         orig_wg = _hip.conv3x3_c64
 
         def timed_conv64(x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
-            if not timing_on[0] or conv_timer.full:
+            if not timing_on[0]:
                 return orig_wg(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
-            o, kind = conv_timer.conv64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
-            conv_shape[:] = ([x.n, x.H, x.W] if isinstance(x, _hip.Blk32) else [x.shape[0], x.shape[2], x.shape[3]]) + [kind]
-            return o
+            blk = isinstance(x, _hip.Blk32)
+            dims = [x.n, x.H, x.W] if blk else [x.shape[0], x.shape[2], x.shape[3]]
+            kind = "f44" if blk else _hip.conv64_kernel_for(dims[0], dims[1], dims[2], x.device if not blk else x.t.device, policy)
+            conv_launches[kind] += 1
+            conv_shape[kind] = dims
+            if conv_timers[kind].full:
+                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
+            return conv_timers[kind].conv64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)[0]
         _hip.conv3x3_c64 = timed_conv64
 
     def fence():
@@ -297,7 +302,8 @@ def run_rank(args):
                                f"{args.denoiser} denoiser ({'net_gray.pth weights, substitute for the missing ffdnet.ckpt' if args.denoiser == 'ffdnet' else 'cnn.ckpt'}), "
                                f"Anderson m=5 lam=1e-2 beta=1, and_maxiters={args.iters}, tol=1e-5",
                    "global_batch": M, "batch_per_gpu": per, "frames_per_measurement": B, "f_calls_per_step": f_calls,
-                   "conv64_policy": None if selftest else f"{eng.conv64} -> {eng.conv64_policy}",
+                   "conv64_policy": None if selftest else (f"{eng.conv64} -> F(2x2,3x3) for f-calls < {eng.conv64_f22_calls}, then {eng.conv64_policy}"
+                                                           if eng.conv64_f22_calls else f"{eng.conv64} -> {eng.conv64_policy}"),
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU",
                    "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches"},
         "final_res": info.get("res"),
@@ -329,18 +335,21 @@ def run_rank(args):
                                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
                                    "note": f"in-loop figure at bsz {bsz}: the kernel's {nbytes / 2**20:.0f} MiB working set sits partly in the "
                                            "256 MiB Infinity Cache; hbm_stream_roofline is the same kernel on a working set far beyond it"}
-        cms = conv_timer.durations_ms() if timing else []
-        if cms:
-            # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call).
-            # Algorithmic flops per launch = the MFMA flops of the Winograd form the launcher picked: direct flops / 4 for
-            # F(4x4,3x3) (36 products per 16 outputs), / 2.25 for F(2x2,3x3), against the dense fp32 MFMA peak;
-            # "hbm_roofline" is the fused streaming kernel of the DEQ loop itself.
-            nimg, ch, cw, kind = conv_shape
+        # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call), in the Winograd
+        # form that takes the larger share of the step (conv64 policy "auto" runs the first f-calls of a chaotic configuration on
+        # F(2x2,3x3) and the rest on F(4x4,3x3)); the other form, if it ran, is reported as "roofline_other_form".
+        # Algorithmic flops per launch = the MFMA flops of the form: direct flops / 4 for F(4x4,3x3) (36 products per 16 outputs),
+        # / 2.25 for F(2x2,3x3), against the dense fp32 MFMA peak; "hbm_roofline" is the fused streaming kernel of the DEQ loop.
+        forms = {}
+        for kind, ct in (conv_timers.items() if timing else ()):
+            cms = ct.durations_ms()
+            if not cms:
+                continue
+            nimg, ch, cw = conv_shape[kind]
             red = 4.0 if kind == "f44" else 2.25
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
             cavg = 1e-3 * sum(cms) / len(cms)
-            n_conv = 13 if args.denoiser == "ffdnet" else 2       # 64->64 layers per denoiser call (models.py:53-58 / SimpleCNN_models.py:47-53)
-            share = cavg * n_conv * f_calls / (elapsed / args.steps)
+            share = cavg * conv_launches[kind] / elapsed
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
             for wname in (("r03_pmc_winograd44.json", "r02_pmc_winograd44.json") if kind == "f44" else
                           ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")):
@@ -352,26 +361,33 @@ def run_rank(args):
                         wtraffic = rec["hbm_bytes_per_launch"]
             kname = ("deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)" if kind == "f44" else
                      "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)")
-            out["roofline"] = {"kernel": kname,
-                               "bound": "mfma", "achieved": direct / red / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
-                               "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
-                               "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "share_of_step_time": round(share, 3),
-                               "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA "
-                                        "work, avg_launch_us and direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
-                                        "F(2x2,3x3): the parity-neutral form for FFDNet + Anderson beyond 30 iterations (conv64_policy), and the "
-                                        "launcher's choice below one wave of F(4x4,3x3) block tiles")}
-            out["config"]["conv64_kernel"] = kind
+            forms[kind] = {"kernel": kname,
+                           "bound": "mfma", "achieved": direct / red / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
+                           "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
+                           "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "launches_per_step": conv_launches[kind] // max(args.steps, 1),
+                           "share_of_step_time": round(share, 3),
+                           "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA "
+                                    "work, avg_launch_us and direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
+                                    "F(2x2,3x3): the form of the early f-calls of a chaotic configuration (conv64 policy), and the "
+                                    "launcher's choice below one wave of F(4x4,3x3) block tiles")}
+        if forms:
+            order = sorted(forms, key=lambda k: -forms[k]["share_of_step_time"])
+            out["roofline"] = forms[order[0]]
+            out["config"]["conv64_kernel"] = order[0] if len(order) == 1 else f"{order[0]} ({forms[order[0]]['launches_per_step']} launches per step) + {order[1]} ({forms[order[1]]['launches_per_step']})"
+            if len(order) > 1:
+                out["roofline_other_form"] = forms[order[1]]
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]
         if timing:
             timer.close()
-            conv_timer.close()
+            for ct in conv_timers.values():
+                ct.close()
         if world == 1 and not selftest:
             if not args.no_other_kernel and args.denoiser == "ffdnet" and not args.no_winograd:
                 # the same step with the OTHER conv64 policy, once, outside the timed region: the reader sees what the parity-neutral
                 # default costs (or what the throughput-first choice would buy) on this very box
-                other = "fast" if eng.conv64_policy == "f22" else "f22"
+                other = "f22" if (eng.conv64_policy != "f22" and not eng.conv64_f22_calls) else "fast"
                 eng2 = build_engine(args, dev, conv64=other)
                 step2 = make_step(eng2, y, Phi, M, distributed.GatherTimer())
                 step2()

@@ -476,7 +476,7 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
     if xt.dtype != torch.float32 or not xt.is_cuda:
         raise DeqsciHipError("conv3x3_c64_winograd44: fp32 channels_last GPU activation with 64 channels required")
     _check_packed(u_packed, 36, "pack_winograd44_weights")
-    if bias is not None and bias.numel() != 64:
+    if bias is not None and bias.numel() < 64:
         raise DeqsciHipError(f"conv3x3_c64_winograd44: bias must have 64 elements, got {bias.numel()}")
     if out_blk:
         o = out if out is not None else Blk32.empty(n, H, W, xt.device)

@@ -60,6 +60,8 @@ namespace w44 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
 
 constexpr int CK = 8, NCHUNK = 64 / CK;
 constexpr int WAVES = 8, TBW = 64 * WAVES;
@@ -263,7 +265,9 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
     // V = B^T d B, rows [3 rg, 3 rg + 3) only
     auto transform = [&](auto rg_c, int buf) __attribute__((always_inline)) {
         constexpr int RG = decltype(rg_c)::value;
-        const float* pp = Raw + buf * RAW_BUF;
+        // (patch reads are VOLATILE LDS loads: hipcc otherwise fuses pairs of them into ds_read2_b64, which is banked mod 32 over 16-lane
+        // groups - the layout below is conflict-free for ds_read_b64's 64 banks over 32 lanes and 2-way conflicted for the fused form)
+        const lds_float* pp = (const lds_float*)Raw + buf * RAW_BUF;
         // float offset of channel pair q of patch pixel (0,0) of the lane's tile in a raw buffer; patch pixel (pr, pc) is a constant
         // away, with the channel halves the other way round in patch rows 4, 5 (they belong to the next group of four pixel rows).
         // Recomputed here from an opaque copy of the lane index instead of being carried through the loop.
@@ -277,8 +281,8 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             for (int j = 0; j < 6; ++j) {
                 f32x2 d[6];
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
-                bt_lo(d, t[0][j], t[1][j], t[2][j]);
+                for (int pr = 0; pr < 5; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const volatile lds_f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
+                bt_lo(d, t[0][j], t[1][j], t[2][j]);          // (rows 0..2 of B^T do not touch patch row 5, rows 3..5 not row 0: a volatile load is not dropped for being unused)
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(TBW, 2) void winograd44_conv64_kernel(const float* 
             for (int j = 0; j < 6; ++j) {
                 f32x2 d[6];
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
+                for (int pr = 1; pr < 6; ++pr) d[pr] = (W44_ABL & 64) ? v[pr + j] : *reinterpret_cast<const volatile lds_f32x2*>(pp + (pr < 4 ? pbaseA : pbaseB) + patch_off(pr, j));
                 bt_hi(d, t[0][j], t[1][j], t[2][j]);
                 __builtin_amdgcn_sched_barrier(0);
             }

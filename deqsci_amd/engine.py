@@ -242,23 +242,29 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto"):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=40):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if conv64 not in ("auto", "fast", "f22", "f44"):
             raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'f22' or 'f44'")
         # Which Winograd form runs the 64->64 layers.  "fast": the faster kernel per launch (F(4x4,3x3) from about one block tile per
-        # CU on).  "auto" (default) = "fast", EXCEPT for the one regime where the choice is visible in the result: FFDNet under Anderson
-        # beyond ~30 iterations is chaotic, and there the rounding noise of the denoiser on the noisy early iterates moves
-        # the ensemble mean of the reconstructions (6 traffic measurements x 25 starts, profiles/r03_config2_ensembles.json: reference
-        # 21.434 +- 0.008 dB; F(2x2,3x3) 21.420, direct fp32 convolution 21.410, F(4x4,3x3) 21.395, all +- 0.004) - so that regime runs
-        # F(2x2,3x3), the least noisy of the three, at every batch size (results then do not depend on how many measurements share a
-        # call either).  Every well-conditioned configuration (SimpleCNN, Picard, <= 30 iterations) is identical to 1e-5 under both.
+        # CU on); "f22" / "f44": that form always.  "auto" (default) = "fast", EXCEPT in the one regime where the choice is visible in
+        # the result: FFDNet under Anderson beyond ~30 iterations is chaotic, and there the rounding noise of the denoiser
+        # on the EARLY iterates - blocky Phi^T y-like inputs, on which F(4x4,3x3) is 3x noisier than F(2x2,3x3); on settled iterates
+        # the two are on par (tools/fcall_error_along_loop.py, tools/conv_error_real.py) - moves the ensemble mean of the
+        # reconstructions.  Six traffic measurements x 25 starts (tools/config2_ensemble.py, profiles/r03_config2_ensembles.json):
+        # reference 21.434 +- 0.008 dB; F(2x2,3x3) throughout 21.420 +- 0.004; F(2x2,3x3) for the first 40 / 20 / 10 f-calls, then
+        # "fast": 21.417 / 21.414 / 21.404; "fast" throughout 21.395; MIOpen's direct fp32 convolution 21.410.  So "auto" runs the first
+        # `conv64_f22_calls` (40) f-calls of that regime on F(2x2,3x3) at every batch size and the rest on the faster kernel: the
+        # statistics of F(2x2,3x3) throughout, at 0.78 of its cost.  Well-conditioned configurations (SimpleCNN, Picard, <= 30
+        # iterations) agree to 1e-5 under every policy.
         self.conv64 = conv64
         chaotic = getattr(denoiser, "tag", None) == "ffdnet" and iterator == "anderson" and int(max_iter) > 30
-        self.conv64_policy = ("f22" if chaotic else "fast") if conv64 == "auto" else conv64
+        self.conv64_policy = "fast" if conv64 == "auto" else conv64
+        self.conv64_f22_calls = int(conv64_f22_calls) if (conv64 == "auto" and chaotic) else None
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
                              fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy)
+        self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
         self.max_iter, self.tol = int(max_iter), float(tol)

