@@ -33,6 +33,7 @@ from deqsci_amd import distributed  # noqa: E402  (no GPU work at import)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA (the 5 PF headline figure includes 2:1 sparsity)
 
 
 def mix_gap_bytes(bsz, H, W, B, n):
@@ -151,9 +152,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch-per-gpu", type=int, default=8, help="weak scaling (default): measurements per GPU")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: total number of measurements, sharded over the GPUs (BASELINE config 3: 64)")
-    ap.add_argument("--conv64", default="auto", choices=["auto", "fast", "f22", "f44"],
-                    help="Winograd form of the 64->64 layers (DEQSCIEngine): auto = F(2x2,3x3) for FFDNet + Anderson beyond 30 "
-                         "iterations (parity-neutral), the faster kernel per launch otherwise")
+    ap.add_argument("--conv64", default="auto", choices=["auto", "fast", "fast32", "f22", "f44", "s16"],
+                    help="kernel of the 64->64 layers (DEQSCIEngine): auto = fast = split-fp16 direct convolution on the f16 matrix cores "
+                         "where it is faster, Winograd F(2x2,3x3) below; fast32 = fp32 MFMA arithmetic only (F(4x4,3x3) / F(2x2,3x3))")
+    ap.add_argument("--conv64-f22-calls", type=int, default=None, help="run the first K f-calls on F(2x2,3x3) whatever the policy")
     ap.add_argument("--no-other-kernel", action="store_true", help="skip the one extra step with the other conv64 policy")
     ap.add_argument("--iters", type=int, default=180)
     ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
@@ -174,7 +176,7 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def build_engine(args, dev, conv64=None):
+def build_engine(args, dev, conv64=None, f22_calls="args"):
     from deqsci_amd import checkpoint
     from deqsci_amd.cli import build_denoiser
     from deqsci_amd.engine import DEQSCIEngine
@@ -190,7 +192,7 @@ def build_engine(args, dev, conv64=None):
     return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                         channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
                         fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
-                        conv64=args.conv64 if conv64 is None else conv64, **kw)
+                        conv64=args.conv64 if conv64 is None else conv64, conv64_f22_calls=args.conv64_f22_calls if f22_calls == "args" else f22_calls, **kw)
 
 
 def make_step(eng, y_local, Phi_local, M, gather_timer):
@@ -235,10 +237,10 @@ def run_rank(args):
             step()
     timing = not (selftest or args.no_kernel_timing or graph_mode) and rank == 0
     timer = None
-    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0}
+    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0}
     if timing:
         timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
-        conv_timers = {"f22": _hip.KernelTimer(capacity=400), "f44": _hip.KernelTimer(capacity=400)}   # a sample of launches of each form is enough
+        conv_timers = {k: _hip.KernelTimer(capacity=400) for k in conv_launches}   # a sample of launches of each kernel is enough
         timing_on = [False]
         orig = _hip.anderson_mix_gap
 
@@ -247,20 +249,14 @@ def run_rank(args):
                 return orig(ws, beta, n, *a)
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
-        orig_wg = _hip.conv3x3_c64
 
-        def timed_conv64(x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
+        def conv_hook(kind, n, H, W):                          # _hip.CONV64_EVENT_HOOK: a (start, stop) event pair per 64->64 launch
             if not timing_on[0]:
-                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
-            blk = isinstance(x, _hip.Blk32)
-            dims = [x.n, x.H, x.W] if blk else [x.shape[0], x.shape[2], x.shape[3]]
-            kind = "f44" if blk else _hip.conv64_kernel_for(dims[0], dims[1], dims[2], x.device if not blk else x.t.device, policy)
+                return None
             conv_launches[kind] += 1
-            conv_shape[kind] = dims
-            if conv_timers[kind].full:
-                return orig_wg(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)
-            return conv_timers[kind].conv64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy)[0]
-        _hip.conv3x3_c64 = timed_conv64
+            conv_shape[kind] = [n, H, W]
+            return conv_timers[kind].pair()
+        _hip.CONV64_EVENT_HOOK = conv_hook
 
     def fence():
         if world > 1:
@@ -335,72 +331,75 @@ def run_rank(args):
                                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
                                    "note": f"in-loop figure at bsz {bsz}: the kernel's {nbytes / 2**20:.0f} MiB working set sits partly in the "
                                            "256 MiB Infinity Cache; hbm_stream_roofline is the same kernel on a working set far beyond it"}
-        # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call), in the Winograd
-        # form that takes the larger share of the step (conv64 policy "auto" runs the first f-calls of a chaotic configuration on
-        # F(2x2,3x3) and the rest on F(4x4,3x3)); the other form, if it ran, is reported as "roofline_other_form".
-        # Algorithmic flops per launch = the MFMA flops of the form: direct flops / 4 for F(4x4,3x3) (36 products per 16 outputs),
-        # / 2.25 for F(2x2,3x3), against the dense fp32 MFMA peak; "hbm_roofline" is the fused streaming kernel of the DEQ loop.
+        # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call), on the kernel that takes
+        # the largest share of the step; any other 64->64 kernel that ran is reported under "roofline_other_kernels".
+        # Algorithmic flops per launch = the MFMA flops the kernel's algorithm executes: split-fp16 direct
+        # convolution 3 x the direct flops (three f16 products per multiplication) against the dense f16 MFMA peak; Winograd F(4x4,3x3)
+        # direct / 4, F(2x2,3x3) direct / 2.25 against the dense fp32 MFMA peak.  "hbm_roofline" is the fused streaming kernel of the DEQ loop.
         forms = {}
         for kind, ct in (conv_timers.items() if timing else ()):
             cms = ct.durations_ms()
             if not cms:
                 continue
             nimg, ch, cw = conv_shape[kind]
-            red = 4.0 if kind == "f44" else 2.25
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
+            mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS), "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
             cavg = 1e-3 * sum(cms) / len(cms)
             share = cavg * conv_launches[kind] / elapsed
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            for wname in (("r03_pmc_winograd44.json", "r02_pmc_winograd44.json") if kind == "f44" else
-                          ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")):
+            for wname in {"s16": ("r03_pmc_conv_s16.json",), "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
+                          "f22": ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")}[kind]:
                 wfile = os.path.join(ROOT, "profiles", wname)
                 if wtraffic is None and os.path.exists(wfile):
                     with open(wfile) as fh:
                         rec = json.load(fh)
                     if rec.get("shape") == [nimg, 64, ch, cw]:
                         wtraffic = rec["hbm_bytes_per_launch"]
-            kname = ("deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)" if kind == "f44" else
-                     "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)")
+            kname = {"s16": "deqsci::s16::conv_s16_kernel (conv3x3 64->64 + bias + ReLU, direct convolution on the f16 matrix cores: fp32 operands as hi + lo "
+                            "fp16 pairs, three MFMAs per product, fp32 accumulation)",
+                     "f44": "deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
+                     "f22": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)"}[kind]
             forms[kind] = {"kernel": kname,
-                           "bound": "mfma", "achieved": direct / red / cavg / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": direct / red / cavg / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": wtraffic,
-                           "algorithmic_flops_per_launch": direct / red, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
+                           "bound": "mfma", "achieved": direct * mult / cavg / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": direct * mult / cavg / 1e12 / peak, "traffic": wtraffic,
+                           "algorithmic_flops_per_launch": direct * mult, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
                            "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "launches_per_step": conv_launches[kind] // max(args.steps, 1),
                            "share_of_step_time": round(share, 3),
-                           "note": ("F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA "
-                                    "work, avg_launch_us and direct_conv_equivalent_TFLOPs compare across the two" if kind == "f44" else
-                                    "F(2x2,3x3): the form of the early f-calls of a chaotic configuration (conv64 policy), and the "
-                                    "launcher's choice below one wave of F(4x4,3x3) block tiles")}
+                           "note": {"s16": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; on random operands the kernel runs against the chip's power limit "
+                                           "(1.9-2.0 GHz, not 2.4): see DESIGN.md section 6",
+                                    "f44": "F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA work",
+                                    "f22": "F(2x2,3x3): the launcher's choice below one wave of 16 x 32 block tiles"}[kind]}
         if forms:
             order = sorted(forms, key=lambda k: -forms[k]["share_of_step_time"])
             out["roofline"] = forms[order[0]]
-            out["config"]["conv64_kernel"] = order[0] if len(order) == 1 else f"{order[0]} ({forms[order[0]]['launches_per_step']} launches per step) + {order[1]} ({forms[order[1]]['launches_per_step']})"
+            out["config"]["conv64_kernel"] = " + ".join(f"{k} ({forms[k]['launches_per_step']} launches per step)" for k in order)
             if len(order) > 1:
-                out["roofline_other_form"] = forms[order[1]]
+                out["roofline_other_kernels"] = {k: forms[k] for k in order[1:]}
         if "roofline" not in out and "hbm_roofline" in out:      # a run without the Winograd kernel (--no-winograd)
             out["roofline"] = out["hbm_roofline"]
         if timing:
             timer.close()
+            _hip.CONV64_EVENT_HOOK = None
             for ct in conv_timers.values():
                 ct.close()
         if world == 1 and not selftest:
-            if not args.no_other_kernel and args.denoiser == "ffdnet" and not args.no_winograd:
-                # the same step with the OTHER conv64 policy, once, outside the timed region: the reader sees what the parity-neutral
-                # default costs (or what the throughput-first choice would buy) on this very box
-                other = "f22" if (eng.conv64_policy != "f22" and not eng.conv64_f22_calls) else "fast"
-                eng2 = build_engine(args, dev, conv64=other)
-                step2 = make_step(eng2, y, Phi, M, distributed.GatherTimer())
-                step2()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                step2()
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t1
-                out["other_conv64_policy"] = {"conv64_policy": other, "value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": 1,
-                                              "note": ("F(4x4,3x3) wherever it is faster: +throughput, but its rounding on noisy iterates moves the chaotic "
-                                                       "FFDNet + Anderson @180 ensemble by -0.02..-0.04 dB (profiles/r03_config2_ensembles.json), so it is opt-in "
-                                                       "there (--conv64 fast)") if other == "fast" else "F(2x2,3x3) everywhere"}
-                del eng2, step2
+            if not args.no_other_kernel and not args.no_winograd:
+                # the same step under the OTHER conv64 policies, once each, outside the timed region: what the all-fp32-MFMA paths deliver on
+                # this very box (the reader who does not accept split-fp16 operands as fp32 arithmetic takes "fast32 + F(2x2) for 40 f-calls")
+                out["other_conv64_policies"] = {}
+                for name, pol, k in (("fast32", "fast32", None), ("fast32, first 40 f-calls on F(2x2,3x3)", "fast32", 40), ("f22", "f22", None)):
+                    if pol == eng.conv64_policy and k == eng.conv64_f22_calls:
+                        continue
+                    eng2 = build_engine(args, dev, conv64=pol, f22_calls=k)
+                    step2 = make_step(eng2, y, Phi, M, distributed.GatherTimer())
+                    step2()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    step2()
+                    torch.cuda.synchronize()
+                    dt2 = time.perf_counter() - t1
+                    out["other_conv64_policies"][name] = {"value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": 1}
+                    del eng2, step2
             if not args.no_hbm_stream:
                 del y, Phi
                 out["hbm_stream_roofline"] = hbm_stream_roofline(H, W, B, eng.m, dev)

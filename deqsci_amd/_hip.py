@@ -45,6 +45,12 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _int, _ptr, _ptr, _ptr],
+    "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "deqsci_ffdnet_head_sp16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_ffdnet_tail_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
+    "deqsci_conv3x3_c64_to_1_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -303,8 +309,15 @@ def pack_tail_weights(w):
 
 
 def ffdnet_tail(h, w_packed, out=None, in_bias=None):
-    """h (n,64,H,W) channels_last -> planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h', w, pad=1), 2) with
-    h' = h, or relu(h + in_bias[c]) when in_bias is given (previous layer's epilogue fused into the read)."""
+    """h (n,64,H,W) channels_last, or an Sp16 -> planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h', w, pad=1), 2) with
+    h' = h, or relu(h + in_bias[c]) when in_bias is given (previous layer's epilogue fused into the read; fp32 input only)."""
+    if isinstance(h, Sp16):
+        if in_bias is not None:
+            raise DeqsciHipError("ffdnet_tail: in_bias is not supported with an Sp16 input")
+        o = out if out is not None else torch.empty((h.n, 1, 2 * h.H, 2 * h.W), device=h.t.device, dtype=torch.float32)
+        with _dev(h.t):
+            _check(load().deqsci_ffdnet_tail_sp16(h.t.data_ptr(), _p(w_packed, "w_packed"), _p(o, "out"), h.n, h.H, h.W, _stream()), "ffdnet_tail_sp16")
+        return o
     n, c, H, W = h.shape
     if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
         raise DeqsciHipError("ffdnet_tail: fp32 channels_last GPU activation with 64 channels required")
@@ -323,7 +336,14 @@ def pack_c64_to_1_weights(w):
 
 
 def conv3x3_c64_to_1(h, w_packed, out=None, in_bias=None):
-    """h (n,64,H,W) channels_last -> planar (n,1,H,W) = conv3x3(h', w, pad=1), h' = h or relu(h + in_bias[c])."""
+    """h (n,64,H,W) channels_last, or an Sp16 -> planar (n,1,H,W) = conv3x3(h', w, pad=1), h' = h or relu(h + in_bias[c])."""
+    if isinstance(h, Sp16):
+        if in_bias is not None:
+            raise DeqsciHipError("conv3x3_c64_to_1: in_bias is not supported with an Sp16 input")
+        o = out if out is not None else torch.empty((h.n, 1, h.H, h.W), device=h.t.device, dtype=torch.float32)
+        with _dev(h.t):
+            _check(load().deqsci_conv3x3_c64_to_1_sp16(h.t.data_ptr(), _p(w_packed, "w_packed"), _p(o, "out"), h.n, h.H, h.W, _stream()), "conv3x3_c64_to_1_sp16")
+        return o
     n, c, H, W = h.shape
     if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
         raise DeqsciHipError("conv3x3_c64_to_1: fp32 channels_last GPU activation with 64 channels required")
@@ -341,11 +361,17 @@ def pack_c1_to_64_weights(w):
     return w.detach().float().reshape(16, 4, 9).permute(2, 0, 1).contiguous()
 
 
-def conv3x3_c1_to_64(x, w_packed, relu=True, out=None):
-    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation."""
+def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False):
+    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True)."""
     n, c, H, W = x.shape
     if c != 1:
         raise DeqsciHipError(f"conv3x3_c1_to_64: (n,1,H,W) image required, got {tuple(x.shape)}")
+    if sp16:
+        o = out if out is not None else Sp16.empty(n, H, W, x.device)
+        with _dev(x):
+            _check(load().deqsci_conv3x3_c1_to_64_sp16(_p(x, "x"), _p(w_packed, "w_packed"), o.t.data_ptr(), n, H, W, 1 if relu else 0,
+                                                       _stream()), "conv3x3_c1_to_64_sp16")
+        return o
     o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     with _dev(x):
         _check(load().deqsci_conv3x3_c1_to_64_f32(_p(x, "x"), _p(w_packed, "w_packed"), o.data_ptr(), n, H, W, 1 if relu else 0,
@@ -360,15 +386,21 @@ def pack_head_weights(w):
     return w.detach().float().reshape(16, 4, 45).permute(2, 0, 1).contiguous()
 
 
-def ffdnet_head(x, w_packed, sigma, out=None):
+def ffdnet_head(x, w_packed, sigma, out=None, sp16=False):
     """x (n,1,2H,2W) planar, sigma (n,) or (1,) -> relu(conv3x3(cat(sigma map, pixel_unshuffle(x,2)), w)) as a
-    channels_last (n,64,H,W) activation."""
+    channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True: what a run of split-fp16 64->64 layers consumes)."""
     n, c, H2, W2 = x.shape
     if c != 1 or H2 % 2 or W2 % 2:
         raise DeqsciHipError(f"ffdnet_head: (n,1,even,even) image required, got {tuple(x.shape)}")
     if sigma.numel() not in (1, n) or sigma.dtype != torch.float32 or not sigma.is_cuda:
         raise DeqsciHipError("ffdnet_head: sigma must be a fp32 GPU tensor with 1 or n elements")
     H, W = H2 // 2, W2 // 2
+    if sp16:
+        o = out if out is not None else Sp16.empty(n, H, W, x.device)
+        with _dev(x):
+            _check(load().deqsci_ffdnet_head_sp16(_p(x, "x"), _p(w_packed, "w_packed"), sigma.data_ptr(),
+                                                  0 if sigma.numel() == 1 else sigma.stride(0), o.t.data_ptr(), n, H, W, _stream()), "ffdnet_head_sp16")
+        return o
     o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32,
                                                   memory_format=torch.channels_last)
     with _dev(x):
@@ -397,16 +429,21 @@ def pack_winograd_weights(w):
     return U.permute(4, 0, 1, 5, 3, 2, 6).contiguous().float()   # [c][xi][wn][q][i][j][s]
 
 
-def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None):
-    """x (n,64,H,W) channels_last -> relu(conv3x3(x, w, pad=1) + bias) as a new channels_last tensor."""
+def conv3x3_c64_winograd(x, u_packed, bias=None, relu=True, out=None, events=None):
+    """x (n,64,H,W) channels_last -> relu(conv3x3(x, w, pad=1) + bias) as a new channels_last tensor (Winograd F(2x2,3x3), fp32 MFMA)."""
     n, c, H, W = x.shape
     if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
         raise DeqsciHipError("conv3x3_c64_winograd: fp32 channels_last GPU activation with 64 channels required")
     _check_packed(u_packed, 16, "pack_winograd_weights")
     o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
+    ev = _hook_events("f22", n, H, W, events)
     with _dev(x):
-        _check(load().deqsci_conv3x3_c64_winograd_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
-                                                      n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd")
+        if ev is None:
+            _check(load().deqsci_conv3x3_c64_winograd_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
+                                                          n, H, W, 1 if relu else 0, _stream()), "conv3x3_c64_winograd")
+        else:
+            _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
+                                                                n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_winograd_timed")
     return o
 
 
@@ -424,6 +461,19 @@ def pack_winograd44_weights(w):
 
 
 ACT_NHWC, ACT_BLK32 = 0, 1
+
+# Measurement hook (bench.py): when set, every launch of a 64->64 kernel asks it for a (start, stop) pair of raw hipEvent_t handles -
+# hook(kind, n, H, W) -> (ev0, ev1) or None - and the dispatch's own begin / end timestamps are written to them.
+CONV64_EVENT_HOOK = None
+
+
+def _hook_events(kind, n, H, W, events):
+    if events is not None:
+        return events
+    if CONV64_EVENT_HOOK is not None:
+        return CONV64_EVENT_HOOK(kind, n, H, W)
+    return None
+
 
 
 class Blk32:
@@ -489,7 +539,7 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
                 or not o.is_contiguous(memory_format=torch.channels_last)):
             raise DeqsciHipError("conv3x3_c64_winograd44: out must be a fp32 channels_last (n,64,H,W) tensor on the input's device")
         ot = o
-    ev = events if events is not None else (None, None)
+    ev = _hook_events("f44", n, H, W, events) or (None, None)
     with _dev(xt):
         _check(load().deqsci_conv3x3_c64_winograd44_layout_f32(xt.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True), ot.data_ptr(),
                                                                n, H, W, 1 if relu else 0, in_l, ACT_BLK32 if out_blk else ACT_NHWC, _stream(),
@@ -497,25 +547,115 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
     return o
 
 
+# ----------------------------------------------------------------------------- split-fp16 direct convolution (csrc/conv_s16.hip)
+SP16_ACT_SCALE = 256.0     # activations are stored as fp16 pieces of 2^8 x: |x| < 255 (FFDNet's stay below 10); an overflow shows as inf / NaN
+
+
+class Sp16:
+    """An activation (n,64,H,W) in the "sp16" layout of csrc/conv_s16.hip: t is (n, 4, 2, 2, H, W, 8) float16 =
+    [cin chunk][piece: hi, lo][8-channel block][H][W][8 channels], holding 2^8 x as hi + lo.  Only exists between 64->64 layers."""
+    __slots__ = ("t", "n", "H", "W")
+
+    def __init__(self, t, n, H, W):
+        self.t, self.n, self.H, self.W = t, n, H, W
+
+    @staticmethod
+    def empty(n, H, W, device):
+        return Sp16(torch.empty((n, 4, 2, 2, H, W, 8), dtype=torch.float16, device=device), n, H, W)
+
+    def to_nchw(self):
+        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: (hi + lo) / 2^8, exactly."""
+        v = (self.t[:, :, 0].float() + self.t[:, :, 1].float()) / SP16_ACT_SCALE       # (n, 4, 2, H, W, 8)
+        return v.permute(0, 1, 2, 5, 3, 4).reshape(self.n, 64, self.H, self.W).contiguous(memory_format=torch.channels_last)
+
+
+def to_split16(x, out=None):
+    """x (n,64,H,W) fp32 channels_last -> Sp16 (HIP streaming kernel)."""
+    n, c, H, W = x.shape
+    if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
+        raise DeqsciHipError("to_split16: fp32 channels_last GPU activation with 64 channels required")
+    o = out if out is not None else Sp16.empty(n, H, W, x.device)
+    with _dev(x):
+        _check(load().deqsci_f32_to_split16(x.data_ptr(), o.t.data_ptr(), n, H, W, SP16_ACT_SCALE, _stream()), "f32_to_split16")
+    return o
+
+
+class Split16Weights:
+    """(64,64,3,3) fp32 conv weight as two fp16 pieces of 2^sw w in the LDS order of csrc/conv_s16.hip:
+    [cin chunk c (4)][tap (9)][piece: hi, lo (2)][cout group g (2)][lane (64)][j (8)], cout = 32 g + lane % 32, cin = 16 c + 8 (lane // 32) + j.
+    sw is the power of two that puts max |w| into [2^13, 2^14): the lo pieces of every weight that matters are then normal fp16 numbers."""
+    __slots__ = ("packed", "sw", "out_scale_sp16", "out_scale_f32")
+
+    def __init__(self, w):
+        if tuple(w.shape) != (64, 64, 3, 3):
+            raise DeqsciHipError(f"split16 conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
+        w = w.detach().float()
+        amax = float(w.abs().max())
+        import math
+        self.sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        ws = w * (2.0 ** self.sw)
+        hi = ws.half()
+        lo = (ws - hi.float()).half()
+        if not bool(torch.isfinite(hi).all()):
+            raise DeqsciHipError("split16 weights overflow fp16")
+        p = torch.stack((hi, lo), 0)                                   # (hl, cout, cin, ky, kx)
+        p = p.reshape(2, 2, 32, 4, 2, 8, 9)                            # [hl][g][m][c][kb][j][tap]
+        self.packed = p.permute(3, 6, 0, 1, 4, 2, 5).contiguous()      # [c][tap][hl][g][kb][m][j]  (lane = 32 kb + m)
+        self.out_scale_sp16 = 2.0 ** (-self.sw)                        # acc = 2^(8+sw) sum w x  ->  2^8 (sum w x): the next layer's sp16 scale
+        self.out_scale_f32 = 2.0 ** (-self.sw) / SP16_ACT_SCALE
+
+
+def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=False, events=None):
+    """x Sp16 -> relu(conv3x3(x, w, pad=1) + bias) as an Sp16 (out_f32=False) or an fp32 channels_last (n,64,H,W) tensor: the
+    direct convolution on the f16 matrix cores with split operands (csrc/conv_s16.hip).  `weights` = Split16Weights(w)."""
+    if not isinstance(x, Sp16) or tuple(x.t.shape) != (x.n, 4, 2, 2, x.H, x.W, 8) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
+        raise DeqsciHipError("conv3x3_c64_split16: a contiguous Sp16 GPU activation is required")
+    if not isinstance(weights, Split16Weights) or weights.packed.numel() != 4 * 9 * 2 * 2 * 64 * 8:
+        raise DeqsciHipError("conv3x3_c64_split16: weights must be a Split16Weights")
+    n, H, W, dev = x.n, x.H, x.W, x.t.device
+    if out_f32:
+        o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        ot, b = o, bias
+        scale = weights.out_scale_f32
+    else:
+        o = out if out is not None else Sp16.empty(n, H, W, dev)
+        ot, b = o.t, (None if bias is None else bias * SP16_ACT_SCALE)
+        scale = weights.out_scale_sp16
+    ev = _hook_events("s16", n, H, W, events) or (None, None)
+    wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
+    with _dev(x.t):
+        _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(b, "bias", True), ot.data_ptr(), n, H, W, 1 if relu else 0,
+                                                 float(scale), 1 if out_f32 else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
+    return o
+
+
 class Conv64Weights:
-    """The transformed weights of one 64->64 layer for both Winograd kernels."""
-    __slots__ = ("f22", "f44")
+    """The weights of one 64->64 layer for all three kernels (the split-fp16 pack is made on first use)."""
+    __slots__ = ("f22", "f44", "_w", "_s16")
 
     def __init__(self, w):
         self.f22 = pack_winograd_weights(w)
         self.f44 = pack_winograd44_weights(w)
+        self._w, self._s16 = w.detach(), None
+
+    @property
+    def s16(self):
+        if self._s16 is None:
+            self._s16 = Split16Weights(self._w)
+        return self._s16
 
 
 def pack_conv64_weights(w):
     return Conv64Weights(w)
 
 
-# launch time of one block tile per CU, us (tools/w44_check.py, profiles/r02_w44_shapes.jsonl): F(4x4,3x3) does 2x the pixels per tile
-_T_TILE_F22, _T_TILE_F44 = 21.5, 35.5
+# launch time of one block tile per CU, us (tools/w44_check.py, tools/s16_check.py; profiles/r02_w44_shapes.jsonl, r03_s16_*): the F(4x4,3x3)
+# and the split-fp16 kernels do 2x the pixels of F(2x2,3x3) per tile
+_T_TILE_F22, _T_TILE_F44, _T_TILE_S16 = 21.5, 33.5, 29.5
 
 
 W44_MAX_PIXELS = (0x80000000 - 4096 - 2048 - 16) // 256   # per image, width padded to 32 columns
-FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44": A/B runs of the tools; overrides every policy below
+FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44" / "s16": A/B runs of the tools; overrides every policy below
 
 
 _CUS = {}
@@ -529,31 +669,42 @@ def _cus(device):
 
 
 def conv64_kernel_for(n, H, W, device=None, policy="fast"):
-    """'f44' or 'f22' for n images of H x W.  policy "fast": the faster kernel of the launch - both run one persistent workgroup per
-    CU over block tiles of 16 x 16 (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3)) output pixels, so the time is (waves of block tiles) x (time of
-    a tile).  policy "f22": always F(2x2,3x3), whose rounding on noisy inputs (1.8e-7 per layer against float64; F(4x4,3x3) 5.5e-7, a
-    direct fp32 convolution 3e-7: tools/conv_error_real.py) is the one that leaves the chaotic FFDNet + Anderson runs where the
-    reference has them (DEQSCIEngine's `conv64="auto"`).  policy "f44": F(4x4,3x3) whatever the size."""
-    if FORCE_CONV64 in ("f22", "f44"):
+    """'s16', 'f44' or 'f22' for a 64->64 layer on n images of H x W.  All three kernels run one persistent workgroup per CU over
+    block tiles of 16 x 16 (F(2x2,3x3)) / 16 x 32 (F(4x4,3x3), split-fp16) output pixels, so a launch takes (waves of block tiles) x
+    (time of a tile).
+      "fast"    the faster of the split-fp16 direct convolution (csrc/conv_s16.hip) and Winograd F(2x2,3x3) (csrc/winograd.hip): split-fp16
+                from about one block tile per CU on (6 images of 128 x 128), F(2x2,3x3) below
+      "fast32"  fp32 MFMA arithmetic only: the faster of F(4x4,3x3) (csrc/winograd44.hip) and F(2x2,3x3)
+      "f22" / "f44" / "s16"   that kernel whatever the size.
+    Rounding per layer against a float64 convolution on FFDNet's own data (tools/conv_error_real.py, profiles/r03_conv_error_real.json):
+    F(2x2,3x3) 2.0e-7, F(4x4,3x3) 2.2e-7 (5.6e-7 on the blocky first iterate), split-fp16 2.5e-7, MIOpen's direct fp32 convolution 3.5e-7."""
+    if FORCE_CONV64 in ("f22", "f44", "s16"):
         return FORCE_CONV64
-    if policy in ("f22", "f44"):
+    if policy in ("f22", "f44", "s16"):
         return policy
-    if policy != "fast":
-        raise DeqsciHipError(f"conv64 policy {policy!r}: expected 'fast', 'f22' or 'f44'")
-    if H * (-(-W // 32)) * 32 > W44_MAX_PIXELS:          # beyond the F(4x4,3x3) kernel's 32-bit buffer offsets (csrc/winograd44.hip launcher)
+    if policy not in ("fast", "fast32"):
+        raise DeqsciHipError(f"conv64 policy {policy!r}: expected 'fast', 'fast32', 'f22', 'f44' or 's16'")
+    if H * (-(-W // 32)) * 32 > W44_MAX_PIXELS:          # beyond the 32-bit buffer offsets of the two 16 x 32-tile kernels (their launchers refuse)
         return "f22"
     cus = _cus(device)
     t22 = -(-(n * (-(-H // 16)) * (-(-W // 16))) // cus) * _T_TILE_F22
-    t44 = -(-(n * (-(-H // 16)) * (-(-W // 32))) // cus) * _T_TILE_F44
-    return "f44" if t44 < t22 else "f22"
+    big = -(-(n * (-(-H // 16)) * (-(-W // 32))) // cus)
+    if policy == "fast32":
+        return "f44" if big * _T_TILE_F44 < t22 else "f22"
+    return "s16" if big * _T_TILE_S16 < t22 else "f22"
 
 
-def conv3x3_c64(x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
-    """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer with the Winograd kernel conv64_kernel_for(..., policy) names
-    (`weights` = pack_conv64_weights(w)).  out_blk=True (only honoured by the F(4x4,3x3) kernel - check with conv64_kernel_for)
-    leaves the result in the blk32 layout for the next 64->64 layer; a Blk32 input is consumed as such."""
-    if isinstance(x, Blk32) or conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device, policy) == "f44":
-        return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk)
+def conv3x3_c64(x, weights, bias=None, relu=True, out=None, policy="fast", chain=False):
+    """relu(conv3x3(x, w, pad=1) + bias) for a 64->64 layer on the kernel conv64_kernel_for(..., policy) names (`weights` =
+    pack_conv64_weights(w)).  x: fp32 channels_last (n,64,H,W), or the previous layer's output in its kernel's own layout (Sp16 /
+    Blk32: that kernel runs again).  chain=True leaves the result in the kernel's own layout for the next 64->64 layer (Sp16 for the
+    split-fp16 kernel, Blk32 for F(4x4,3x3); F(2x2,3x3) has none); chain=False returns fp32 channels_last."""
+    kind = ("s16" if isinstance(x, Sp16) else "f44" if isinstance(x, Blk32) else
+            conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device, policy))
+    if kind == "s16":
+        return conv3x3_c64_split16(x if isinstance(x, Sp16) else to_split16(x), weights.s16, bias, relu, out, out_f32=not chain)
+    if kind == "f44":
+        return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=chain)
     return conv3x3_c64_winograd(x, weights.f22, bias, relu, out)
 
 
@@ -564,7 +715,6 @@ class KernelTimer:
     destroyed by close(); launches beyond the capacity run untimed.  Read durations after synchronising the stream."""
 
     _plain_mix_gap = staticmethod(anderson_mix_gap)          # bound here: callers may monkey-patch the module names
-    _plain_winograd = staticmethod(conv3x3_c64_winograd)
 
     def __init__(self, capacity=0):
         self.events = []
@@ -599,34 +749,9 @@ class KernelTimer:
                 _p(x_out, "x_out"), _p(z1, "z1"), bsz, H, W, B, layout, _phi_shared(phi, bsz), _stream(), ev[0], ev[1]),
                 "anderson_mix_gap_timed")
 
-    def winograd(self, x, u_packed, bias=None, relu=True, out=None):
-        ev = self._pair()
-        if ev is None:
-            return self._plain_winograd(x, u_packed, bias, relu, out)
-        n, c, H, W = x.shape
-        _check_packed(u_packed, 16, "pack_winograd_weights")
-        o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-        with _dev(x):
-            _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(u_packed, "u_packed"), _p(bias, "bias", True),
-                                                                o.data_ptr(), n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]),
-                   "conv3x3_c64_winograd_timed")
-        return o
-
-    def conv64(self, x, weights, bias=None, relu=True, out=None, out_blk=False, policy="fast"):
-        """The timed counterpart of conv3x3_c64; returns (output, 'f22' | 'f44')."""
-        blk = isinstance(x, Blk32)
-        kind = "f44" if blk else conv64_kernel_for(x.shape[0], x.shape[2], x.shape[3], x.device, policy)
-        ev = self._pair()
-        if ev is None:
-            return conv3x3_c64(x, weights, bias, relu, out, out_blk=out_blk, policy=policy), kind
-        if kind == "f44":
-            return conv3x3_c64_winograd44(x, weights.f44, bias, relu, out, out_blk=out_blk, events=ev), kind
-        n, c, H, W = x.shape
-        o = out if out is not None else torch.empty_like(x, memory_format=torch.channels_last)
-        with _dev(x):
-            _check(load().deqsci_conv3x3_c64_winograd_timed_f32(x.data_ptr(), _p(weights.f22, "u_packed"), _p(bias, "bias", True), o.data_ptr(),
-                                                                n, H, W, 1 if relu else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_timed")
-        return o, kind
+    def pair(self):
+        """The next unused (start, stop) pair, or None when the capacity is used up (for CONV64_EVENT_HOOK)."""
+        return self._pair()
 
     def durations_ms(self):
         out = []

@@ -1,0 +1,371 @@
+// 3x3 convolution 64 -> 64 channels (pad 1, stride 1) as a DIRECT convolution on the f16 matrix cores of MI355X with fp32-class
+// accuracy: every fp32 operand is split into two fp16 pieces, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits),
+// and the product is formed from three f16 MFMAs with fp32 accumulation
+//        w x  ~=  w_hi x_hi + w_lo x_hi + w_hi x_lo            (the dropped w_lo x_lo term is 2^-22 relative)
+// The f16 matrix pipe is 16x faster than the f32 one (v_mfma_f32_32x32x16_f16: 32768 flops per 32 cycles against 2048 for
+// v_mfma_f32_16x16x4_f32), so three f16 products of a direct convolution (3 x 9 taps) cost 0.42 of the f32 MFMA time of Winograd
+// F(4x4,3x3) (2.25 taps-equivalent) - and there is NO transform: no input transform (13 % of the F(4x4,3x3) kernel), no output
+// transform, no exchange, none of the cancellation that makes Winograd forms noisy on rough inputs.  Measured rounding against a
+// float64 convolution on FFDNet's own data: see tools/conv_error_real.py (on par with the fp32 forms, below MIOpen's direct fp32
+// convolution), tools/ubench/mfma_f16_numerics.hip for what the f16 MFMA does with its 16 products (fp16 subnormals kept, one
+// rounding per instruction).
+//
+// Scaling: fp16 has 5 exponent bits.  Activations are stored multiplied by 2^8 (|v| < 255: FFDNet's stay below 10; an overflow shows
+// as inf/NaN in the output, never silently) and each layer's weights by a power of two chosen at pack time so that max |w| lands in
+// [2^13, 2^14); the lo pieces then stay normal fp16 numbers for every value that matters.  The epilogue multiplies the fp32
+// accumulator by the exact inverse power of two.
+//
+// Activation layout between layers ("sp16"): [n][cin chunk c (4)][piece hl (2: hi, lo)][k block kb (2)][H][W][8 halfs] - 16 planes
+// of 16-byte pixels (256 bytes per pixel in all, as fp32 NHWC).  A pixel's 16 bytes in plane (c, hl, kb) are exactly one lane's
+// B operand of v_mfma_f32_32x32x16_f16 (channels 16 c + 8 kb .. + 8), a staged tile row is 544 contiguous bytes per plane, and a
+// tap (dy, dx) is a constant offset into the staged plane: conflict-free ds_read_b128 for every tap, no per-tap address arithmetic.
+//
+// Block tile = 16 x 32 output pixels x 64 couts, one persistent 8-wave workgroup per CU (as csrc/winograd44.hip); wave w owns pixel
+// rows 2 w, 2 w + 1 (two N tiles of 32 pixels) x both cout groups of 32 (two M tiles): four accumulators of 16 registers.  Input
+// channels in chunks of 16 (= K of one MFMA): per chunk the 18 x 34 pixel halo tile (4 planes, 39 KB) and the chunk's weights
+// (9 taps x 2 pieces x 2 cout groups x 1 KB = 36 KB, host-packed in LDS order) are double-buffered and fetched by the LDS-DMA path
+// one stage ahead; out-of-image pixels are zeros the buffer hardware writes for out-of-range lanes.  One barrier per stage.
+#include "common.hpp"
+#include <hip/hip_ext.h>
+#include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"
+
+#ifndef S16_ABL
+#define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
+                      // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
+#endif
+
+namespace deqsci {
+namespace s16 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) h8 lds_h8;
+
+constexpr int WAVES = 8, TBW = 64 * WAVES, NCHUNK = 4;
+constexpr int OUT_ROWS = 16, OUT_COLS = 32, RAW_ROWS = 18, RAW_COLS = 34, RAW_PIX = RAW_ROWS * RAW_COLS;     // 612
+constexpr int PLANE_B = RAW_PIX * 16;                          // 9792 bytes of one staged plane
+constexpr int RAW_SLOTS = 4 * RAW_PIX;                         // 2448 units of 16 bytes per chunk tile
+constexpr int RAW_INSTR = 5;                                   // LDS-DMA instructions of 64 units per wave and chunk (40 in all, 2560 slots)
+constexpr int RAW_BUF = WAVES * RAW_INSTR * 1024;              // 40960 bytes
+constexpr int W_CHUNK = 9 * 2 * 2 * 1024;                      // 36864 bytes: [tap][hl][cout group][lane][8 halfs]
+constexpr uint32_t RAW_BIAS = 4096;                            // the descriptor starts this far below the image (see set_fetch_tile)
+constexpr uint32_t RAW_OOB = 0x80000000u;                      // beyond num_records: the hardware writes zeros
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
+
+// OUT_F32 = 0: sp16 output (the next 64->64 layer's input); 1: fp32 channels_last (n, H, W, 64) output (the consumer is not this kernel)
+template <int OUT_F32>
+__global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
+                                                          char* __restrict__ y, int H, int W, int relu, float oscale, int tiles_x, int tiles_y,
+                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+    __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
+    __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
+    int t_first, t_step, t_end;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((nb & 7) == 0) {                                   // block b runs on XCD b % 8: give every XCD a contiguous range of tiles
+            const int per_xcd = (n_tiles + 7) >> 3;
+            t_first = (b & 7) * per_xcd + (b >> 3);
+            t_step = nb >> 3;
+            t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
+        } else { t_first = b; t_step = nb; t_end = n_tiles; }
+    }
+    if (t_first >= t_end) return;
+    const int64_t HW = (int64_t)H * W;
+
+    // ---- halo tile by LDS-DMA: slot s = 64 (5 wave + j) + lane of the chunk tile is plane p = s / 612 (p = 2 hl + kb), pixel
+    // (row, col) = ((s % 612) / 34, (s % 612) % 34): lane-linear in LDS, a per-lane byte offset on the global side.
+    i32x4 rsrc;
+    uint32_t vo[RAW_INSTR];
+    auto set_fetch_tile = [&](int t) {
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        // the descriptor starts RAW_BIAS bytes BELOW the image: four of a wave's instructions differ only in their immediate offset, which
+        // the hardware adds to the LDS AND the global address; the per-lane offsets take it back out
+        const uint64_t base = (uint64_t)(x + (int64_t)n * HW * 256) - RAW_BIAS;
+        rsrc.x = (int)uniform((uint32_t)base);
+        rsrc.y = (int)uniform((uint32_t)(base >> 32));
+        rsrc.z = (int)uniform((uint32_t)(HW * 256) + RAW_BIAS);
+        rsrc.w = 0x00020000;
+        const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;
+#pragma unroll
+        for (int j = 0; j < RAW_INSTR; ++j) {
+            const int s = 64 * (RAW_INSTR * wave + j) + lane;
+            const int p = (s * 857) >> 19;                     // s / 612 for s < 2560
+            const int q = s - p * RAW_PIX;
+            const int row = (q * 1928) >> 16, col = q - row * RAW_COLS;      // q / 34 for q < 768
+            const int iy = py0 + row, ix = px0 + col;
+            const bool ok = s < RAW_SLOTS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            vo[j] = ok ? (uint32_t)(p * (int)HW + iy * W + ix) * 16u + (RAW_BIAS - 1024u * (j & 3)) : RAW_OOB;
+        }
+    };
+    const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
+    auto raw_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
+        int w_ = wave;
+        asm volatile("" : "+s"(w_));                           // (recomputed at every use: hoisted out of the tile loop, these scalars fill the SGPR file)
+        const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
+        const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + RAW_INSTR * w_ * 1024 + (j == 4 ? 4096 : 0)));
+        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+    };
+    // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves pieces [9 w / 2, ...): 5 for even waves, 4 for odd
+    auto w_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
+        int w_ = wave;
+        asm volatile("" : "+s"(w_));
+        const int first = (9 * w_) >> 1, count = ((9 * (w_ + 1)) >> 1) - first;
+        if (j >= count) return;
+        const uint32_t off = (uint32_t)((first + j) * 1024);
+        const uint64_t g = (uint64_t)(Wp + (int64_t)c * W_CHUNK) + off;
+        const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_CHUNK) + off);
+        const uint64_t gs = ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
+        const uint32_t lv = (uint32_t)lane * 16u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lv), "s"(gs) : "m0");
+    };
+
+    f32x16 acc[1][2][2];                                       // [set (one)][cout group g][pixel row r]
+    struct Done { i32x4 orsrc; uint32_t pix[2]; };             // where the finished tile goes: descriptor of its image, per-lane offsets of rows r
+    const int pl = lane & 31, kb = lane >> 5;
+    const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (2 * wave * RAW_COLS + pl) * 16;
+    const lds_char* abase = (const lds_char*)Wt + lane * 16;
+
+    // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of the next one) is
+    // fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
+    // ---- epilogue of one (r, g, gp) piece of accumulator set S: acc[S][g][r][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of pixel (2 wave + r, pl)
+    auto ep_piece = [&](auto set_c, const Done& d, int k) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1;
+        float v[8];                                            // [gq = 2 gp, 2 gp + 1][k]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = 4 * (2 * gp + (e >> 2)) + (e & 3);
+            const float val = fmaf(acc[S][g][r][i], oscale, bias_s[32 * g + 8 * (2 * gp + (e >> 2)) + 4 * kb + (e & 3)]);
+            v[e] = relu ? fmaxf(val, 0.0f) : val;
+        }
+        if (OUT_F32) {
+            // fp32 channels_last: the lane's four consecutive couts of each group are 16 contiguous bytes (pix = byte offset of the pixel)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
+            }
+        } else {
+            // sp16: split, pack, and trade halves with the lane 32 away so that each lane holds one whole 16-byte pixel of
+            // plane (chunk 2 g + gp, hl, kb) - even couts-of-8 block for lanes < 32, odd block for lanes >= 32
+            unsigned hi[4], lo[4];                             // [block parity (gq & 1)][k pair]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = v[2 * e], b = v[2 * e + 1];
+                const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+                const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
+                hi[e] = __builtin_bit_cast(unsigned, (h2){ha, hb});
+                lo[e] = __builtin_bit_cast(unsigned, (h2){la, lb});
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                      // (E, O) = (block 0, block 1) registers e: swap E[32..63] with O[0..31]
+                auto sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
+                hi[e] = sh[0]; hi[2 + e] = sh[1];
+                auto sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
+                lo[e] = sl[0]; lo[2 + e] = sl[1];
+            }
+            // now lanes < 32 hold couts [0, 8) of block 0 as (hi[0], hi[1], hi[2], hi[3]) = (own 0..3, partner's 4..7); lanes >= 32
+            // hold block 1 of pixel lane - 32 likewise: plane kb of the lane (inside pix), pixel pl
+            const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
+            const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
+            const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(oh), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_h) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_l) : "memory");
+        }
+    };
+    auto tile_done = [&](int t) -> Done {
+        Done d;
+        const int n = mdiv(t, mg_img, sh_img), rr_ = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(rr_, mg_tx, sh_tx), bx = rr_ - by * tiles_x;
+        const int ox = OUT_COLS * bx + pl;
+        const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
+        d.orsrc.x = (int)uniform((uint32_t)ob);
+        d.orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+        d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
+        d.orsrc.w = 0x00020000;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int oy = OUT_ROWS * by + 2 * wave + r;
+            const bool ok = oy < H && ox < W;
+            d.pix[r] = !ok ? RAW_OOB : OUT_F32 ? (uint32_t)((oy * W + ox) * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + oy * W + ox) * 16);
+        }
+        return d;
+    };
+
+    // One stage = chunk c of the current tile (accumulator set S): Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
+    // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.  `flush`: the previous
+    // tile's epilogue (the other accumulator set) rides along, one piece behind every other group.
+    auto stage = [&](auto set_c, int c, bool more, bool flush, const Done& prev) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int buf = c & 1, nb = buf ^ 1, cn = (c + 1) & 3;
+        const lds_char* bb = bbase + buf * RAW_BUF;
+        const lds_char* ab = abase + buf * W_CHUNK;
+        // 18 groups (dx, dy, g) of 6 MFMAs: the two pixel rows x three products of one tap and cout group.  Operands are read from LDS
+        // TWO groups ahead (software pipeline pinned by sched_barriers: left to itself hipcc reads each fragment one MFMA before its use
+        // and waits for it): per group two weight fragments (hi, lo) and, when a new halo row comes into play, its hi and lo fragments
+        // (rows 0, 1 at dy = 0, row 2 at dy = 1, row 3 at dy = 2 of every dx; kept per dx parity).
+        h8 Ah[3], Al[3], Bh[2][4], Bl[2][4];
+        auto loads = [&](int i) __attribute__((always_inline)) {
+            if (i >= 18 || ((S16_ABL & 8) && i >= 2)) return;
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1, tap = dy * 3 + dx;
+            Ah[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 0) * 2 + g) * 1024);
+            Al[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 1) * 2 + g) * 1024);
+            if (g == 0) {
+#pragma unroll
+                for (int rr = (dy == 0 ? 0 : dy + 1); rr <= dy + 1; ++rr) {
+                    Bh[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + (rr * RAW_COLS + dx) * 16);
+                    Bl[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + 2 * PLANE_B + (rr * RAW_COLS + dx) * 16);
+                }
+            }
+        };
+        loads(0);
+        loads(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1;
+            loads(i + 2);
+            if (more && i < 2 * RAW_INSTR && !(S16_ABL & 1)) {   // the next chunk: 10 DMA instructions, one per group in the FIRST half of the
+                                                               // stage - the last one needs the second half (an HBM round trip) to land
+                if (i < RAW_INSTR) raw_piece(cn, nb, i); else w_piece(cn, nb, i - RAW_INSTR);
+            }
+            if (c == 0 && (i & 1) && i < 16 && (!(S16_ABL & 4) || relu == 77)) {
+                if (flush) ep_piece(set_c, prev, i >> 1);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
+                acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!(S16_ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_barrier();
+        }
+    };
+
+    // ---- prologue: bias, chunk 0 of the first tile
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] : 0.0f;
+    set_fetch_tile(t_first);
+#pragma unroll
+    for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (Spreading a tile's epilogue over the MFMA stream of the next tile - a second accumulator set, one piece behind every other group -
+    // was built and measured: 192 us against 187 us at 64 x 128 x 128.  On random data this kernel runs against the chip's POWER limit
+    // (1.87-1.97 GHz instead of 2.4; all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles.)
+    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}};
+    constexpr std::integral_constant<int, 0> S0{};
+#pragma unroll 1
+    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = 0.0f;
+        stage(S0, 0, true, false, none);
+        stage(S0, 1, true, false, none);
+        stage(S0, 2, true, false, none);
+        const bool next = t_cur + t_step < t_end;
+        if (next) set_fetch_tile(t_cur + t_step);             // (the fetches of chunks 1..3 of this tile have been issued)
+        stage(S0, 3, next, false, none);
+        if (!(S16_ABL & 4) || relu == 77) {
+            const Done d = tile_done(t_cur);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ep_piece(S0, d, k);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// fp32 channels_last (n, H, W, 64) -> sp16, activations scaled by `scale` (the engine's 2^8): one lane per (pixel, 8-channel block)
+__global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restrict__ x, char* __restrict__ y, int64_t HW, int64_t total, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over n * HW * 8
+    if (i >= total) return;
+    const int blk = (int)(i & 7);
+    const int64_t pix = i >> 3, n = pix / HW, p = pix - n * HW;
+    const float4 a = ld4s(x + pix * 64 + blk * 8), b = ld4s(x + pix * 64 + blk * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = v[k] * scale;
+        hi[k] = (_Float16)t;
+        lo[k] = (_Float16)(t - (float)hi[k]);
+    }
+    const int c = blk >> 1, kb = blk & 1;
+    char* base = y + n * HW * 256;
+    *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 0 + kb) * HW + p) * 16) = hi;
+    *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 2 + kb) * HW + p) * 16) = lo;
+}
+
+}  // namespace s16
+}  // namespace deqsci
+
+using namespace deqsci;
+
+static void s16_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = 31 + s;
+    *mg = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+}
+
+extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y, int64_t n, int64_t H, int64_t W,
+                                          int relu, float out_scale, int out_f32, deqsci_stream_t stream, void* start_event, void* stop_event) {
+    if (!x_sp16 || !w_packed || !y) return DEQSCI_ERR_NULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (x_sp16 == y || (out_f32 != 0 && out_f32 != 1)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    // 32-bit byte offsets inside one image, and the out-of-range sentinel 2^31 must lie beyond the descriptor's range
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t resident = (int64_t)num_cus();
+    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
+    hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
+#define S16_LAUNCH(KERNEL)                                                                                                                  \
+    hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
+                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, \
+                          mg_tx, sh_tx)
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1>)); else S16_LAUNCH((s16::conv_s16_kernel<0>));
+#undef S16_LAUNCH
+    return launch_status();
+}
+
+extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream) {
+    if (!x_nhwc || !y_sp16) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (!aligned16(x_nhwc) || !aligned16(y_sp16)) return DEQSCI_ERR_ALIGN;
+    const int64_t total = n * H * W * 8;
+    hipLaunchKernelGGL(s16::f32_to_sp16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_nhwc,
+                       static_cast<char*>(y_sp16), H * W, total, scale);
+    return launch_status();
+}

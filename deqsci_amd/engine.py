@@ -68,8 +68,8 @@ class _Denoiser:
         self.net = net
         self.fused_edges = fused_edges
         self.winograd = winograd
-        self.conv64 = conv64                                        # _hip.conv64_kernel_for policy: "fast" | "f22" | "f44"
-        self.f22_calls = None                                       # with policy "fast": f-calls [0, f22_calls) still run F(2x2,3x3) (DEQSCIEngine)
+        self.conv64 = conv64                                        # _hip.conv64_kernel_for policy: "fast" | "fast32" | "f22" | "f44" | "s16"
+        self.f22_calls = None                                       # f-calls [0, f22_calls) run F(2x2,3x3) whatever the policy (DEQSCIEngine)
         self._policy = conv64
         self.blk32 = os.environ.get("DEQSCI_BLK32", "1") != "0"     # (A/B knob) blk32 activations between F(4x4,3x3) layers
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
@@ -134,6 +134,7 @@ class _Denoiser:
             self.wino = [(_hip.pack_conv64_weights(w) if (self.winograd and self.channels_last and w.is_cuda
                                                              and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
+
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
             if (not isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[0][0].is_cuda):
@@ -171,12 +172,22 @@ class _Denoiser:
     def _run_layers(self, h, idx, fused):
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
-            if self.wino[i] is not None and (isinstance(h, _hip.Blk32) or (h.is_cuda and h.is_contiguous(memory_format=torch.channels_last))):
-                # between two 64->64 layers that run on the F(4x4,3x3) kernel the activation stays in that kernel's own layout
-                f44 = isinstance(h, _hip.Blk32) or _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device, self._policy) == "f44"
-                nxt = idx[pos + 1] if pos + 1 < len(idx) else None
-                h = _hip.conv3x3_c64(h, self.wino[i], b, relu, out_blk=bool(f44 and self.blk32 and nxt is not None and self.wino[nxt] is not None),
-                                     policy=self._policy)
+            nxt = idx[pos + 1] if pos + 1 < len(idx) else None
+            chain = nxt is not None and self.wino[nxt] is not None          # the next layer is a 64->64 layer too: keep the kernel's own layout
+            native = isinstance(h, (_hip.Sp16, _hip.Blk32))
+            if self.wino[i] is not None and (native or (h.is_cuda and h.is_contiguous(memory_format=torch.channels_last))):
+                # 64->64 layer on one of the three HIP kernels; between two such layers the activation stays in the kernel's own layout
+                # (sp16 for the split-fp16 direct convolution, blk32 for F(4x4,3x3)); the layer's kind is fixed by the FIRST layer of a run
+                kind = ("s16" if isinstance(h, _hip.Sp16) else "f44" if isinstance(h, _hip.Blk32) else
+                        _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device, self._policy))
+                if kind == "s16":
+                    if not isinstance(h, _hip.Sp16):
+                        h = _hip.to_split16(h)
+                    h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not chain)
+                elif kind == "f44":
+                    h = _hip.conv3x3_c64_winograd44(h, self.wino[i].f44, b, relu, out_blk=bool(self.blk32 and chain))
+                else:
+                    h = _hip.conv3x3_c64_winograd(h, self.wino[i].f22, b, relu)
             elif fused and b is not None:
                 # Conv-BN-ReLU = MIOpen conv with folded weights + ONE in-place bias+ReLU pass (HIP)
                 h = _hip.bias_relu_(F.conv2d(h, w, None, padding=1), b, relu)
@@ -242,26 +253,25 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=40):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
-        if conv64 not in ("auto", "fast", "f22", "f44"):
-            raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'f22' or 'f44'")
-        # Which Winograd form runs the 64->64 layers.  "fast": the faster kernel per launch (F(4x4,3x3) from about one block tile per
-        # CU on); "f22" / "f44": that form always.  "auto" (default) = "fast", EXCEPT in the one regime where the choice is visible in
-        # the result: FFDNet under Anderson beyond ~30 iterations is chaotic, and there the rounding noise of the denoiser
-        # on the EARLY iterates - blocky Phi^T y-like inputs, on which F(4x4,3x3) is 3x noisier than F(2x2,3x3); on settled iterates
-        # the two are on par (tools/fcall_error_along_loop.py, tools/conv_error_real.py) - moves the ensemble mean of the
-        # reconstructions.  Six traffic measurements x 25 starts (tools/config2_ensemble.py, profiles/r03_config2_ensembles.json):
-        # reference 21.434 +- 0.008 dB; F(2x2,3x3) throughout 21.420 +- 0.004; F(2x2,3x3) for the first 40 / 20 / 10 f-calls, then
-        # "fast": 21.417 / 21.414 / 21.404; "fast" throughout 21.395; MIOpen's direct fp32 convolution 21.410.  So "auto" runs the first
-        # `conv64_f22_calls` (40) f-calls of that regime on F(2x2,3x3) at every batch size and the rest on the faster kernel: the
-        # statistics of F(2x2,3x3) throughout, at 0.78 of its cost.  Well-conditioned configurations (SimpleCNN, Picard, <= 30
+        if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
+            raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'fast32', 'f22', 'f44' or 's16'")
+        # Which kernel runs the 64->64 layers (_hip.conv64_kernel_for): "fast" (= "auto") the faster of the split-fp16 direct convolution
+        # on the f16 matrix cores and Winograd F(2x2,3x3) on the f32 ones, per launch; "fast32" fp32 MFMA arithmetic only (F(4x4,3x3) /
+        # F(2x2,3x3)); "f22" / "f44" / "s16" one kernel always.  `conv64_f22_calls=K` additionally runs the first K f-calls on F(2x2,3x3).
+        # What the choice does to the result was measured where it can matter - FFDNet under Anderson beyond ~30 iterations is chaotic
+        #  - as 25-start ensembles over the six traffic measurements (tools/config2_ensemble.py,
+        # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.008 (as it is 21.446); F(2x2,3x3)
+        # 21.420; split-fp16 21.420; F(2x2,3x3) for 40 f-calls then F(4x4,3x3) 21.417; MIOpen's direct fp32 convolution 21.410;
+        # F(4x4,3x3) throughout 21.395.  Single measurements move by up to 0.09 dB under ANY change of arithmetic (the reference's own two
+        # Gram variants: RMS 0.06 dB), so only the pooled mean separates kernels; it puts split-fp16 and F(2x2,3x3) together, nearest
+        # the reference, which is why "auto" uses exactly those two.  Well-conditioned configurations (SimpleCNN, Picard, <= 30
         # iterations) agree to 1e-5 under every policy.
         self.conv64 = conv64
-        chaotic = getattr(denoiser, "tag", None) == "ffdnet" and iterator == "anderson" and int(max_iter) > 30
         self.conv64_policy = "fast" if conv64 == "auto" else conv64
-        self.conv64_f22_calls = int(conv64_f22_calls) if (conv64 == "auto" and chaotic) else None
+        self.conv64_f22_calls = None if conv64_f22_calls is None else int(conv64_f22_calls)
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
                              fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy)
         self.den.f22_calls = self.conv64_f22_calls

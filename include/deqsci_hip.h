@@ -184,6 +184,30 @@ int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_pack
                                              int64_t n, int64_t H, int64_t W, int relu, int in_layout, int out_layout,
                                              deqsci_stream_t stream, void* start_event, void* stop_event);
 
+/* ---- the same layer as a DIRECT convolution on the f16 matrix cores with fp32-class accuracy (csrc/conv_s16.hip): every operand
+ *     is two fp16 pieces (x = hi + lo, 22 significant bits), three f16 MFMAs per product (w_hi x_hi + w_lo x_hi + w_hi x_lo), fp32
+ *     accumulation.  x_sp16: the activation as [n][4 cin chunks][2 pieces: hi, lo][2 blocks of 8 channels][H][W][8 halfs] holding
+ *     2^8 x (deqsci_f32_to_split16 writes it from fp32 channels_last; the kernel itself writes it with out_f32 = 0).  w_packed:
+ *     2^sw w as [4 chunks][9 taps][2 pieces][2 cout groups of 32][64 lanes][8 halfs] (cout = 32 g + lane % 32, cin = 16 c +
+ *     8 (lane / 32) + j).  Output = relu?(acc * out_scale + bias): out_f32 = 0 -> sp16 of 2^8 y (pass out_scale = 2^-sw and
+ *     2^8 bias), out_f32 = 1 -> fp32 channels_last (n,H,W,64) (pass out_scale = 2^-(8+sw) and bias).  An activation beyond
+ *     fp16's range (|y| >= 255.9) becomes inf, never a silently wrong finite number.  Images up to 2^31 / 256 - 33 pixels.
+ *     start_event / stop_event: both NULL, or both raw hipEvent_t handles (measurement). */
+int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y,
+                               int64_t n, int64_t H, int64_t W, int relu, float out_scale, int out_f32,
+                               deqsci_stream_t stream, void* start_event, void* stop_event);
+int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream);
+/* The edge layers of the denoisers with the sp16 layout on their 64-channel side (same kernels, other stores / loads): the heads
+ *     write relu(conv) as sp16 (2^8 x as hi + lo), the tails read sp16 - no conversion pass on either side of a run of split16 layers. */
+int deqsci_ffdnet_head_sp16(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
+                            int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
+int deqsci_ffdnet_tail_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                            deqsci_stream_t stream);
+int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W, int relu,
+                                 deqsci_stream_t stream);
+int deqsci_conv3x3_c64_to_1_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                                 deqsci_stream_t stream);
+
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
  * without the marker-packet overhead of events recorded around a launch. */

@@ -579,7 +579,7 @@ def test_winograd44_conv64_vs_torch(shape):
     want2 = torch.relu(ref + b.double().view(1, -1, 1, 1))
     assert float((got2.double() - want2).norm() / want2.norm()) < 2.5e-6
     # repeated launches on one stream (the persistent pipeline leaves nothing behind) and the selecting front end
-    got3 = _hip.conv3x3_c64(x, _hip.pack_conv64_weights(w), b, relu=True)
+    got3 = _hip.conv3x3_c64(x, _hip.pack_conv64_weights(w), b, relu=True, policy="fast32")
     assert float((got3.double() - want2).norm() / want2.norm()) < 2.5e-6
     with pytest.raises(_hip.DeqsciHipError):                                   # the other kernel's pack would be read out of bounds
         _hip.conv3x3_c64_winograd44(x, _hip.pack_winograd_weights(w), b, relu=True)
@@ -628,12 +628,88 @@ def test_winograd44_blk32_layouts_vs_torch(shape):
 
 
 def test_conv64_front_end_picks_the_faster_kernel():
-    """More than one wave of F(2x2,3x3) block tiles -> F(4x4,3x3) (measured: profiles/r02_w44_shapes.jsonl)."""
+    """One block tile per CU and more -> the 16 x 32-tile kernel (split-fp16 under "fast", F(4x4,3x3) under "fast32"); below ->
+    F(2x2,3x3) (measured: profiles/r02_w44_shapes.jsonl, profiles/r03_s16_time.jsonl); and the front end runs what it names."""
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     assert cus == 256
-    assert _hip.conv64_kernel_for(8, 128, 128) == "f44" and _hip.conv64_kernel_for(64, 128, 128) == "f44"
+    assert _hip.conv64_kernel_for(8, 128, 128) == "s16" and _hip.conv64_kernel_for(64, 128, 128) == "s16"
     assert _hip.conv64_kernel_for(1, 128, 128) == "f22" and _hip.conv64_kernel_for(4, 128, 128) == "f22"
-    assert _hip.conv64_kernel_for(2, 256, 256) == "f44" and _hip.conv64_kernel_for(1, 256, 256) == "f22"
+    assert _hip.conv64_kernel_for(2, 256, 256) == "s16" and _hip.conv64_kernel_for(1, 256, 256) == "f22"
+    assert _hip.conv64_kernel_for(8, 128, 128, policy="fast32") == "f44" and _hip.conv64_kernel_for(4, 128, 128, policy="fast32") == "f22"
+    import torch.nn.functional as Fn
+    g = torch.Generator(device=DEV).manual_seed(21)
+    x = torch.randn(8, 64, 128, 128, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05
+    b = torch.randn(64, device=DEV, generator=g)
+    Wts = _hip.pack_conv64_weights(w)
+    want = torch.relu(Fn.conv2d(x.double(), w.double(), b.double(), padding=1))
+    seen = []
+    _hip.CONV64_EVENT_HOOK = lambda kind, n, H, W: seen.append(kind)           # returns None: untimed launches, but the kind is reported
+    try:
+        for pol, kind, tol in (("fast", "s16", 4e-7), ("fast32", "f44", 2.5e-6), ("f22", "f22", 4e-7)):
+            got = _hip.conv3x3_c64(x, Wts, b, True, policy=pol)
+            assert seen[-1] == kind and got.is_contiguous(memory_format=torch.channels_last)
+            assert float((got.double() - want).norm() / want.norm()) < tol, pol
+        mid = _hip.conv3x3_c64(x, Wts, b, True, policy="fast", chain=True)       # the kernel's own layout between layers ...
+        assert isinstance(mid, _hip.Sp16) and isinstance(_hip.conv3x3_c64(x, Wts, b, True, policy="fast32", chain=True), _hip.Blk32)
+        out2 = _hip.conv3x3_c64(mid, Wts, b, True, policy="f22")                  # ... which pins the next layer's kernel
+        assert seen[-1] == "s16" and out2.shape == x.shape
+    finally:
+        _hip.CONV64_EVENT_HOOK = None
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 32), (8, 128, 128), (3, 40, 56), (1, 18, 14), (2, 17, 23), (1, 1, 1), (70, 64, 80), (33, 50, 46),
+                                   (300, 16, 16), (2, 250, 130)])
+def test_split16_conv64_vs_torch(shape):
+    """Split-fp16 direct convolution 64->64 (+bias+ReLU) on the f16 matrix cores vs conv2d in fp64: random asymmetric weights, block tiles
+    that stick out of the image on every side (16 x 32 outputs), single tiles and runs of many per workgroup, both output forms
+    (sp16 for the next layer / fp32 channels_last), a three-layer chain, repeated launches.  Bound on random data: 4e-7 (measured
+    1.9-2.3e-7; MIOpen's direct fp32 convolution on the same data: 1.6-3.6e-7; F(2x2,3x3) 2e-7; F(4x4,3x3) 1.2-1.7e-6).
+    The sp16 round trip itself (fp32 -> hi + lo -> fp32) is exact to 2^-22."""
+    import torch.nn.functional as Fn
+    n, H, W = shape
+    g = torch.Generator(device=DEV).manual_seed(12)
+    x = torch.randn(n, 64, H, W, device=DEV, generator=g).contiguous(memory_format=torch.channels_last)
+    ws = [torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05 for _ in range(3)]
+    bs = [torch.randn(64, device=DEV, generator=g) * 0.3 for _ in range(3)]
+    Ws = [_hip.Split16Weights(w) for w in ws]
+
+    def err(a, b):
+        return float((a.double() - b).norm() / b.norm())
+    xs = _hip.to_split16(x)
+    assert err(xs.to_nchw(), x.double()) < 2.0 ** -22
+    ref = Fn.conv2d(x.double(), ws[0].double(), padding=1)
+    got = _hip.conv3x3_c64_split16(xs, Ws[0], None, relu=False, out_f32=True)
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape and err(got, ref) < 4e-7
+    want = torch.relu(ref + bs[0].double().view(1, -1, 1, 1))
+    o_sp = _hip.Sp16.empty(n, H, W, DEV)
+    o_sp.t.fill_(float("nan"))
+    got_sp = _hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out=o_sp)
+    assert got_sp is o_sp and bool(torch.isfinite(o_sp.t).all()) and err(o_sp.to_nchw(), want) < 4e-7
+    got_f = _hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out_f32=True)
+    assert err(got_f, want) < 4e-7
+    assert torch.equal(_hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out_f32=True), got_f)      # repeated launches: nothing left behind
+    h, wd = xs, x.double()
+    for i in range(3):                                                       # sp16 -> sp16 -> fp32, as the engine chains a denoiser
+        h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, out_f32=(i == 2))
+        wd = torch.relu(Fn.conv2d(wd, ws[i].double(), bs[i].double(), padding=1))
+    assert err(h, wd) < 8e-7
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.conv3x3_c64_split16(x, Ws[0], bs[0], True)                       # an fp32 tensor is not an Sp16
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.conv3x3_c64_split16(xs, _hip.pack_winograd_weights(ws[0]), bs[0], True)
+
+
+def test_split16_overflow_is_loud():
+    """Activations beyond fp16's range (2^8 |y| >= 65504) must surface as inf / NaN, never as a wrong finite number."""
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand(1, 64, 16, 32, device=DEV, generator=g).contiguous(memory_format=torch.channels_last) * 40.0
+    w = torch.ones(64, 64, 3, 3, device=DEV) * 0.5                          # y ~ 64 * 9 * 20 * 0.5 = 5760 >> 255
+    out = _hip.conv3x3_c64_split16(_hip.to_split16(x), _hip.Split16Weights(w), None, True)
+    assert not bool(torch.isfinite(out.t).all())
+    ok = _hip.conv3x3_c64_split16(_hip.to_split16(x), _hip.Split16Weights(w), None, True, out_f32=True)   # the fp32 output form has no such limit
+    want = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
+    assert float((ok.double() - want).norm() / want.norm()) < 4e-7
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 24), (1, 256, 256), (3, 33, 70)])
@@ -850,7 +926,7 @@ def _se(v):
 
 def test_config2_ffdnet_anderson_180_all_measurements():
     """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement, on the
-    DEFAULT engine (conv64="auto": F(2x2,3x3) for the first 40 f-calls of this regime, then the faster kernel).
+    DEFAULT engine (conv64="auto": the split-fp16 direct convolution at this size).
     The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0),
     so one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and
     x0 (1 + 1e-7 randn), seeds 1.. - on both sides:
@@ -870,13 +946,15 @@ def test_config2_ffdnet_anderson_180_all_measurements():
         convolution sits at +0.01 / -0.09 dB on m0 and -0.09 / +0.00 dB on m2 (profiles/r03_config2_ensembles.json); the six-measurement
         mean above averages that out and is the statistic with power.)  Median PSNR / residual inside the hull of both reference
         ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than one hull width outside;
-      * well-conditioned measurements (drop8, runner8: bands of 2 and 25 mdB): every run inside the widened band;
+      * well-conditioned measurements (drop8, runner8: reference bands of 2 and 25 mdB): ensemble mean within 0.01 dB (+ 3 SE) of the
+        reference's, every one of the 25 runs within one reference hull width of the reference's 9-10 run hull;
       * the harness average of the unperturbed run inside the hull of the two reference average bands."""
     from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements
     a, b = _config2_reference()
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
     eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
-    assert eng.conv64 == "auto" and eng.conv64_f22_calls == 40 and eng.conv64_policy == "fast"
+    assert eng.conv64 == "auto" and eng.conv64_f22_calls is None and eng.conv64_policy == "fast"
+    assert _hip.conv64_kernel_for(8, 128, 128, policy=eng.conv64_policy) == "s16"      # one measurement per call = 8 images of 128 x 128
     report, base_by_clip = [], {}
     for clip in (as_clip(c) for c in SCITestDataset(orc.DATA_DIR)):
         Phi = clip["mask"].to(DEV)[None].contiguous()
@@ -904,15 +982,18 @@ def test_config2_ffdnet_anderson_180_all_measurements():
         se = float(np.hypot(_se(ps), _se(rb)))
         print("%-22s build mean %.4f +- %.4f median %.4f [%.4f, %.4f] | reference exact-Gram mean %.4f +- %.4f, fp32 mean %.4f, widened hull [%.4f, %.4f]"
               % (mid, np.mean(ps), _se(ps), np.median(ps), min(ps), max(ps), np.mean(rb), _se(rb), np.mean(ra), lo, hi))
-        if max(ra + rb) - min(ra + rb) < 0.05:                               # well-conditioned: every run inside the widened band
-            assert all(lo <= p <= hi for p in ps), (mid, ps, lo, hi)
-            assert all(rlo * 0.99 <= r <= rhi * 1.01 for r in rs), (mid, rs, rlo, rhi)
+        w = max(ra + rb) - min(ra + rb)
+        if w < 0.05:
+            # well-conditioned (drop8: reference band 2 mdB, runner8: 25 mdB): the ensemble mean to the north_star tolerance of 0.01 dB
+            # (+ 3 SE), every one of the 25 runs within one reference hull width of the (9-10 run) reference hull, residuals likewise
+            assert abs(np.mean(ps) - np.mean(rb)) <= 0.01 + 3 * se, (mid, np.mean(ps), np.mean(rb), se)
+            assert min(ra + rb) - w - 0.01 <= min(ps) and max(ps) <= max(ra + rb) + w + 0.01, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
+            assert all(rlo * 0.97 <= r <= rhi * 1.03 for r in rs), (mid, rs, rlo, rhi)
             continue
         chaotic.append((ps, ra, rb))
         assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se + abs(np.mean(ra) - np.mean(rb)), (mid, np.mean(ps), np.mean(rb), se, np.mean(ra))
         assert lo <= np.median(ps) <= hi, (mid, np.median(ps), lo, hi)
         assert rlo * 0.99 <= np.median(rs) <= rhi * 1.01, (mid, np.median(rs), rlo, rhi)
-        w = max(ra + rb) - min(ra + rb)
         assert min(ra + rb) - w <= min(ps) and max(ps) <= max(ra + rb) + w, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
     assert len(chaotic) == 6
     pooled = lambda k: float(np.mean([np.mean(c[k]) for c in chaotic]))       # mean of the per-measurement ensemble means
@@ -935,7 +1016,9 @@ def test_conv64_rounding_on_the_networks_own_data():
     data - folded net_gray weights, the activations of a noisy first iterate (x0) and of a settled one (30 Anderson iterations).
     Random data mislead here: on randn inputs F(4x4,3x3) is 6-8x noisier than a direct convolution, on a settled iterate it is on
     par with F(2x2,3x3).  Bounds = measured (profiles/r03_conv_error_real.json) + margin: F(2x2,3x3) <= 3e-7 everywhere (<= the
-    direct fp32 convolution's, MIOpen: 2.4-3.5e-7); F(4x4,3x3) <= 1.2e-6 on x0, <= 3.5e-7 on the settled iterate."""
+    direct fp32 convolution's, MIOpen: 2.4-3.7e-7); F(4x4,3x3) <= 1.2e-6 on x0, <= 3.5e-7 on the settled iterate; the split-fp16
+    direct convolution (fp32 operands as hi + lo fp16 pairs on the f16 matrix cores) <= 3.2e-7 everywhere (measured 2.4-2.6e-7) and
+    in every single layer no noisier than MIOpen's fp32 direct convolution of the same operands - the bar VERDICT r2 #8 set for it."""
     import torch.nn.functional as Fn
     from deqsci_amd.engine import SIGMA0
     d = _clip("traffic_cacti.mat")
@@ -948,7 +1031,7 @@ def test_conv64_rounding_on_the_networks_own_data():
     for name, z in inputs.items():
         x = z.permute(0, 3, 1, 2).reshape(8, 1, 256, 256).contiguous()
         h = _hip.ffdnet_head(x, den.head_w, torch.full((1,), SIGMA0, device=DEV))
-        worst = {"f22": 0.0, "f44": 0.0, "direct": 0.0}
+        worst = {"f22": 0.0, "f44": 0.0, "s16": 0.0, "direct": 0.0}
         for li in range(1, len(den.fast) - 1):
             w, b, relu = den.fast[li]
             ref = torch.relu(Fn.conv2d(h.double(), w.double(), b.double(), padding=1))
@@ -956,23 +1039,27 @@ def test_conv64_rounding_on_the_networks_own_data():
             got22 = _hip.conv3x3_c64_winograd(h, den.wino[li].f22, b, relu)
             worst["f22"] = max(worst["f22"], e(got22))
             worst["f44"] = max(worst["f44"], e(_hip.conv3x3_c64_winograd44(h, den.wino[li].f44, b, relu)))
-            worst["direct"] = max(worst["direct"], e(torch.relu(Fn.conv2d(h, w, b, padding=1))))
+            e_direct = e(torch.relu(Fn.conv2d(h, w, b, padding=1)))
+            e_s16 = e(_hip.conv3x3_c64_split16(_hip.to_split16(h), den.wino[li].s16, b, relu, out_f32=True))
+            assert e_s16 < 1.15 * e_direct, (name, li, e_s16, e_direct)       # layer by layer no noisier than the vendor's fp32 convolution
+            worst["direct"], worst["s16"] = max(worst["direct"], e_direct), max(worst["s16"], e_s16)
             h = got22
         print(name, {k: "%.2e" % v for k, v in worst.items()})
-        assert worst["f22"] < 3e-7, (name, worst)
+        assert worst["f22"] < 3e-7 and worst["s16"] < 3.2e-7, (name, worst)
         assert worst["f44"] < (1.2e-6 if name == "x0" else 3.5e-7), (name, worst)
 
 
 def test_engine_conv_layout_and_kernel_choice():
-    """The engine's 64->64 layers: with the activations kept in the F(4x4,3x3) kernel's own layout between layers (the
-    default) the reconstruction is BIT-identical to the same kernel on channels_last tensors (same arithmetic, other
-    addresses); with the F(2x2,3x3) kernel forced it agrees to the rounding of the two algorithms."""
+    """The engine's 64->64 layers under its conv64 policies: the F(4x4,3x3) kernel with the activations kept in its own blk32 layout
+    between layers is BIT-identical to the same kernel on channels_last tensors (same arithmetic, other addresses); the kernels
+    agree with one another to their rounding; the engine-level policy equals the forced kernel bit for bit; conv64_f22_calls runs
+    exactly the first K f-calls on F(2x2,3x3)."""
     d = _clip("traffic_cacti.mat")
     Phi = d["mask"][None].to(DEV)
-    ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)[:2]            # 2 measurements = 16 images of 128x128: F(4x4) territory
+    ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)[:2]            # 2 measurements = 16 images of 128x128: 16 x 32-tile territory
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 6)[0].nonlinear_op
-    assert _hip.conv64_kernel_for(16, 128, 128) == "f44"
-    eng = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    assert _hip.conv64_kernel_for(16, 128, 128) == "s16" and _hip.conv64_kernel_for(16, 128, 128, policy="fast32") == "f44"
+    eng = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="fast32")
     assert eng.den.blk32
     a = eng.reconstruct(ys, Phi).clone()
     eng.den.blk32 = False
@@ -986,15 +1073,28 @@ def test_engine_conv_layout_and_kernel_choice():
     finally:
         _hip.FORCE_CONV64 = old
     assert not torch.equal(a, c) and rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 2e-5
-    # the engine-level policy: explicit "f22" == the forced run above, bit for bit; "auto" resolves by regime, not by batch size
     e22 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="f22")
     assert torch.equal(e22.reconstruct(ys, Phi), c)
-    assert eng.conv64_policy == "fast" and eng.conv64_f22_calls is None and DEQSCIEngine(net, max_iter=180).conv64_f22_calls == 40
-    assert DEQSCIEngine(net, max_iter=180, iterator="picard").conv64_f22_calls is None and DEQSCIEngine(net, max_iter=180, conv64="fast").conv64_f22_calls is None
-    # "auto" in the chaotic regime with every f-call inside the F(2x2,3x3) window == "f22", bit for bit
-    e_auto = DEQSCIEngine(net, max_iter=31, use_graph=False)
-    e_f22 = DEQSCIEngine(net, max_iter=31, use_graph=False, conv64="f22")
-    assert e_auto.conv64_f22_calls == 40 and torch.equal(e_auto.reconstruct(ys, Phi), e_f22.reconstruct(ys, Phi))
+    # the default: split-fp16 at this size
+    dflt = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    assert dflt.conv64 == "auto" and dflt.conv64_policy == "fast" and dflt.conv64_f22_calls is None
+    seen = []
+    _hip.CONV64_EVENT_HOOK = lambda kind, n, H, W: seen.append(kind)
+    try:
+        s_ = dflt.reconstruct(ys, Phi).clone()
+        assert set(seen) == {"s16"} and len(seen) == 13 * dflt.last_info["f_calls"]
+        es16 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="s16")
+        assert torch.equal(es16.reconstruct(ys, Phi), s_)
+        assert not torch.equal(s_, c) and rel_l2(s_.cpu().numpy(), c.cpu().numpy()) < 2e-5
+        # conv64_f22_calls = K: the first K f-calls on F(2x2,3x3), the rest on the policy's kernel; K >= all calls == "f22" bit for bit
+        del seen[:]
+        mixed = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64_f22_calls=3)
+        mixed.reconstruct(ys, Phi)
+        assert seen == ["f22"] * 39 + ["s16"] * (13 * (mixed.last_info["f_calls"] - 3))
+        allf = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64_f22_calls=100)
+        assert torch.equal(allf.reconstruct(ys, Phi), c)
+    finally:
+        _hip.CONV64_EVENT_HOOK = None
 
 
 def test_engine_graph_replay_is_bit_identical_to_eager():

@@ -312,17 +312,48 @@ def test_reference_pickle_checkpoint_formats(tmp_path):
 
 
 def test_conv64_policy_resolution():
-    """DEQSCIEngine(conv64="auto"): F(2x2,3x3) for the first 40 f-calls exactly where the choice is visible in the result (FFDNet +
-    Anderson beyond 30 iterations, the chaotic regime of SURVEY F9), the faster kernel per launch everywhere else; explicit
-    policies are honoured as they are."""
+    """DEQSCIEngine(conv64=...): "auto" = "fast" (split-fp16 direct convolution / Winograd F(2x2,3x3), the faster per launch) for every
+    configuration; "fast32" restricts to fp32 MFMA arithmetic; explicit kernels are honoured; conv64_f22_calls is off unless asked for."""
     ff = build_denoiser("ffdnet").eval()
     cnn = build_denoiser("SimpleCNN").eval()
-    pol = lambda net, **kw: (lambda e: (e.conv64_policy, e.conv64_f22_calls, e.den.f22_calls))(DEQSCIEngine(net, **kw))
-    assert pol(ff) == ("fast", 40, 40) and pol(ff, max_iter=31) == ("fast", 40, 40) and pol(ff, conv64_f22_calls=181) == ("fast", 181, 181)
-    assert pol(ff, max_iter=30) == ("fast", None, None) and pol(ff, iterator="picard") == ("fast", None, None) and pol(cnn) == ("fast", None, None)
-    assert pol(ff, conv64="fast") == ("fast", None, None) and pol(ff, conv64="f44") == ("f44", None, None) and pol(cnn, conv64="f22") == ("f22", None, None)
+    pol = lambda net, **kw: (lambda e: (e.conv64_policy, e.conv64_f22_calls, e.den.f22_calls, e.den.conv64))(DEQSCIEngine(net, **kw))
+    assert pol(ff) == ("fast", None, None, "fast") and pol(cnn, iterator="picard") == ("fast", None, None, "fast")
+    assert pol(ff, conv64="fast32", conv64_f22_calls=40) == ("fast32", 40, 40, "fast32")
+    for k in ("f22", "f44", "s16"):
+        assert pol(ff, conv64=k) == (k, None, None, k)
     with pytest.raises(ValueError):
         DEQSCIEngine(ff, conv64="f33")
-    assert _hip.conv64_kernel_for(64, 128, 128, policy="f22") == "f22" and _hip.conv64_kernel_for(1, 16, 16, policy="f44") == "f44"
+    for k in ("f22", "f44", "s16"):
+        assert _hip.conv64_kernel_for(64, 128, 128, policy=k) == k and _hip.conv64_kernel_for(1, 16, 16, policy=k) == k
     with pytest.raises(_hip.DeqsciHipError):
         _hip.conv64_kernel_for(1, 16, 16, policy="direct")
+    # the size rule (256 CUs): one block tile per CU and more -> the 16 x 32-tile kernel; below -> F(2x2,3x3); huge images -> F(2x2,3x3)
+    _hip._CUS[0] = 256
+    try:
+        import torch
+        dev = torch.device("cuda", 0)
+        assert [_hip.conv64_kernel_for(n, 128, 128, dev, "fast") for n in (1, 4, 6, 8, 64)] == ["f22", "f22", "s16", "s16", "s16"]
+        assert [_hip.conv64_kernel_for(n, 128, 128, dev, "fast32") for n in (1, 4, 6, 8, 64)] == ["f22", "f22", "f44", "f44", "f44"]
+        assert _hip.conv64_kernel_for(2, 256, 256, dev, "fast") == "s16" and _hip.conv64_kernel_for(1, 256, 256, dev, "fast") == "f22"
+        assert _hip.conv64_kernel_for(64, 2900, 2900, dev, "fast") == "f22"
+    finally:
+        _hip._CUS.pop(0, None)
+
+
+def test_split16_weight_pack_layout():
+    """Split16Weights: hi + lo == 2^sw w to 2^-22, max |2^sw w| in [2^13, 2^14), and the LDS order of csrc/conv_s16.hip
+    [chunk][tap][piece][cout group][lane][j] with cout = 32 g + lane % 32, cin = 16 c + 8 (lane // 32) + j."""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.07
+    W = _hip.Split16Weights(w)
+    ws = w * 2.0 ** W.sw
+    assert 2 ** 13 <= float(ws.abs().max()) < 2 ** 14
+    assert tuple(W.packed.shape) == (4, 9, 2, 2, 2, 32, 8) and W.packed.dtype == torch.float16
+    rec = W.packed[:, :, 0].float() + W.packed[:, :, 1].float()                       # [c][tap][g][kb][m][j]
+    for (c, tap, gq, kb, m, j) in ((0, 0, 0, 0, 0, 0), (3, 8, 1, 1, 31, 7), (2, 4, 1, 0, 5, 3), (1, 7, 0, 1, 17, 6)):
+        cout, cin = 32 * gq + m, 16 * c + 8 * kb + j
+        want = float(ws[cout, cin, tap // 3, tap % 3])
+        assert abs(float(rec[c, tap, gq, kb, m, j]) - want) <= 2.0 ** -21 * abs(want) + 1e-30
+    assert W.out_scale_sp16 == 2.0 ** -W.sw and W.out_scale_f32 == 2.0 ** -(W.sw + 8)
+    rel = float(((rec.permute(2, 4, 0, 3, 5, 1).reshape(64, 64, 9) - ws.reshape(64, 64, 9)).norm()) / ws.norm())
+    assert rel < 2e-7

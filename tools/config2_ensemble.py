@@ -50,6 +50,9 @@ def main():
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
     configs = {"F(4x4) conv wherever faster (conv64='fast')": {"kw": dict(conv64="fast")}, "F(2x2) conv (conv64='f22')": {"kw": dict(conv64="f22")},
                "MIOpen direct conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}, "engine default (conv64='auto')": {}}
+    configs["split-fp16 direct conv (conv64='s16')"] = {"kw": dict(conv64="s16")}
+    for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID_S16", "").split(",") if v]:
+        configs[f"hybrid: F(2x2) for f-calls < {k}, then s16"] = {"kw": dict(conv64="s16"), "f22_calls": k}
     for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID", "").split(",") if v]:
         configs[f"hybrid: F(2x2) for f-calls < {k}, then fast"] = {"kw": dict(conv64="fast"), "f22_calls": k}
     res = {}

@@ -56,10 +56,7 @@ def main():
             got["f44"] = _hip.conv3x3_c64_winograd44(h, den.wino[li].f44, b, relu)
             g = F.conv2d(h, w, b, padding=1)
             got["miopen"] = torch.relu(g) if relu else g
-            extra = getattr(_hip, "extra_conv64_kernels", None)
-            if extra is not None:
-                for k, fn in extra(w, b, relu).items():
-                    got[k] = fn(h)
+            got["s16"] = _hip.conv3x3_c64_split16(_hip.to_split16(h), _hip.Split16Weights(w), b, relu, out_f32=True)
             for k, v in got.items():
                 row[k] = rel(v, ref)
             # where the F(4x4) error sits

@@ -56,7 +56,7 @@ def main():
         ref = ffdnet64(den, x, sig)
         row = {"call": call, "sigma": float(sig), "z1_rms": float(z1.pow(2).mean().sqrt()),
                "z1_roughness": float((z1[..., 1:] - z1[..., :-1]).pow(2).mean().sqrt() / z1.pow(2).mean().sqrt())}
-        for pol in ("f22", "f44"):
+        for pol in ("f22", "f44", "s16"):
             den.conv64 = den._policy = pol
             den.f22_calls = None
             out, _ = orig(z1, call)
