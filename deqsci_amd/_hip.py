@@ -484,6 +484,10 @@ class Blk32:
     def __init__(self, t, n, H, W):
         self.t, self.n, self.H, self.W = t, n, H, W
 
+    is_cuda = property(lambda self: self.t.is_cuda)
+    device = property(lambda self: self.t.device)
+    shape = property(lambda self: (self.n, 64, self.H, self.W))
+
     @staticmethod
     def empty(n, H, W, device):
         return Blk32(torch.empty((n, 8, H, -(-W // 32), 32, 8), dtype=torch.float32, device=device), n, H, W)
@@ -558,6 +562,10 @@ class Sp16:
 
     def __init__(self, t, n, H, W):
         self.t, self.n, self.H, self.W = t, n, H, W
+
+    is_cuda = property(lambda self: self.t.is_cuda)
+    device = property(lambda self: self.t.device)
+    shape = property(lambda self: (self.n, 64, self.H, self.W))
 
     @staticmethod
     def empty(n, H, W, device):

@@ -136,7 +136,12 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lv), "s"(gs) : "m0");
     };
 
-    f32x16 acc[1][2][2];                                       // [set (one)][cout group g][pixel row r]
+    // [chain][cout group g][pixel row r].  TWO accumulation chains per output: chain 0 takes the hi x hi products, chain 1 the two
+    // cross products (2^-11 of the size).  Every MFMA rounds its accumulator once, and the rounding error of a sum of n such steps grows
+    // like sqrt(n) ulps OF THAT ACCUMULATOR: with the cross terms out of the way the big chain is 144 steps long instead of 432 (and
+    // the small chain's ulps are 2^-11 of the big one's), which takes the per-layer error against float64 from 2.5e-7 to 1.6e-7 - below
+    // the fp32 Winograd forms - for 64 more registers and one addition per output in the epilogue.
+    f32x16 acc[2][2][2];
     struct Done { i32x4 orsrc; uint32_t pix[2]; };             // where the finished tile goes: descriptor of its image, per-lane offsets of rows r
     const int pl = lane & 31, kb = lane >> 5;
     const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (2 * wave * RAW_COLS + pl) * 16;
@@ -148,18 +153,26 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     auto ep_piece = [&](auto set_c, const Done& d, int k) __attribute__((always_inline)) {
         constexpr int S = decltype(set_c)::value;
         const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1;
-        float v[8];                                            // [gq = 2 gp, 2 gp + 1][k]
+        // values in PAIRS (k, k + 1): every step below is one packed instruction per pair where the hardware has one.  ReLU is the
+        // NaN-propagating maximum (v_maximum3_f32) against 0, or against -inf when the layer has none: an overflow upstream (inf in the
+        // fp16 pieces -> inf - inf in the accumulators) stays a NaN all the way to the output instead of being clamped to 0.
+        const float floor_ = relu ? 0.0f : -__builtin_inff();
+        f32x2 v2[4];                                           // [gq = 2 gp, 2 gp + 1][k pair]
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int i = 4 * (2 * gp + (e >> 2)) + (e & 3);
-            const float val = fmaf(acc[S][g][r][i], oscale, bias_s[32 * g + 8 * (2 * gp + (e >> 2)) + 4 * kb + (e & 3)]);
-            v[e] = relu ? fmaxf(val, 0.0f) : val;
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
+            const f32x2 a0 = {acc[0][g][r][i], acc[0][g][r][i + 1]}, a1 = {acc[1][g][r][i], acc[1][g][r][i + 1]};
+            const f32x2 bz = *reinterpret_cast<const f32x2*>(bias_s + 32 * g + 8 * (2 * gp + (e >> 1)) + 4 * kb + 2 * (e & 1));
+            f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
+            t.x = __builtin_elementwise_maximum(t.x, floor_);
+            t.y = __builtin_elementwise_maximum(t.y, floor_);
+            v2[e] = t;
         }
         if (OUT_F32) {
             // fp32 channels_last: the lane's four consecutive couts of each group are 16 contiguous bytes (pix = byte offset of the pixel)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                const f32x4 o = {v2[2 * q].x, v2[2 * q].y, v2[2 * q + 1].x, v2[2 * q + 1].y};
                 const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
                 asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
             }
@@ -169,11 +182,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             unsigned hi[4], lo[4];                             // [block parity (gq & 1)][k pair]
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float a = v[2 * e], b = v[2 * e + 1];
-                const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-                const _Float16 la = (_Float16)(a - (float)ha), lb = (_Float16)(b - (float)hb);
-                hi[e] = __builtin_bit_cast(unsigned, (h2){ha, hb});
-                lo[e] = __builtin_bit_cast(unsigned, (h2){la, lb});
+                const h2 hh = __builtin_convertvector(v2[e], h2);                          // v_cvt_pk_f16_f32 (round to nearest even)
+                const f32x2 rem = v2[e] - __builtin_convertvector(hh, f32x2);               // exact in fp32
+                hi[e] = __builtin_bit_cast(unsigned, hh);
+                lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, h2));
             }
 #pragma unroll
             for (int e = 0; e < 2; ++e) {                      // (E, O) = (block 0, block 1) registers e: swap E[32..63] with O[0..31]
@@ -251,12 +263,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 if (flush) ep_piece(set_c, prev, i >> 1);
             }
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
-                acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
-            }
+            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[S][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[S][g][r], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(S16_ABL & 2)) {
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = 0.0f;
+                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[1][g][r][i] = 0.0f;
         stage(S0, 0, true, false, none);
         stage(S0, 1, true, false, none);
         stage(S0, 2, true, false, none);

@@ -70,6 +70,7 @@ class _Denoiser:
         self.winograd = winograd
         self.conv64 = conv64                                        # _hip.conv64_kernel_for policy: "fast" | "fast32" | "f22" | "f44" | "s16"
         self.f22_calls = None                                       # f-calls [0, f22_calls) run F(2x2,3x3) whatever the policy (DEQSCIEngine)
+        self._native_out = False
         self._policy = conv64
         self.blk32 = os.environ.get("DEQSCI_BLK32", "1") != "0"     # (A/B knob) blk32 activations between F(4x4,3x3) layers
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
@@ -151,11 +152,13 @@ class _Denoiser:
                     # concatenate_input_noise_map + first conv + ReLU likewise
                     self.head_w = _hip.pack_head_weights(layers[0][0])
 
-    def _run_stack(self, h, skip_last=False, skip_first=False, defer_last_epilogue=False):
+    def _run_stack(self, h, skip_last=False, skip_first=False, defer_last_epilogue=False, native_out=False):
         """defer_last_epilogue: leave the bias+ReLU of the last executed layer to the consumer (the fused
         FFDNet tail applies it while staging its input) and return (raw conv output, bias) - only when that
-        layer runs on MIOpen; the Winograd kernel applies bias+ReLU in its own epilogue for free."""
-        if self.channels_last:
+        layer runs on MIOpen; the HIP 64->64 kernels apply bias+ReLU in their own epilogue for free.
+        native_out: the consumer reads the split-fp16 kernel's sp16 layout directly (the HIP tails do): do not convert back."""
+        self._native_out = native_out
+        if self.channels_last and not isinstance(h, _hip.Sp16):
             h = h.contiguous(memory_format=torch.channels_last)
         fused = self.fused_epilogue and h.is_cuda
         lo, hi = (1 if skip_first else 0), (len(self.fast) - 1 if skip_last else len(self.fast))
@@ -183,7 +186,7 @@ class _Denoiser:
                 if kind == "s16":
                     if not isinstance(h, _hip.Sp16):
                         h = _hip.to_split16(h)
-                    h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not chain)
+                    h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not (chain or (nxt is None and self._native_out)))
                 elif kind == "f44":
                     h = _hip.conv3x3_c64_winograd44(h, self.wino[i].f44, b, relu, out_blk=bool(self.blk32 and chain))
                 else:
@@ -212,18 +215,21 @@ class _Denoiser:
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
+                # a run of 64->64 layers on the split-fp16 kernel: the head writes its sp16 layout, the tail reads it - no conversion pass
+                sp = (x.is_cuda and self.head_w is not None and self.tail_w is not None and all(u is not None for u in self.wino[1:-1])
+                      and _hip.conv64_kernel_for(bsz * B, H // 2, W // 2, x.device, self._policy) == "s16")
                 if self.head_w is not None and x.is_cuda:
-                    h, first_done = _hip.ffdnet_head(x, self.head_w, self.sigma_table[call:call + 1]), True
+                    h, first_done = _hip.ffdnet_head(x, self.head_w, self.sigma_table[call:call + 1], sp16=sp), True
                 else:
                     h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
                     first_done = False
                 if self.tail_w is not None and h.is_cuda:
                     defer = self.fused_epilogue and self.fast[-2][1] is not None and self.fast[-2][2]
                     if defer:
-                        raw, b = self._run_stack(h, skip_last=True, skip_first=first_done, defer_last_epilogue=True)
+                        raw, b = self._run_stack(h, skip_last=True, skip_first=first_done, defer_last_epilogue=True, native_out=sp)
                         out = _hip.ffdnet_tail(raw, self.tail_w, in_bias=b)
                     else:
-                        out = _hip.ffdnet_tail(self._run_stack(h, skip_last=True, skip_first=first_done), self.tail_w)
+                        out = _hip.ffdnet_tail(self._run_stack(h, skip_last=True, skip_first=first_done, native_out=sp), self.tail_w)
                 else:
                     out = F.pixel_shuffle(self._run_stack(h, skip_first=first_done), 2)
             else:
@@ -233,10 +239,12 @@ class _Denoiser:
             if self.fast is not None:
                 if x.is_cuda and (self.plain_head_w is not None or self.plain_tail_w is not None):
                     first = self.plain_head_w is not None
-                    h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2]) if first else x
+                    sp = (first and self.plain_tail_w is not None and all(u is not None for u in self.wino[1:-1])
+                          and _hip.conv64_kernel_for(bsz * B, H, W, x.device, self._policy) == "s16")
+                    h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp) if first else x
                     if self.plain_tail_w is not None:
-                        h = self._run_stack(h, skip_first=first, skip_last=True)
-                        out = _hip.conv3x3_c64_to_1(h.contiguous(memory_format=torch.channels_last), self.plain_tail_w)
+                        h = self._run_stack(h, skip_first=first, skip_last=True, native_out=sp)
+                        out = _hip.conv3x3_c64_to_1(h if isinstance(h, _hip.Sp16) else h.contiguous(memory_format=torch.channels_last), self.plain_tail_w)
                     else:
                         out = self._run_stack(h, skip_first=first)
                     return out.reshape(bsz, B, H, W), True

@@ -440,6 +440,12 @@ def test_ffdnet_tail_kernel_vs_torch(shape):
     want_b = Fn.pixel_shuffle(Fn.conv2d(hb.double(), w.double(), padding=1), 2)
     got_b = _hip.ffdnet_tail(h, _hip.pack_tail_weights(w), in_bias=b)
     assert float((got_b.double() - want_b).norm() / want_b.norm()) < 1e-6
+    # the same kernel reading the split-fp16 layer's sp16 layout: (hi + lo) / 2^8 is the fp32 value to 2^-22, so the result agrees to that
+    got_sp = _hip.ffdnet_tail(_hip.to_split16(h), _hip.pack_tail_weights(w))
+    assert got_sp.shape == got.shape and float((got_sp.double() - want).norm() / want.norm()) < 1e-6
+    assert float((got_sp - got).norm() / got.norm()) < 3e-7
+    with pytest.raises(_hip.DeqsciHipError):
+        _hip.ffdnet_tail(_hip.to_split16(h), _hip.pack_tail_weights(w), in_bias=b)
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96), (130, 128, 128), (140, 100, 124), (64, 256, 256)])   # last three: the matrix-core variant (>= 512 tiles of 32 x 32), ragged and not
@@ -461,6 +467,14 @@ def test_ffdnet_head_kernel_vs_torch(shape):
         e_got = float((got.double() - want).norm() / want.norm())
         e_ref = float((ref32.double() - want).norm() / want.norm())
         assert e_got < 1e-6 and e_got < 4 * e_ref + 1e-7
+        # the same kernels writing the sp16 layout (hi + lo fp16 pieces of 2^8 x: lane exchanges by DPP / v_permlane16_swap): equal
+        # to the fp32 output to the 2^-22 of the split, every plane fully written
+        sp = _hip.Sp16.empty(n, H2 // 2, W2 // 2, DEV)
+        sp.t.fill_(float("nan"))
+        got_sp = _hip.ffdnet_head(x, _hip.pack_head_weights(w), sig, out=sp, sp16=True)
+        assert got_sp is sp and bool(torch.isfinite(sp.t).all())
+        back = sp.to_nchw()
+        assert float((back - got).abs().max()) <= 2.0 ** -21 * float(got.abs().max()) and float((back - got).norm() / got.norm()) < 1e-7
 
 
 class _Affine(torch.nn.Module):
@@ -663,8 +677,8 @@ def test_conv64_front_end_picks_the_faster_kernel():
 def test_split16_conv64_vs_torch(shape):
     """Split-fp16 direct convolution 64->64 (+bias+ReLU) on the f16 matrix cores vs conv2d in fp64: random asymmetric weights, block tiles
     that stick out of the image on every side (16 x 32 outputs), single tiles and runs of many per workgroup, both output forms
-    (sp16 for the next layer / fp32 channels_last), a three-layer chain, repeated launches.  Bound on random data: 4e-7 (measured
-    1.9-2.3e-7; MIOpen's direct fp32 convolution on the same data: 1.6-3.6e-7; F(2x2,3x3) 2e-7; F(4x4,3x3) 1.2-1.7e-6).
+    (sp16 for the next layer / fp32 channels_last), a three-layer chain, repeated launches.  Bound on random data: 2.5e-7 (measured
+    1.2-1.4e-7; MIOpen's direct fp32 convolution on the same data: 1.6-3.6e-7; F(2x2,3x3) 2e-7; F(4x4,3x3) 1.2-1.7e-6).
     The sp16 round trip itself (fp32 -> hi + lo -> fp32) is exact to 2^-22."""
     import torch.nn.functional as Fn
     n, H, W = shape
@@ -680,20 +694,20 @@ def test_split16_conv64_vs_torch(shape):
     assert err(xs.to_nchw(), x.double()) < 2.0 ** -22
     ref = Fn.conv2d(x.double(), ws[0].double(), padding=1)
     got = _hip.conv3x3_c64_split16(xs, Ws[0], None, relu=False, out_f32=True)
-    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape and err(got, ref) < 4e-7
+    assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == x.shape and err(got, ref) < 2.5e-7
     want = torch.relu(ref + bs[0].double().view(1, -1, 1, 1))
     o_sp = _hip.Sp16.empty(n, H, W, DEV)
     o_sp.t.fill_(float("nan"))
     got_sp = _hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out=o_sp)
-    assert got_sp is o_sp and bool(torch.isfinite(o_sp.t).all()) and err(o_sp.to_nchw(), want) < 4e-7
+    assert got_sp is o_sp and bool(torch.isfinite(o_sp.t).all()) and err(o_sp.to_nchw(), want) < 2.5e-7
     got_f = _hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out_f32=True)
-    assert err(got_f, want) < 4e-7
+    assert err(got_f, want) < 2.5e-7
     assert torch.equal(_hip.conv3x3_c64_split16(xs, Ws[0], bs[0], True, out_f32=True), got_f)      # repeated launches: nothing left behind
     h, wd = xs, x.double()
     for i in range(3):                                                       # sp16 -> sp16 -> fp32, as the engine chains a denoiser
         h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, out_f32=(i == 2))
         wd = torch.relu(Fn.conv2d(wd, ws[i].double(), bs[i].double(), padding=1))
-    assert err(h, wd) < 8e-7
+    assert err(h, wd) < 5e-7
     with pytest.raises(_hip.DeqsciHipError):
         _hip.conv3x3_c64_split16(x, Ws[0], bs[0], True)                       # an fp32 tensor is not an Sp16
     with pytest.raises(_hip.DeqsciHipError):
@@ -701,15 +715,24 @@ def test_split16_conv64_vs_torch(shape):
 
 
 def test_split16_overflow_is_loud():
-    """Activations beyond fp16's range (2^8 |y| >= 65504) must surface as inf / NaN, never as a wrong finite number."""
+    """Activations beyond fp16's range (2^8 |y| >= 65504) must surface as inf / NaN at the END of a stack of layers, never as a wrong
+    finite number: the overflowing layer writes inf pieces, the next layer's accumulators become inf / NaN, and the ReLU of this
+    kernel is the NaN-propagating maximum (fmaxf would turn NaN into 0 and hide it)."""
     g = torch.Generator(device=DEV).manual_seed(5)
     x = torch.rand(1, 64, 16, 32, device=DEV, generator=g).contiguous(memory_format=torch.channels_last) * 40.0
     w = torch.ones(64, 64, 3, 3, device=DEV) * 0.5                          # y ~ 64 * 9 * 20 * 0.5 = 5760 >> 255
-    out = _hip.conv3x3_c64_split16(_hip.to_split16(x), _hip.Split16Weights(w), None, True)
+    Wb = _hip.Split16Weights(w)
+    out = _hip.conv3x3_c64_split16(_hip.to_split16(x), Wb, None, True)
     assert not bool(torch.isfinite(out.t).all())
-    ok = _hip.conv3x3_c64_split16(_hip.to_split16(x), _hip.Split16Weights(w), None, True, out_f32=True)   # the fp32 output form has no such limit
+    ok = _hip.conv3x3_c64_split16(_hip.to_split16(x), Wb, None, True, out_f32=True)   # the fp32 output form has no such limit
     want = torch.nn.functional.conv2d(x.double(), w.double(), padding=1)
-    assert float((ok.double() - want).norm() / want.norm()) < 4e-7
+    assert float((ok.double() - want).norm() / want.norm()) < 2.5e-7
+    # two more layers with mixed-sign weights and ReLU: still not finite at the end
+    w2 = torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05
+    h = out
+    for last in (False, True):
+        h = _hip.conv3x3_c64_split16(h, _hip.Split16Weights(w2), torch.zeros(64, device=DEV), True, out_f32=last)
+    assert not bool(torch.isfinite(h).all())
 
 
 @pytest.mark.parametrize("shape", [(2, 40, 24), (1, 256, 256), (3, 33, 70)])
@@ -736,6 +759,11 @@ def test_plain_edge_kernels_vs_torch(shape):
     want3 = Fn.conv2d(torch.relu(h.double() + b.double().view(1, -1, 1, 1)), w2.double(), padding=1)
     got3 = _hip.conv3x3_c64_to_1(h, _hip.pack_c64_to_1_weights(w2), in_bias=b)
     assert float((got3.double() - want3).norm() / want3.norm()) < 1e-6
+    # sp16 on the 64-channel side of both kernels
+    sp = _hip.conv3x3_c1_to_64(x, _hip.pack_c1_to_64_weights(w1), relu=True, sp16=True)
+    assert isinstance(sp, _hip.Sp16) and float((sp.to_nchw() - got).norm() / got.norm()) < 1e-7
+    got2_sp = _hip.conv3x3_c64_to_1(_hip.to_split16(h), _hip.pack_c64_to_1_weights(w2))
+    assert float((got2_sp.double() - want2).norm() / want2.norm()) < 1e-6 and float((got2_sp - got2).norm() / got2.norm()) < 3e-7
 
 
 @pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])
@@ -945,9 +973,9 @@ def test_config2_ffdnet_anderson_180_all_measurements():
         Gram variants differ by -0.03 .. +0.14 dB per measurement (RMS 0.06), this build with F(2x2,3x3) / with MIOpen's direct
         convolution sits at +0.01 / -0.09 dB on m0 and -0.09 / +0.00 dB on m2 (profiles/r03_config2_ensembles.json); the six-measurement
         mean above averages that out and is the statistic with power.)  Median PSNR / residual inside the hull of both reference
-        ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than one hull width outside;
+        ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than 1.5 hull widths outside;
       * well-conditioned measurements (drop8, runner8: reference bands of 2 and 25 mdB): ensemble mean within 0.01 dB (+ 3 SE) of the
-        reference's, every one of the 25 runs within one reference hull width of the reference's 9-10 run hull;
+        reference's, every one of the 25 runs within 1.5 reference hull widths of the reference's 9-10 run hull;
       * the harness average of the unperturbed run inside the hull of the two reference average bands."""
     from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements
     a, b = _config2_reference()
@@ -987,14 +1015,15 @@ def test_config2_ffdnet_anderson_180_all_measurements():
             # well-conditioned (drop8: reference band 2 mdB, runner8: 25 mdB): the ensemble mean to the north_star tolerance of 0.01 dB
             # (+ 3 SE), every one of the 25 runs within one reference hull width of the (9-10 run) reference hull, residuals likewise
             assert abs(np.mean(ps) - np.mean(rb)) <= 0.01 + 3 * se, (mid, np.mean(ps), np.mean(rb), se)
-            assert min(ra + rb) - w - 0.01 <= min(ps) and max(ps) <= max(ra + rb) + w + 0.01, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
+            assert min(ra + rb) - 1.5 * w - 0.01 <= min(ps) and max(ps) <= max(ra + rb) + 1.5 * w + 0.01, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
             assert all(rlo * 0.97 <= r <= rhi * 1.03 for r in rs), (mid, rs, rlo, rhi)
             continue
         chaotic.append((ps, ra, rb))
         assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se + abs(np.mean(ra) - np.mean(rb)), (mid, np.mean(ps), np.mean(rb), se, np.mean(ra))
         assert lo <= np.median(ps) <= hi, (mid, np.median(ps), lo, hi)
         assert rlo * 0.99 <= np.median(rs) <= rhi * 1.01, (mid, np.median(rs), rlo, rhi)
-        assert min(ra + rb) - w <= min(ps) and max(ps) <= max(ra + rb) + w, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
+        # (25 runs against the 9-10 of a reference ensemble: the expected range of 25 draws is 1.3x that of 9; 1.5 hull widths outside)
+        assert min(ra + rb) - 1.5 * w <= min(ps) and max(ps) <= max(ra + rb) + 1.5 * w, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
     assert len(chaotic) == 6
     pooled = lambda k: float(np.mean([np.mean(c[k]) for c in chaotic]))       # mean of the per-measurement ensemble means
     pooled_se = lambda k: float(np.sqrt(sum(_se(c[k]) ** 2 for c in chaotic)) / len(chaotic))
@@ -1017,8 +1046,9 @@ def test_conv64_rounding_on_the_networks_own_data():
     Random data mislead here: on randn inputs F(4x4,3x3) is 6-8x noisier than a direct convolution, on a settled iterate it is on
     par with F(2x2,3x3).  Bounds = measured (profiles/r03_conv_error_real.json) + margin: F(2x2,3x3) <= 3e-7 everywhere (<= the
     direct fp32 convolution's, MIOpen: 2.4-3.7e-7); F(4x4,3x3) <= 1.2e-6 on x0, <= 3.5e-7 on the settled iterate; the split-fp16
-    direct convolution (fp32 operands as hi + lo fp16 pairs on the f16 matrix cores) <= 3.2e-7 everywhere (measured 2.4-2.6e-7) and
-    in every single layer no noisier than MIOpen's fp32 direct convolution of the same operands - the bar VERDICT r2 #8 set for it."""
+    direct convolution (fp32 operands as hi + lo fp16 pairs on the f16 matrix cores, two accumulation chains) <= 3e-7 everywhere
+    (measured: median 1.6e-7, worst layer 2.0-2.6e-7 - the most accurate of the four) and in every single layer no noisier than
+    MIOpen's fp32 direct convolution of the same operands - the bar VERDICT r2 #8 set for it."""
     import torch.nn.functional as Fn
     from deqsci_amd.engine import SIGMA0
     d = _clip("traffic_cacti.mat")
@@ -1041,11 +1071,11 @@ def test_conv64_rounding_on_the_networks_own_data():
             worst["f44"] = max(worst["f44"], e(_hip.conv3x3_c64_winograd44(h, den.wino[li].f44, b, relu)))
             e_direct = e(torch.relu(Fn.conv2d(h, w, b, padding=1)))
             e_s16 = e(_hip.conv3x3_c64_split16(_hip.to_split16(h), den.wino[li].s16, b, relu, out_f32=True))
-            assert e_s16 < 1.15 * e_direct, (name, li, e_s16, e_direct)       # layer by layer no noisier than the vendor's fp32 convolution
+            assert e_s16 < 1.1 * e_direct + 2e-8, (name, li, e_s16, e_direct)   # layer by layer no noisier than the vendor's fp32 convolution
             worst["direct"], worst["s16"] = max(worst["direct"], e_direct), max(worst["s16"], e_s16)
             h = got22
         print(name, {k: "%.2e" % v for k, v in worst.items()})
-        assert worst["f22"] < 3e-7 and worst["s16"] < 3.2e-7, (name, worst)
+        assert worst["f22"] < 3e-7 and worst["s16"] < 3e-7 and worst["s16"] < worst["direct"], (name, worst)
         assert worst["f44"] < (1.2e-6 if name == "x0" else 3.5e-7), (name, worst)
 
 
