@@ -45,7 +45,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _f32, _int, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "deqsci_ffdnet_head_sp16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_ffdnet_tail_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
@@ -623,17 +623,17 @@ def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=Fals
     n, H, W, dev = x.n, x.H, x.W, x.t.device
     if out_f32:
         o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        ot, b = o, bias
+        ot, bscale = o, 1.0
         scale = weights.out_scale_f32
     else:
         o = out if out is not None else Sp16.empty(n, H, W, dev)
-        ot, b = o.t, (None if bias is None else bias * SP16_ACT_SCALE)
+        ot, bscale = o.t, SP16_ACT_SCALE
         scale = weights.out_scale_sp16
     ev = _hook_events("s16", n, H, W, events) or (None, None)
     wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
     with _dev(x.t):
-        _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(b, "bias", True), ot.data_ptr(), n, H, W, 1 if relu else 0,
-                                                 float(scale), 1 if out_f32 else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
+        _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), ot.data_ptr(), n, H, W, 1 if relu else 0,
+                                                 float(scale), float(bscale), 1 if out_f32 else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
     return o
 
 

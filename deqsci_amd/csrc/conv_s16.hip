@@ -65,7 +65,7 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // OUT_F32 = 0: sp16 output (the next 64->64 layer's input); 1: fp32 channels_last (n, H, W, 64) output (the consumer is not this kernel)
 template <int OUT_F32>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
-                                                          char* __restrict__ y, int H, int W, int relu, float oscale, int tiles_x, int tiles_y,
+                                                          char* __restrict__ y, int H, int W, int relu, float oscale, float bscale, int tiles_x, int tiles_y,
                                                           int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     };
 
     // ---- prologue: bias, chunk 0 of the first tile
-    if (wave == 0) bias_s[lane] = bias ? bias[lane] : 0.0f;
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
     set_fetch_tile(t_first);
 #pragma unroll
     for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
@@ -345,7 +345,8 @@ static void s16_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
 }
 
 extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y, int64_t n, int64_t H, int64_t W,
-                                          int relu, float out_scale, int out_f32, deqsci_stream_t stream, void* start_event, void* stop_event) {
+                                          int relu, float out_scale, float bias_scale, int out_f32, deqsci_stream_t stream, void* start_event,
+                                          void* stop_event) {
     if (!x_sp16 || !w_packed || !y) return DEQSCI_ERR_NULL;
     if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
@@ -364,7 +365,8 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
     hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
 #define S16_LAUNCH(KERNEL)                                                                                                                  \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
-                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img, sh_img, \
+                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, bias_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img,    \
+                          sh_img, \
                           mg_tx, sh_tx)
     if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1>)); else S16_LAUNCH((s16::conv_s16_kernel<0>));
 #undef S16_LAUNCH

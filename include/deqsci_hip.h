@@ -189,12 +189,12 @@ int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_pack
  *     accumulation.  x_sp16: the activation as [n][4 cin chunks][2 pieces: hi, lo][2 blocks of 8 channels][H][W][8 halfs] holding
  *     2^8 x (deqsci_f32_to_split16 writes it from fp32 channels_last; the kernel itself writes it with out_f32 = 0).  w_packed:
  *     2^sw w as [4 chunks][9 taps][2 pieces][2 cout groups of 32][64 lanes][8 halfs] (cout = 32 g + lane % 32, cin = 16 c +
- *     8 (lane / 32) + j).  Output = relu?(acc * out_scale + bias): out_f32 = 0 -> sp16 of 2^8 y (pass out_scale = 2^-sw and
- *     2^8 bias), out_f32 = 1 -> fp32 channels_last (n,H,W,64) (pass out_scale = 2^-(8+sw) and bias).  An activation beyond
+ *     8 (lane / 32) + j).  Output = relu?(acc * out_scale + bias * bias_scale): out_f32 = 0 -> sp16 of 2^8 y (pass out_scale = 2^-sw,
+ *     bias_scale = 2^8), out_f32 = 1 -> fp32 channels_last (n,H,W,64) (pass out_scale = 2^-(8+sw), bias_scale = 1).  An activation beyond
  *     fp16's range (|y| >= 255.9) becomes inf, never a silently wrong finite number.  Images up to 2^31 / 256 - 33 pixels.
  *     start_event / stop_event: both NULL, or both raw hipEvent_t handles (measurement). */
 int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y,
-                               int64_t n, int64_t H, int64_t W, int relu, float out_scale, int out_f32,
+                               int64_t n, int64_t H, int64_t W, int relu, float out_scale, float bias_scale, int out_f32,
                                deqsci_stream_t stream, void* start_event, void* stop_event);
 int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream);
 /* The edge layers of the denoisers with the sp16 layout on their 64-channel side (same kernels, other stores / loads): the heads

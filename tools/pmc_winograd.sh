@@ -18,21 +18,26 @@ python - <<'PY'
 import csv, collections, glob, json
 n, H, W = 64, 128, 128
 for kern, fname, pos, outs, name in (("winograd_conv64_kernel", "gpurun_out/pmc_winograd.json", 16, 4, "deqsci::winograd_conv64_kernel"),
-                                     ("winograd44_conv64_kernel", "gpurun_out/pmc_winograd44.json", 36, 16, "deqsci::w44::winograd44_conv64_kernel")):
+                                     ("winograd44_conv64_kernel<1, 1>", "gpurun_out/pmc_winograd44.json", 36, 16, "deqsci::w44::winograd44_conv64_kernel<1,1> (blk32 -> blk32)"),
+                                     ("conv_s16_kernel<0>", "gpurun_out/pmc_conv_s16.json", 0, 0, "deqsci::s16::conv_s16_kernel<0> (sp16 -> sp16)")):
     agg = collections.defaultdict(list)
     for f in sorted(glob.glob('gpurun_out/pmc_wg/p*/k_counter_collection.csv')):
         for r in csv.DictReader(open(f)):
             if kern in r["Kernel_Name"]:
                 agg[r['Counter_Name']].append(float(r['Counter_Value']))
     med = {k: sorted(v)[len(v) // 2] for k, v in agg.items()}
-    alg = 2 * n * H * W * 64 * 4 + pos * 64 * 64 * 4
+    s16 = pos == 0
+    alg = 2 * n * H * W * 64 * 4 + (64 * 64 * 9 * 4 if s16 else pos * 64 * 64 * 4)   # read x once, write y once (256 B per pixel each way) + the weights
     rd, wr = med.get("FETCH_SIZE", 0) * 1024 * 2.0, med.get("WRITE_SIZE", 0) * 1024 * 1.0
-    mfma = n * H * W / outs * pos * 64 * 64 * 2 / 2048          # v_mfma_f32_16x16x4_f32: 2048 flops each
+    # MFMA instructions: split-fp16 3 x 9 taps x 64 x 64 x 2 flops per pixel on v_mfma_f32_32x32x16_f16 (32768 flops each); Winograd on
+    # v_mfma_f32_16x16x4_f32 (2048 flops each)
+    mfma = n * H * W * 3 * 9 * 64 * 64 * 2 / 32768 if s16 else n * H * W / outs * pos * 64 * 64 * 2 / 2048
     out = {"kernel": name, "shape": [n, 64, H, W], "launches": len(agg.get("FETCH_SIZE", [])), "counters_median": med,
            "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "hbm_bytes_per_launch": int(rd + wr),
            "algorithmic_hbm_bytes": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 3),
            "mfma_instructions": int(mfma), "non_mfma_valu_per_mfma": round((med.get("SQ_INSTS_VALU", 0) - mfma) / mfma, 3),
-           "mfma_busy_fraction": round(med.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * med.get("GRBM_GUI_ACTIVE", 1) / 8), 3)}
+           "mfma_busy_fraction": round(med.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * med.get("GRBM_GUI_ACTIVE", 1) / 8), 3),
+           "lds_bank_conflict_share": round(med.get("SQ_LDS_BANK_CONFLICT", 0) / max(med.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3)}
     json.dump(out, open(fname, "w"), indent=1)
 PY
-cat gpurun_out/pmc_winograd.json gpurun_out/pmc_winograd44.json
+cat gpurun_out/pmc_winograd.json gpurun_out/pmc_winograd44.json gpurun_out/pmc_conv_s16.json
