@@ -47,6 +47,8 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _f32, _int, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "deqsci_ffdnet_head_sp16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_ffdnet_tail_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
@@ -611,6 +613,45 @@ class Split16Weights:
         self.packed = p.permute(3, 6, 0, 1, 4, 2, 5).contiguous()      # [c][tap][hl][g][kb][m][j]  (lane = 32 kb + m)
         self.out_scale_sp16 = 2.0 ** (-self.sw)                        # acc = 2^(8+sw) sum w x  ->  2^8 (sum w x): the next layer's sp16 scale
         self.out_scale_f32 = 2.0 ** (-self.sw) / SP16_ACT_SCALE
+
+
+class TailSplit16Weights:
+    """The last layer's (COUT,64,3,3) weight, COUT = 4 (FFDNet) or 1 (SimpleCNN), for the MFMA tail of csrc/conv_s16.hip: the taps go into
+    the matrix N dimension - column 32 nt + lane % 32 = COUT tap + cout - as two fp16 pieces of 2^sw w in the order
+    [cin chunk c (4)][piece (2)][N tile nt][lane (64)][j (8)], cin = 16 c + 8 (lane // 32) + j; columns >= 9 COUT are zero."""
+    __slots__ = ("packed", "cout", "out_scale")
+
+    def __init__(self, w):
+        cout = w.shape[0]
+        if tuple(w.shape) != (cout, 64, 3, 3) or cout not in (1, 4):
+            raise DeqsciHipError(f"split16 tail expects a (4,64,3,3) or (1,64,3,3) weight, got {tuple(w.shape)}")
+        import math
+        w = w.detach().float()
+        amax = float(w.abs().max())
+        sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        nt = (9 * cout + 31) // 32
+        cols = torch.zeros(32 * nt, 64, dtype=torch.float32, device=w.device)             # [col][cin]
+        cols[:9 * cout] = (w * 2.0 ** sw).permute(2, 3, 0, 1).reshape(9 * cout, 64)      # col = cout_count * tap + cout
+        hi = cols.half()
+        lo = (cols - hi.float()).half()
+        p = torch.stack((hi, lo), 0).reshape(2, nt, 32, 4, 2, 8)                         # [hl][nt][m][c][kb][j]
+        self.packed = p.permute(3, 0, 1, 4, 2, 5).contiguous()                           # [c][hl][nt][kb][m][j]  (lane = 32 kb + m)
+        self.cout = cout
+        self.out_scale = 2.0 ** (-sw) / SP16_ACT_SCALE
+
+
+def tail_split16(h, weights, out=None):
+    """h Sp16 -> the denoiser's last layer on the f16 matrix cores: COUT = 4: planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h, w, pad=1), 2)
+    (FFDNet); COUT = 1: (n,1,H,W) = conv3x3(h, w, pad=1) (SimpleCNN).  `weights` = TailSplit16Weights(w)."""
+    if not isinstance(h, Sp16) or not isinstance(weights, TailSplit16Weights):
+        raise DeqsciHipError("tail_split16: an Sp16 activation and TailSplit16Weights are required")
+    f = 2 if weights.cout == 4 else 1
+    o = out if out is not None else torch.empty((h.n, 1, f * h.H, f * h.W), device=h.t.device, dtype=torch.float32)
+    wp = weights.packed if weights.packed.device == h.t.device else weights.packed.to(h.t.device)
+    fn = load().deqsci_ffdnet_tail_split16 if weights.cout == 4 else load().deqsci_conv3x3_c64_to_1_split16
+    with _dev(h.t):
+        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, float(weights.out_scale), _stream()), "tail_split16")
+    return o
 
 
 def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=False, events=None):

@@ -332,6 +332,104 @@ __global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restric
     *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 2 + kb) * HW + p) * 16) = lo;
 }
 
+
+// ---- the denoisers' LAST layer on the same arithmetic: conv3x3 64 -> COUT (4: FFDNet, followed by its 2x2 pixel shuffle; 1: SimpleCNN), no bias,
+// reading the sp16 activation of the last 64->64 layer.  As a matrix product it is tiny in N, so the taps go INTO N:
+//     P[pixel q][col = 4 tap + cout] = sum_cin a[q][cin] w[tap][cin][cout]          one 32 x 32 x 16 f16 MFMA tile row per 32 pixels, K = 64 x 3 products
+//     out[pixel][cout]               = sum_tap P[pixel + (dy, dx)][4 tap + cout]      nine float4 reads of P from LDS per output pixel
+// The activation fragments go from global memory straight into the MFMA's A operand (a lane's 16 bytes of plane (c, hl, kb) ARE its
+// operand), the 36-column weight operands (16 KB as hi + lo) stay in registers for the whole workgroup, and the only LDS traffic is P.
+// The vector-ALU form of this layer (ffdnet_edges.hip: edge_tail_kernel) was bound by its scalar weight loads: 95-108 us at 64 images of
+// 128 x 128 against 45 us for reading its input once.
+constexpr int TL_H = 8, TL_W = 32, TL_IW = TL_W + 2, TL_IH = TL_H + 2, TL_PIX = TL_IH * TL_IW;      // 8 x 32 outputs, 10 x 34 = 340 halo pixels
+constexpr int TL_MB = (TL_PIX + 31) / 32;                                                      // 11 blocks of 32 halo pixels
+template <int COUT>
+__global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
+                                                       float oscale) {
+    constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
+    __shared__ __attribute__((aligned(16))) float P[TL_PIX * PS + 32 * 36];       // (+ slack: the last pixel block writes 352 rows)
+    const int n = blockIdx.z, r0 = blockIdx.y * TL_H, c0 = blockIdx.x * TL_W;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
+    const int64_t HW = (int64_t)H * W;
+    const char* xn = x + (int64_t)n * HW * 256;
+    // weight operands (B: column = lane % 32 of N tile nt, k block = lane / 32): [chunk][hl][nt][lane][8 halfs]
+    h8 Bw[4][2][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Bw[c][hl][nt] = *reinterpret_cast<const h8*>(Wp + ((((c * 2 + hl) * NT + nt) * 64 + lane) * 16));
+    // a wave's pixel blocks mb = wave, wave + 4, wave + 8.  (Requesting the NEXT block's fragments before multiplying the current one was
+    // measured: 74.0 vs 72.3 us - the extra 32 registers cost a workgroup per CU; three resident workgroups already overlap each other.)
+    auto fetch = [&](int mb, h8 (&A)[4][2]) __attribute__((always_inline)) {
+        const int q = 32 * mb + pl, row = q / TL_IW, col = q - row * TL_IW;
+        const int gr = r0 - 1 + row, gc = c0 - 1 + col;
+        const bool ok = mb < TL_MB && q < TL_PIX && gr >= 0 && gr < H && gc >= 0 && gc < W;
+        const char* px = xn + ((int64_t)kb * HW + (int64_t)gr * W + gc) * 16;   // plane (c, hl, kb): + (4 c + 2 hl) HW 16 bytes
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const h8*>(px + (int64_t)(4 * c + 2 * hl) * HW * 16);
+                A[c][hl] = v;
+            }
+    };
+    h8 A[4][2];
+#pragma unroll 1
+    for (int mb = wave; mb < TL_MB; mb += 4) {
+        fetch(mb, A);
+        f32x16 acc[NT], acs[NT];                               // hi x hi chain / cross-term chain (as in the 64 -> 64 kernel)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = acs[nt][i] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acs[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][1], Bw[c][0][nt], acs[nt], 0, 0, 0);
+                acs[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][1][nt], acs[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][0][nt], acc[nt], 0, 0, 0);
+            }
+        // D: row (pixel) 8 (i >> 2) + 4 kb + (i & 3) of the block, column pl of the N tile
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int colp = 32 * nt + pl;
+            if (colp < NCOL) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P[(32 * mb + 8 * (i >> 2) + 4 * kb + (i & 3)) * PS + colp] = (acc[nt][i] + acs[nt][i]) * oscale;
+            }
+        }
+    }
+    __syncthreads();
+    const int lr = (int)threadIdx.x / TL_W, lc = (int)threadIdx.x % TL_W, r = r0 + lr, cc = c0 + lc;
+    float o[COUT];
+#pragma unroll
+    for (int k = 0; k < COUT; ++k) o[k] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* pp = P + ((lr + tap / 3) * TL_IW + lc + tap % 3) * PS + COUT * tap;
+        if (COUT == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+            o[0] += v.x; o[COUT > 1 ? 1 : 0] += v.y; o[COUT > 2 ? 2 : 0] += v.z; o[COUT > 3 ? 3 : 0] += v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < COUT; ++k) o[k] += pp[k];
+        }
+    }
+    if (r < H && cc < W) {
+        if (COUT == 4) {        // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
+            float* op = out + (int64_t)n * 4 * HW + (int64_t)(2 * r) * (2 * W) + 2 * cc;
+            *reinterpret_cast<f32x2*>(op) = (f32x2){o[0], o[COUT > 1 ? 1 : 0]};
+            *reinterpret_cast<f32x2*>(op + 2 * W) = (f32x2){o[COUT > 2 ? 2 : 0], o[COUT > 3 ? 3 : 0]};
+        } else {
+            out[(int64_t)n * HW + (int64_t)r * W + cc] = o[0];
+        }
+    }
+}
+
 }  // namespace s16
 }  // namespace deqsci
 
@@ -381,4 +479,26 @@ extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t 
     hipLaunchKernelGGL(s16::f32_to_sp16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_nhwc,
                        static_cast<char*>(y_sp16), H * W, total, scale);
     return launch_status();
+}
+
+template <int COUT>
+static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+    if (!x_sp16 || !w_packed || !out) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
+    const dim3 grid((unsigned)ceil_div(W, s16::TL_W), (unsigned)ceil_div(H, s16::TL_H), (unsigned)n);
+    hipLaunchKernelGGL(s16::tail_s16_kernel<COUT>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
+                       static_cast<const char*>(w_packed), out, (int)H, (int)W, out_scale);
+    return launch_status();
+}
+
+extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                                          deqsci_stream_t stream) {
+    return tail_s16_impl<4>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+}
+
+extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                                               deqsci_stream_t stream) {
+    return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
 }

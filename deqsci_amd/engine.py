@@ -138,16 +138,19 @@ class _Denoiser:
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
+            self.tail_w16 = self.plain_tail_w16 = None
             if (not isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[0][0].is_cuda):
                 # SimpleCNN-style stacks: 1 -> 64 (+ReLU) and 64 -> 1 edge layers as HIP stencils (csrc/ffdnet_edges.hip)
                 if tuple(layers[0][0].shape) == (64, 1, 3, 3) and layers[0][1] is None:
                     self.plain_head_w = _hip.pack_c1_to_64_weights(layers[0][0])
                 if tuple(layers[-1][0].shape) == (1, 64, 3, 3) and layers[-1][1] is None and not layers[-1][2]:
                     self.plain_tail_w = _hip.pack_c64_to_1_weights(layers[-1][0])
+                    self.plain_tail_w16 = _hip.TailSplit16Weights(layers[-1][0])
             if (isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[-1][1] is None
                     and not layers[-1][2] and tuple(layers[-1][0].shape) == (4, 64, 3, 3) and layers[-1][0].is_cuda):
                 # last layer + upsamplefeatures as one HIP stencil kernel (csrc/ffdnet_edges.hip)
                 self.tail_w = _hip.pack_tail_weights(layers[-1][0])
+                self.tail_w16 = _hip.TailSplit16Weights(layers[-1][0])          # the same layer for an sp16 input (MFMA form)
                 if layers[0][1] is None and layers[0][2] and tuple(layers[0][0].shape) == (64, 5, 3, 3):
                     # concatenate_input_noise_map + first conv + ReLU likewise
                     self.head_w = _hip.pack_head_weights(layers[0][0])
@@ -227,9 +230,9 @@ class _Denoiser:
                     defer = self.fused_epilogue and self.fast[-2][1] is not None and self.fast[-2][2]
                     if defer:
                         raw, b = self._run_stack(h, skip_last=True, skip_first=first_done, defer_last_epilogue=True, native_out=sp)
-                        out = _hip.ffdnet_tail(raw, self.tail_w, in_bias=b)
                     else:
-                        out = _hip.ffdnet_tail(self._run_stack(h, skip_last=True, skip_first=first_done, native_out=sp), self.tail_w)
+                        raw, b = self._run_stack(h, skip_last=True, skip_first=first_done, native_out=sp), None
+                    out = _hip.tail_split16(raw, self.tail_w16) if isinstance(raw, _hip.Sp16) else _hip.ffdnet_tail(raw, self.tail_w, in_bias=b)
                 else:
                     out = F.pixel_shuffle(self._run_stack(h, skip_first=first_done), 2)
             else:
@@ -244,7 +247,8 @@ class _Denoiser:
                     h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp) if first else x
                     if self.plain_tail_w is not None:
                         h = self._run_stack(h, skip_first=first, skip_last=True, native_out=sp)
-                        out = _hip.conv3x3_c64_to_1(h if isinstance(h, _hip.Sp16) else h.contiguous(memory_format=torch.channels_last), self.plain_tail_w)
+                        out = (_hip.tail_split16(h, self.plain_tail_w16) if isinstance(h, _hip.Sp16) else
+                               _hip.conv3x3_c64_to_1(h.contiguous(memory_format=torch.channels_last), self.plain_tail_w))
                     else:
                         out = self._run_stack(h, skip_first=first)
                     return out.reshape(bsz, B, H, W), True

@@ -207,6 +207,13 @@ int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_
                                  deqsci_stream_t stream);
 int deqsci_conv3x3_c64_to_1_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
                                  deqsci_stream_t stream);
+/* The same last layers (conv3x3 64 -> 4 + pixel shuffle / 64 -> 1, no bias) on the f16 matrix cores with the split-fp16 arithmetic of
+ *     deqsci_conv3x3_c64_split16: the 9 taps ride in the matrix N dimension (column = COUT tap + cout), the per-tap products are summed from
+ *     LDS.  w_packed: 2^sw w as [4 chunks][2 pieces][N tiles][64 lanes][8 halfs]; out_scale = 2^-(8+sw). */
+int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                               deqsci_stream_t stream);
+int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                                    deqsci_stream_t stream);
 
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,

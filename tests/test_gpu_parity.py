@@ -446,6 +446,11 @@ def test_ffdnet_tail_kernel_vs_torch(shape):
     assert float((got_sp - got).norm() / got.norm()) < 3e-7
     with pytest.raises(_hip.DeqsciHipError):
         _hip.ffdnet_tail(_hip.to_split16(h), _hip.pack_tail_weights(w), in_bias=b)
+    # the matrix-core form of the layer on the sp16 input (taps in the N dimension, split-fp16 products): what the engine runs behind
+    # a stack of split-fp16 layers
+    got_mm = _hip.tail_split16(_hip.to_split16(h), _hip.TailSplit16Weights(w))
+    e_mm = float((got_mm.double() - want).norm() / want.norm())
+    assert got_mm.shape == got.shape and e_mm < 3e-7 and e_mm < 2 * e_ref + 1e-7, (e_mm, e_ref)
 
 
 @pytest.mark.parametrize("shape", [(3, 32, 64), (2, 26, 38), (1, 256, 256), (4, 16, 96), (130, 128, 128), (140, 100, 124), (64, 256, 256)])   # last three: the matrix-core variant (>= 512 tiles of 32 x 32), ragged and not
@@ -764,6 +769,8 @@ def test_plain_edge_kernels_vs_torch(shape):
     assert isinstance(sp, _hip.Sp16) and float((sp.to_nchw() - got).norm() / got.norm()) < 1e-7
     got2_sp = _hip.conv3x3_c64_to_1(_hip.to_split16(h), _hip.pack_c64_to_1_weights(w2))
     assert float((got2_sp.double() - want2).norm() / want2.norm()) < 1e-6 and float((got2_sp - got2).norm() / got2.norm()) < 3e-7
+    got2_mm = _hip.tail_split16(_hip.to_split16(h), _hip.TailSplit16Weights(w2))       # matrix-core form, COUT = 1
+    assert got2_mm.shape == (n, 1, H, W) and float((got2_mm.double() - want2).norm() / want2.norm()) < 3e-7
 
 
 @pytest.mark.parametrize("kind", ["SimpleCNN", "ffdnet"])

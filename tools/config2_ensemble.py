@@ -48,21 +48,20 @@ def main():
     a = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")))["measurements"]
     b = json.load(open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json")))["measurements"]
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
-    configs = {"F(4x4) conv wherever faster (conv64='fast')": {"kw": dict(conv64="fast")}, "F(2x2) conv (conv64='f22')": {"kw": dict(conv64="f22")},
-               "MIOpen direct conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}, "engine default (conv64='auto')": {}}
-    configs["split-fp16 direct conv (conv64='s16')"] = {"kw": dict(conv64="s16")}
-    for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID_S16", "").split(",") if v]:
-        configs[f"hybrid: F(2x2) for f-calls < {k}, then s16"] = {"kw": dict(conv64="s16"), "f22_calls": k}
+    configs = {"engine default: conv64='auto' = 'fast' (split-fp16 direct conv on the f16 matrix cores at this size)": {},
+               "conv64='fast32' (fp32 MFMA only: F(4x4,3x3) at this size)": {"kw": dict(conv64="fast32")},
+               "conv64='f22' (F(2x2,3x3) throughout)": {"kw": dict(conv64="f22")},
+               "MIOpen direct fp32 conv, BN not folded": {"kw": dict(winograd=False, fold_bn=False)}}
     for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID", "").split(",") if v]:
-        configs[f"hybrid: F(2x2) for f-calls < {k}, then fast"] = {"kw": dict(conv64="fast"), "f22_calls": k}
+        configs[f"conv64='fast32', first {k} f-calls on F(2x2,3x3)"] = {"kw": dict(conv64="fast32", conv64_f22_calls=k)}
+    for k in [int(v) for v in os.environ.get("DEQSCI_ENSEMBLE_HYBRID_S16", "").split(",") if v]:
+        configs[f"conv64='s16', first {k} f-calls on F(2x2,3x3)"] = {"kw": dict(conv64="s16", conv64_f22_calls=k)}
     res = {}
     if ONLY:
         configs = {k: v for k, v in configs.items() if any(o in k for o in ONLY.split(","))}
     for name, c in configs.items():
         _hip.FORCE_CONV64 = c.get("force")
         eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, **c.get("kw", {}))
-        if "f22_calls" in c:
-            eng.den.f22_calls = c["f22_calls"]
         res[name] = ensemble(eng)
         _hip.FORCE_CONV64 = None
     rows = {}
