@@ -302,6 +302,10 @@ def run_rank(args):
                                                            if eng.conv64_f22_calls else f"{eng.conv64} -> {eng.conv64_policy}"),
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU",
                    "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches"},
+        "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  64->64 conv layers under conv64 policy 'fast' (default): products on the f16 matrix "
+                       "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, two fp32 accumulation "
+                       "chains); rounding per layer against float64 on FFDNet's own data 1.6e-7 (fp32 Winograd F(2x2,3x3) 2.0e-7, MIOpen's fp32 direct "
+                       "convolution 3.5e-7: profiles/r03_conv_error_real.json).  other_conv64_policies gives the same step on fp32-MFMA kernels only."),
         "final_res": info.get("res"),
         "allgather_ms_per_step": 1e3 * gather_timer.total_seconds() / max(args.steps, 1) if world > 1 else 0.0,
         "allgather_bytes_per_step": world * per * H * W * B * 4 if world > 1 else 0,      # what every rank receives: (R*per,H,W,B) fp32

@@ -57,6 +57,9 @@ def parser():
     p.add_argument('--loadpath', default='')
     p.add_argument('--testpath', default="./data/test_gray/")
     p.add_argument('--inference', default='True')
+    p.add_argument('--conv64', default='auto', choices=['auto', 'fast', 'fast32', 'f22', 'f44', 's16'],
+                   help="(this build) kernel of the denoiser's 64->64 layers: auto = split-fp16 direct convolution on the f16 matrix cores / "
+                        "Winograd F(2x2,3x3), the faster per launch; fast32 = fp32 MFMA arithmetic only")
     p.add_argument('--batch_measurements', action='store_true',
                    help="(this build) a clip's measurements as ONE engine batch instead of the reference's one-by-one schedule; "
                         "implied by more than one --gpu_ids entry, which shards them")
@@ -79,6 +82,8 @@ def run(args):
     rank, world, _, dev = distributed.init_from_env("nccl")
     loadpath = args.loadpath or checkpoint.shipped(SHIPPED[args.denoiser])
     _, deq = build_pipeline(args.denoiser, loadpath, args.and_maxiters, args.and_m, args.and_beta, device=dev)
+    if args.conv64 != 'auto':
+        deq.engine_options = {"conv64": args.conv64}
     if rank == 0:
         print('loaded dict!')
         os.makedirs(args.savepath, exist_ok=True)

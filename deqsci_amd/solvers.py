@@ -169,6 +169,7 @@ class DEQFixedPoint(nn.Module):
         self.kwargs = kwargs
         self.forward_res = None
         self.use_engine = True
+        self.engine_options = {}          # extra DEQSCIEngine arguments of this build, e.g. {"conv64": "fast32"} (fp32-MFMA kernels only)
         self._engine = None
 
     def _engine_for(self):
@@ -187,9 +188,9 @@ class DEQFixedPoint(nn.Module):
             return None
         if kw:
             raise TypeError(f"{self.solver.__name__}() got an unexpected keyword argument '{next(iter(kw))}'")
-        key = (id(f.nonlinear_op), f.nonlinear_op.training, tuple(sorted(cfg.items())))
+        key = (id(f.nonlinear_op), f.nonlinear_op.training, tuple(sorted(cfg.items())), tuple(sorted(self.engine_options.items())))
         if self._engine is None or self._engine[0] != key:
-            self._engine = (key, DEQSCIEngine(f.nonlinear_op, **cfg))
+            self._engine = (key, DEQSCIEngine(f.nonlinear_op, **cfg, **self.engine_options))
         return self._engine[1]
 
     def forward(self, x, Phi, Phi_sum, initial_point=None, train_flag=True):
