@@ -364,7 +364,18 @@ class DEQSCIEngine:
         r = ws.host_res[res_row]
         self.last_info = {"res": float(r[0]), "res_per_sample": r[1:].tolist(), "iterations": last,
                           "f_calls": call, "iterator": self.iterator, "graph": False}
+        self._warn_if_not_finite()
         return rec
+
+    def _warn_if_not_finite(self):
+        """A non-finite residual is what an fp16 overflow inside the split-fp16 layers (activations beyond |x| = 255.9: csrc/conv_s16.hip keeps
+        it inf / NaN all the way to the output on purpose) looks like from here - as does a genuinely diverging run.  Say so, loudly."""
+        import math
+        import warnings
+        if not math.isfinite(self.last_info["res"]) and self.conv64_policy in ("fast", "s16"):
+            warnings.warn("DEQSCIEngine: the reconstruction's residual is not finite.  If the iteration itself is not diverging, an activation of "
+                          "the denoiser has left fp16's range inside the split-fp16 64->64 layers (|x| >= 255.9; inputs are expected in [0, 1]): "
+                          "rerun with conv64='fast32' (fp32 MFMA kernels, no such limit).", RuntimeWarning, stacklevel=3)
 
     def _enqueue(self, ws, y, Phi4, Phi_sum, initial_point, poll):
         """Every launch of one reconstruction on the current stream.  poll: True = lagged residual read-back with early stop,
@@ -431,6 +442,7 @@ class DEQSCIEngine:
         r = ws.host_res[g["res_row"]]
         self.last_info = {"res": float(r[0]), "res_per_sample": r[1:].tolist(), "iterations": g["last"],
                           "f_calls": g["call"], "iterator": self.iterator, "graph": True}
+        self._warn_if_not_finite()
         return rec
 
     # ------------------------------------------------------------------ Anderson (new_equilibrium_utils_yaping.py:153-189)

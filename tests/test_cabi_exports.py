@@ -64,6 +64,18 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 0, 16, 16, 1, None) == -2
     assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 2, 0, None, None, None) == -4   # unknown layout
     assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 1, 1, None, p16, None) == -1   # one event only
+    # the split-fp16 convolution and its edge layers: the same contract
+    assert lib.deqsci_conv3x3_c64_split16(None, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -1
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, p16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -4      # in place
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 2, None, None, None) == -4      # unknown output form
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 2900, 2900, 1, 1.0, 1.0, 0, None, None, None) == -4  # 32-bit offsets / OOB sentinel
+    assert lib.deqsci_conv3x3_c64_split16(p16 + 4, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -3
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 0, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -2
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, p16, None) == -1       # one event only
+    assert lib.deqsci_f32_to_split16(None, q16, 1, 4, 4, 256.0, None) == -1 and lib.deqsci_f32_to_split16(p16, q16, 1, 0, 4, 256.0, None) == -2
+    assert lib.deqsci_ffdnet_tail_split16(None, p16, q16, 1, 4, 4, 1.0, None) == -1 and lib.deqsci_ffdnet_tail_split16(p16, p16, q16, 1, 4, -4, 1.0, None) == -2
+    assert lib.deqsci_conv3x3_c64_to_1_split16(p16 + 4, p16, q16, 1, 4, 4, 1.0, None) == -3
+    assert lib.deqsci_ffdnet_head_sp16(None, p16, p16, 0, q16, 1, 4, 4, None) == -1 and lib.deqsci_ffdnet_tail_sp16(None, p16, q16, 1, 4, 4, None) == -1
 
 
 def test_shipped_library_reads_no_environment():
@@ -77,7 +89,9 @@ def test_shipped_library_reads_no_environment():
         assert name not in blob, name
     undefined = subprocess.run(["nm", "-D", "--undefined-only", _hip.lib_path()], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in undefined
-    for src in ("anderson.hip", "common.hpp", "ffdnet_edges.hip", "sci_ops.hip", "winograd.hip", "winograd44.hip", "epilogue.hip"):
+    csrc = sorted(f for f in os.listdir(os.path.join(ROOT, "deqsci_amd", "csrc")) if f.endswith((".hip", ".hpp")))
+    assert "conv_s16.hip" in csrc and "winograd44.hip" in csrc and len(csrc) >= 8
+    for src in csrc:
         text = open(os.path.join(ROOT, "deqsci_amd", "csrc", src)).read()
         outside = "".join(seg.split("#endif", 1)[-1] if i else seg for i, seg in enumerate(text.split("#ifdef DEQSCI_DIAG")))
         assert "getenv" not in outside and "static const" not in outside.replace("static constexpr", ""), src

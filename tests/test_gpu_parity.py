@@ -719,6 +719,24 @@ def test_split16_conv64_vs_torch(shape):
         _hip.conv3x3_c64_split16(xs, _hip.pack_winograd_weights(ws[0]), bs[0], True)
 
 
+def test_engine_warns_when_split16_overflows():
+    """The engine end of the same promise: measurements 255x too large (the classic forgotten /255) push FFDNet's activations beyond fp16's
+    range inside the split-fp16 layers; the reconstruction comes back non-finite and the engine says why - and conv64='fast32' has no limit."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = (d["meas"][None, ..., 0] * 2000.0).contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 6)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    with pytest.warns(RuntimeWarning, match="fp16's range"):
+        rec = eng.reconstruct(y, Phi)
+    assert not bool(torch.isfinite(rec).all())
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        rec32 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="fast32").reconstruct(y, Phi)
+    assert bool(torch.isfinite(rec32).all())
+
+
 def test_split16_overflow_is_loud():
     """Activations beyond fp16's range (2^8 |y| >= 65504) must surface as inf / NaN at the END of a stack of layers, never as a wrong
     finite number: the overflowing layer writes inf pieces, the next layer's accumulators become inf / NaN, and the ReLU of this
