@@ -719,6 +719,33 @@ def test_split16_conv64_vs_torch(shape):
         _hip.conv3x3_c64_split16(xs, _hip.pack_winograd_weights(ws[0]), bs[0], True)
 
 
+@pytest.mark.parametrize("kind,weights", [("ffdnet", "ffdnet_gray"), ("SimpleCNN", "cnn")])
+def test_engine_split16_on_ragged_sizes(kind, weights):
+    """The whole split-fp16 path of the engine (head -> sp16 -> 64->64 layers -> matrix-core tail) forced at sizes where every kernel's
+    tiles stick out of the image (frames of 100 x 76: FFDNet's half-resolution planes are 50 x 38, neither a multiple of 16 nor 32),
+    against the same engine on the fp32 Winograd F(2x2,3x3) kernels and against the CPU oracle."""
+    g = torch.Generator().manual_seed(31)
+    H, W, B = 100, 76, 8
+    Phi = (torch.rand(2, H, W, B, generator=g) < 0.5).float()
+    x = torch.rand(2, H, W, B, generator=g)
+    y = orc.sci_forward(x, Phi)
+    net = build_pipeline(kind, checkpoint.shipped(weights), 6)[0].nonlinear_op
+    seen = []
+    _hip.CONV64_EVENT_HOOK = lambda k, n, h, w: seen.append((k, n, h, w))
+    try:
+        a = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="s16").reconstruct(G(y), G(Phi))
+        assert {k for k, *_ in seen} == {"s16"} and seen[0][1:] == ((16, 50, 38) if kind == "ffdnet" else (16, 100, 76))
+        del seen[:]
+        b = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="f22").reconstruct(G(y), G(Phi))
+        assert {k for k, *_ in seen} == {"f22"}
+    finally:
+        _hip.CONV64_EVENT_HOOK = None
+    assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
+    Ps = orc.phi_sum(Phi)
+    want, _ = orc.deq_forward(orc.ProxGradSCI(kind), orc.andersonexp, y, Phi, Ps, orc.initial_point(y, Phi), m=5, beta=1.0, lam=1e-2, max_iter=6, tol=1e-5)
+    assert rel_l2(a.cpu().numpy(), want.numpy()) < 1e-4
+
+
 def test_engine_warns_when_split16_overflows():
     """The engine end of the same promise: measurements 255x too large (the classic forgotten /255) push FFDNet's activations beyond fp16's
     range inside the split-fp16 layers; the reconstruction comes back non-finite and the engine says why - and conv64='fast32' has no limit."""
