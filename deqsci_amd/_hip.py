@@ -48,6 +48,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _f32, _int, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
+    "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
     "deqsci_ffdnet_head_sp16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "deqsci_ffdnet_tail_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
@@ -638,6 +639,45 @@ class TailSplit16Weights:
         self.packed = p.permute(3, 0, 1, 4, 2, 5).contiguous()                           # [c][hl][nt][kb][m][j]  (lane = 32 kb + m)
         self.cout = cout
         self.out_scale = 2.0 ** (-sw) / SP16_ACT_SCALE
+
+
+class HeadSplit16Weights:
+    """FFDNet's first-layer (64,5,3,3) weight for the MFMA head of csrc/conv_s16.hip: two fp16 pieces of 2^sw w as
+    [k step (3)][piece (2)][cout group g (2)][lane (64)][j (8)], cout = 32 g + lane % 32, k = 16 ks + 8 (lane // 32) + j = 9 ch + tap
+    (k >= 45: zero)."""
+    __slots__ = ("packed", "out_scale")
+
+    def __init__(self, w):
+        if tuple(w.shape) != (64, 5, 3, 3):
+            raise DeqsciHipError(f"split16 head expects a (64,5,3,3) weight, got {tuple(w.shape)}")
+        import math
+        w = w.detach().float()
+        amax = float(w.abs().max())
+        sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        wk = torch.zeros(64, 48, dtype=torch.float32, device=w.device)
+        wk[:, :45] = (w * 2.0 ** sw).reshape(64, 45)                                    # k = 9 ch + tap
+        hi = wk.half()
+        lo = (wk - hi.float()).half()
+        p = torch.stack((hi, lo), 0).reshape(2, 2, 32, 3, 2, 8)                           # [hl][g][m][ks][kb][j]
+        self.packed = p.permute(3, 0, 1, 4, 2, 5).contiguous()                           # [ks][hl][g][kb][m][j]
+        self.out_scale = 2.0 ** (-sw)          # acc = 2^(8+sw) y  ->  the sp16 output holds 2^8 y
+
+
+def ffdnet_head_split16(x, weights, sigma, out=None):
+    """x (n,1,2H,2W) planar, sigma (n,) or (1,) -> relu(conv3x3(cat(sigma map, pixel_unshuffle(x,2)), w)) as an Sp16, on the f16 matrix
+    cores with the split-fp16 arithmetic (`weights` = HeadSplit16Weights(w))."""
+    n, c, H2, W2 = x.shape
+    if c != 1 or H2 % 2 or W2 % 2 or not isinstance(weights, HeadSplit16Weights):
+        raise DeqsciHipError(f"ffdnet_head_split16: (n,1,even,even) image and HeadSplit16Weights required, got {tuple(x.shape)}")
+    if sigma.numel() not in (1, n) or sigma.dtype != torch.float32 or not sigma.is_cuda:
+        raise DeqsciHipError("ffdnet_head_split16: sigma must be a fp32 GPU tensor with 1 or n elements")
+    H, W = H2 // 2, W2 // 2
+    o = out if out is not None else Sp16.empty(n, H, W, x.device)
+    wp = weights.packed if weights.packed.device == x.device else weights.packed.to(x.device)
+    with _dev(x):
+        _check(load().deqsci_ffdnet_head_split16(_p(x, "x"), wp.data_ptr(), sigma.data_ptr(), 0 if sigma.numel() == 1 else sigma.stride(0),
+                                                 o.t.data_ptr(), n, H, W, float(weights.out_scale), _stream()), "ffdnet_head_split16")
+    return o
 
 
 def tail_split16(h, weights, out=None):

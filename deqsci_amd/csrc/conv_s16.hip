@@ -57,6 +57,7 @@ constexpr int RAW_BUF = WAVES * RAW_INSTR * 1024;              // 40960 bytes
 constexpr int W_CHUNK = 9 * 2 * 2 * 1024;                      // 36864 bytes: [tap][hl][cout group][lane][8 halfs]
 constexpr uint32_t RAW_BIAS = 4096;                            // the descriptor starts this far below the image (see set_fetch_tile)
 constexpr uint32_t RAW_OOB = 0x80000000u;                      // beyond num_records: the hardware writes zeros
+constexpr float SP_SCALE = 256.0f;                             // sp16 activations hold 2^8 x
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -430,6 +431,130 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
     }
 }
 
+
+// ---- FFDNet's FIRST layer on the same arithmetic, writing sp16: concatenate_input_noise_map (functions.py:16-53: sigma map + 2x2
+// pixel-unshuffle, channel 2i+j) + conv3x3(5 -> 64, pad 1, no bias) + ReLU.  K = 5 channels x 9 taps = 45 (padded to 48 = three MFMA k
+// steps); the B operand (k x 32 positions) is GATHERED: lane (position, k block) reads its eight taps from the full-resolution patch /
+// the sigma plane in LDS, multiplies by 2^8 and splits them into hi + lo fp16 on the fly; the weight operands (12 fragments) stay in
+// registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
+constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
+__global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
+                                                       int sigma_stride, char* __restrict__ y, int H, int W, float oscale) {
+    __shared__ __attribute__((aligned(16))) float patch[HS_P * HS_QS + (HS_H + 2) * HS_SS];
+    constexpr int SGM = HS_P * HS_QS;
+    const int n = blockIdx.z, r0 = blockIdx.y * HS_H, c0 = blockIdx.x * HS_W;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* xn = x + (int64_t)n * H2 * W2;
+    // full-resolution pixels (2 r0 - 2 + pr, 2 c0 - 2 + pc): half-res position (r, c), sub-pixel (i, j), tap (dy, dx) reads
+    // (2 (r + dy - 1) + i, 2 (c + dx - 1) + j); zero outside the image = the conv's zero padding of the unshuffled channels
+    for (int e = threadIdx.x; e < HS_P * HS_Q; e += 256) {
+        const int pr = e / HS_Q, pc = e - pr * HS_Q;
+        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
+        patch[pr * HS_QS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
+    }
+    const float sig = sigma[(int64_t)n * sigma_stride];
+    for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
+        const int pr = e / HS_SW, pc = e - pr * HS_SW;
+        const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
+        patch[SGM + pr * HS_SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+    }
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
+    // this lane's 24 taps: k = 16 ks + 8 kb + j = 9 ch + tap (k >= 45: zero weight, any address): LDS float offset relative to the
+    // position's patch origin (2 lr, 2 lc) / sigma origin (lr, lc)
+    int off[3][8];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * kb + j, kk = k < 45 ? k : 0;
+            const int ch = kk / 9, tap = kk - 9 * ch, dy = tap / 3, dx = tap - 3 * dy;
+            off[ks][j] = ch == 0 ? SGM + dy * HS_SS + dx + pl : (2 * dy + ((ch - 1) >> 1)) * HS_QS + 2 * dx + ((ch - 1) & 1) + 2 * pl;
+        }
+    h8 Aw[3][2][2];                                            // weights: [k step][hi, lo][cout group]
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) Aw[ks][hl][g] = *reinterpret_cast<const h8*>(Wp + ((((ks * 2 + hl) * 2 + g) * 64 + lane) * 16));
+    __syncthreads();
+    const int64_t HW = (int64_t)H * W;
+    i32x4 orsrc;
+    {
+        const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
+        orsrc.x = (int)uniform((uint32_t)ob);
+        orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+        orsrc.z = (int)uniform((uint32_t)(HW * 256));
+        orsrc.w = 0x00020000;
+    }
+#pragma unroll 1
+    for (int lr = wave; lr < HS_H; lr += 4) {
+        const int sbase = lr * HS_SS, pbase = 2 * lr * HS_QS;
+        h8 Bh[3], Bl[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            f32x2 v[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * kb + j;
+                const bool is_sigma = (k < 45 ? k : 0) < 9;      // (sigma taps live in their own plane; per lane: k depends on its k block)
+                v[j >> 1][j & 1] = patch[off[ks][j] + (is_sigma ? sbase : pbase)] * SP_SCALE;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const h2 hh = __builtin_convertvector(v[e], h2);
+                const h2 ll = __builtin_convertvector(v[e] - __builtin_convertvector(hh, f32x2), h2);
+                Bh[ks][2 * e] = hh.x; Bh[ks][2 * e + 1] = hh.y;
+                Bl[ks][2 * e] = ll.x; Bl[ks][2 * e + 1] = ll.y;
+            }
+        }
+        f32x16 acc[2], acs[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[g][i] = acs[g][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                acs[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][1][g], Bh[ks], acs[g], 0, 0, 0);
+                acs[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bl[ks], acs[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bh[ks], acc[g], 0, 0, 0);
+            }
+        // D[g][i]: cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of position (r0 + lr, c0 + pl): ReLU, x 2^8, split, lane exchange, sp16 stores
+        const int r = r0 + lr, c = c0 + pl;
+        const uint32_t pix = (r < H && c < W) ? (uint32_t)((kb * (int)HW + r * W + c) * 16) : RAW_OOB;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
+                    f32x2 t = ((f32x2){acc[g][i], acc[g][i + 1]} + (f32x2){acs[g][i], acs[g][i + 1]}) * (f32x2){oscale, oscale};
+                    t.x = __builtin_elementwise_maximum(t.x, 0.0f);
+                    t.y = __builtin_elementwise_maximum(t.y, 0.0f);
+                    const h2 hh = __builtin_convertvector(t, h2);
+                    hi[e] = __builtin_bit_cast(unsigned, hh);
+                    lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t - __builtin_convertvector(hh, f32x2), h2));
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
+                    hi[e] = sh[0]; hi[2 + e] = sh[1];
+                    auto sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
+                    lo[e] = sl[0]; lo[2 + e] = sl[1];
+                }
+                const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
+                const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
+                const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(oh), "v"(pix), "s"(orsrc), "s"(so_h) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
+            }
+    }
+}
+
 }  // namespace s16
 }  // namespace deqsci
 
@@ -501,4 +626,16 @@ extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_pack
 extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
                                                deqsci_stream_t stream) {
     return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+}
+
+extern "C" int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
+                                          int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+    if (!x || !w_packed || !sigma || !h_sp16) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || H * W * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(w_packed) || !aligned16(h_sp16)) return DEQSCI_ERR_ALIGN;
+    const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
+    hipLaunchKernelGGL(s16::head_s16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                       (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, out_scale);
+    return launch_status();
 }

@@ -138,7 +138,7 @@ class _Denoiser:
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
-            self.tail_w16 = self.plain_tail_w16 = None
+            self.tail_w16 = self.plain_tail_w16 = self.head_w16 = None
             if (not isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[0][0].is_cuda):
                 # SimpleCNN-style stacks: 1 -> 64 (+ReLU) and 64 -> 1 edge layers as HIP stencils (csrc/ffdnet_edges.hip)
                 if tuple(layers[0][0].shape) == (64, 1, 3, 3) and layers[0][1] is None:
@@ -154,6 +154,7 @@ class _Denoiser:
                 if layers[0][1] is None and layers[0][2] and tuple(layers[0][0].shape) == (64, 5, 3, 3):
                     # concatenate_input_noise_map + first conv + ReLU likewise
                     self.head_w = _hip.pack_head_weights(layers[0][0])
+                    self.head_w16 = _hip.HeadSplit16Weights(layers[0][0])        # the same layer writing sp16 (f16 matrix-core form)
 
     def _run_stack(self, h, skip_last=False, skip_first=False, defer_last_epilogue=False, native_out=False):
         """defer_last_epilogue: leave the bias+ReLU of the last executed layer to the consumer (the fused
@@ -222,7 +223,8 @@ class _Denoiser:
                 sp = (x.is_cuda and self.head_w is not None and self.tail_w is not None and all(u is not None for u in self.wino[1:-1])
                       and _hip.conv64_kernel_for(bsz * B, H // 2, W // 2, x.device, self._policy) == "s16")
                 if self.head_w is not None and x.is_cuda:
-                    h, first_done = _hip.ffdnet_head(x, self.head_w, self.sigma_table[call:call + 1], sp16=sp), True
+                    sg = self.sigma_table[call:call + 1]
+                    h, first_done = (_hip.ffdnet_head_split16(x, self.head_w16, sg) if sp else _hip.ffdnet_head(x, self.head_w, sg)), True
                 else:
                     h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
                     first_done = False

@@ -212,6 +212,11 @@ int deqsci_conv3x3_c64_to_1_sp16(const void* h_sp16, const float* w_packed, floa
  *     LDS.  w_packed: 2^sw w as [4 chunks][2 pieces][N tiles][64 lanes][8 halfs]; out_scale = 2^-(8+sw). */
 int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
                                deqsci_stream_t stream);
+/* FFDNet's first layer (sigma map + pixel-unshuffle + conv3x3 5 -> 64 + ReLU) likewise, writing sp16: K = 45 taps padded to 48, the
+ *     activation operand gathered from the image and split on the fly.  w_packed: 2^sw w as [3 k steps][2 pieces][2 cout groups][64 lanes]
+ *     [8 halfs], k = 9 ch + tap; out_scale = 2^-sw (the 2^8 of the input split carries over to the sp16 output). */
+int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
+                               int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream);
 int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
                                     deqsci_stream_t stream);
 

@@ -480,6 +480,12 @@ def test_ffdnet_head_kernel_vs_torch(shape):
         assert got_sp is sp and bool(torch.isfinite(sp.t).all())
         back = sp.to_nchw()
         assert float((back - got).abs().max()) <= 2.0 ** -21 * float(got.abs().max()) and float((back - got).norm() / got.norm()) < 1e-7
+        # the matrix-core form on the f16 pipes (input taps split into hi + lo on the fly): what the engine runs in front of split-fp16 layers
+        sp.t.fill_(float("nan"))
+        got_mm = _hip.ffdnet_head_split16(x, _hip.HeadSplit16Weights(w), sig, out=sp)
+        assert got_mm is sp and bool(torch.isfinite(sp.t).all())
+        e_mm = float((sp.to_nchw().double() - want).norm() / want.norm())
+        assert e_mm < 3e-7 and e_mm < 2 * e_ref + 1e-7, (e_mm, e_ref)
 
 
 class _Affine(torch.nn.Module):
