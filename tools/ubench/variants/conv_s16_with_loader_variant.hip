@@ -284,10 +284,6 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // (A "loader + 4" form - four compute waves, one per SIMD, each 4 pixel rows x 64 couts, and a fifth wave issuing all 76 DMA
-    // instructions of a stage: 40 % less LDS operand traffic, no compute wave ever at the memory pipeline's door - was built and measured
-    // (tools/ubench/variants/conv_s16_with_loader_variant.hip, -DS16_V2): 212 us against 193 us.  Five waves put two on one SIMD, so the
-    // register budget stays 256 and only one accumulation chain fits; and a wave alone on its SIMD has nobody to cover its stalls.)
     // (Spreading a tile's epilogue over the MFMA stream of the next tile - a second accumulator set, one piece behind every other group -
     // was built and measured: 192 us against 187 us at 64 x 128 x 128.  On random data this kernel runs against the chip's POWER limit
     // (1.87-1.97 GHz instead of 2.4; all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles.)
@@ -311,6 +307,216 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             const Done d = tile_done(t_cur);
 #pragma unroll
             for (int k = 0; k < 8; ++k) ep_piece(S0, d, k);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- variant "loader + 4" (S16_V2; measured against the kernel above in profiles/r03_s16_ablations.jsonl): FOUR compute waves, one per SIMD, each
+// owning 4 pixel rows x 64 couts (256 accumulator registers with the two chains: a wave alone on its SIMD may use all 512), and a FIFTH wave
+// that does nothing but issue the stage's 76 LDS-DMA instructions.  LDS operand traffic per stage drops from 8 x (36 + 24) KB to 4 x (36 + 36) KB
+// and no compute wave ever stands at the memory pipeline's door; the price is that nothing covers a compute wave's own stalls.
+#ifndef S16_V2_CHAINS
+#define S16_V2_CHAINS 1
+#endif
+constexpr int V2_ROWS = 4, V2_CW = OUT_ROWS / V2_ROWS, V2_TBW = 64 * (V2_CW + 1), V2_NCH = S16_V2_CHAINS, V2_X = V2_NCH - 1;
+template <int OUT_F32>
+__global__ __launch_bounds__(V2_TBW, 1) void conv_s16_loader_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
+                                                                   char* __restrict__ y, int H, int W, int relu, float oscale, float bscale, int tiles_x,
+                                                                   int tiles_y, int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+    __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
+    __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
+    int t_first, t_step, t_end;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((nb & 7) == 0) {
+            const int per_xcd = (n_tiles + 7) >> 3;
+            t_first = (b & 7) * per_xcd + (b >> 3);
+            t_step = nb >> 3;
+            t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
+        } else { t_first = b; t_step = nb; t_end = n_tiles; }
+    }
+    if (t_first >= t_end) return;
+    const int64_t HW = (int64_t)H * W;
+    const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;
+
+    if (wave == V2_CW) {
+        // ================= the loader wave: per stage 40 halo-tile instructions + 36 weight instructions, then wait, then the barrier
+        auto fetch = [&](int t, int c, int buf) __attribute__((always_inline)) {
+            const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+            const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+            const uint64_t base = (uint64_t)(x + (int64_t)n * HW * 256) - RAW_BIAS;
+            i32x4 rsrc;
+            rsrc.x = (int)uniform((uint32_t)base);
+            rsrc.y = (int)uniform((uint32_t)(base >> 32));
+            rsrc.z = (int)uniform((uint32_t)(HW * 256) + RAW_BIAS);
+            rsrc.w = 0x00020000;
+            const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;
+            const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);
+#pragma unroll 1
+            for (int i4 = 0; i4 < 10; ++i4) {                  // 10 groups of 4 instructions sharing one M0 (immediate offsets 0..3072)
+                uint32_t vo[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = 64 * (4 * i4 + j) + lane;
+                    const int p = (s * 857) >> 19;
+                    const int q = s - p * RAW_PIX;
+                    const int row = (q * 1928) >> 16, col = q - row * RAW_COLS;
+                    const int iy = py0 + row, ix = px0 + col;
+                    const bool ok = s < RAW_SLOTS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                    vo[j] = ok ? (uint32_t)(p * (int)HW + iy * W + ix) * 16u + (RAW_BIAS - 1024u * j) : RAW_OOB;
+                }
+                const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + i4 * 4096));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %6 offen lds\n\tbuffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
+                             "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\tbuffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds"
+                             ::"s"(m0v), "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "s"(rsrc), "s"(soff) : "m0", "memory");
+            }
+            const uint64_t g = (uint64_t)(Wp + (int64_t)c * W_CHUNK);
+            const uint64_t gs = ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
+#pragma unroll 1
+            for (int i4 = 0; i4 < 9; ++i4) {                   // 36 KiB of weights: 9 groups of 4 KiB
+                const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_CHUNK + i4 * 4096));
+                const uint32_t lv = (uint32_t)(i4 * 4096 + lane * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                             "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
+                             ::"s"(m0v), "v"(lv), "s"(gs) : "m0", "memory");
+            }
+        };
+        fetch(t_first, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll 1
+        for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                const bool next = t_cur + t_step < t_end;
+                if (c < 3) fetch(t_cur, c + 1, (c + 1) & 1);
+                else if (next) fetch(t_cur + t_step, 0, 0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_barrier();
+            }
+        }
+        return;
+    }
+
+    // ================= compute waves: rows 4 wave .. 4 wave + 3
+    f32x16 acc[V2_NCH][2][V2_ROWS];
+    const int pl = lane & 31, kb = lane >> 5;
+    const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (V2_ROWS * wave * RAW_COLS + pl) * 16;
+    const lds_char* abase = (const lds_char*)Wt + lane * 16;
+    auto stage = [&](int c) __attribute__((always_inline)) {
+        const int buf = c & 1;
+        const lds_char* bb = bbase + buf * RAW_BUF;
+        const lds_char* ab = abase + buf * W_CHUNK;
+        h8 Ah[3], Al[3], Bh[2][V2_ROWS + 2], Bl[2][V2_ROWS + 2];
+        auto loads = [&](int i) __attribute__((always_inline)) {
+            if (i >= 18) return;
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1, tap = dy * 3 + dx;
+            Ah[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 0) * 2 + g) * 1024);
+            Al[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 1) * 2 + g) * 1024);
+            if (g == 0) {
+#pragma unroll
+                for (int rr = (dy == 0 ? 0 : dy + V2_ROWS - 1); rr <= dy + V2_ROWS - 1; ++rr) {
+                    Bh[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + (rr * RAW_COLS + dx) * 16);
+                    Bl[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + 2 * PLANE_B + (rr * RAW_COLS + dx) * 16);
+                }
+            }
+        };
+        loads(0);
+        loads(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1;
+            loads(i + 2);
+#pragma unroll
+            for (int r = 0; r < V2_ROWS; ++r) acc[V2_X][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[V2_X][g][r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < V2_ROWS; ++r) acc[V2_X][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[V2_X][g][r], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < V2_ROWS; ++r) acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_barrier();
+    };
+    __syncthreads();
+#pragma unroll 1
+    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+#pragma unroll
+        for (int ch = 0; ch < V2_NCH; ++ch)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < V2_ROWS; ++r)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[ch][g][r][i] = 0.0f;
+        stage(0); stage(1); stage(2); stage(3);
+        // epilogue (as above), rows 4 wave + r
+        const int n = mdiv(t_cur, mg_img, sh_img), rr_ = t_cur - n * (tiles_x * tiles_y);
+        const int by = mdiv(rr_, mg_tx, sh_tx), bx = rr_ - by * tiles_x;
+        const int ox = OUT_COLS * bx + pl;
+        i32x4 orsrc;
+        {
+            const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
+            orsrc.x = (int)uniform((uint32_t)ob);
+            orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+            orsrc.z = (int)uniform((uint32_t)(HW * 256));
+            orsrc.w = 0x00020000;
+        }
+        const float floor_ = relu ? 0.0f : -__builtin_inff();
+#pragma unroll
+        for (int r = 0; r < V2_ROWS; ++r) {
+            const int oy = OUT_ROWS * by + V2_ROWS * wave + r;
+            const bool ok = oy < H && ox < W;
+            const uint32_t pix = !ok ? RAW_OOB : OUT_F32 ? (uint32_t)((oy * W + ox) * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + oy * W + ox) * 16);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    f32x2 v2[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
+                        const f32x2 a0 = {acc[0][g][r][i], acc[0][g][r][i + 1]}, a1 = V2_NCH > 1 ? (f32x2){acc[V2_X][g][r][i], acc[V2_X][g][r][i + 1]} : (f32x2){0.0f, 0.0f};
+                        const f32x2 bz = *reinterpret_cast<const f32x2*>(bias_s + 32 * g + 8 * (2 * gp + (e >> 1)) + 4 * kb + 2 * (e & 1));
+                        f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
+                        t.x = __builtin_elementwise_maximum(t.x, floor_);
+                        t.y = __builtin_elementwise_maximum(t.y, floor_);
+                        v2[e] = t;
+                    }
+                    if (OUT_F32) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const f32x4 o = {v2[2 * q].x, v2[2 * q].y, v2[2 * q + 1].x, v2[2 * q + 1].y};
+                            const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
+                            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(o), "v"(pix), "s"(orsrc), "s"(so) : "memory");
+                        }
+                    } else {
+                        unsigned hi[4], lo[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const h2 hh = __builtin_convertvector(v2[e], h2);
+                            hi[e] = __builtin_bit_cast(unsigned, hh);
+                            lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(v2[e] - __builtin_convertvector(hh, f32x2), h2));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            auto sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
+                            hi[e] = sh[0]; hi[2 + e] = sh[1];
+                            auto sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
+                            lo[e] = sl[0]; lo[2 + e] = sl[1];
+                        }
+                        const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
+                        const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
+                        const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(oh), "v"(pix), "s"(orsrc), "s"(so_h) : "memory");
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
+                    }
+                }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -595,7 +801,16 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
                           bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, bias_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img,    \
                           sh_img, \
                           mg_tx, sh_tx)
+#ifdef S16_V2
+#define S16_LAUNCH2(KERNEL)                                                                                                                 \
+    hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::V2_TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
+                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, bias_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img,    \
+                          sh_img, mg_tx, sh_tx)
+    if (out_f32) S16_LAUNCH2((s16::conv_s16_loader_kernel<1>)); else S16_LAUNCH2((s16::conv_s16_loader_kernel<0>));
+#undef S16_LAUNCH2
+#else
     if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1>)); else S16_LAUNCH((s16::conv_s16_kernel<0>));
+#endif
 #undef S16_LAUNCH
     return launch_status();
 }
