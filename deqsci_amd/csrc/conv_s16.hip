@@ -30,6 +30,14 @@
 #include <type_traits>
 #pragma clang diagnostic ignored "-Winline-asm"
 
+#ifndef S16_RAW_NT
+#define S16_RAW_NT 0  // 1: the halo-tile DMA with the non-temporal hint (A/B: tools/s16_variants.sh)
+#endif
+#if S16_RAW_NT
+#define S16_NT " nt"
+#else
+#define S16_NT ""
+#endif
 #ifndef S16_ABL
 #define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
                       // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
@@ -118,10 +126,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         asm volatile("" : "+s"(w_));                           // (recomputed at every use: hoisted out of the tile loop, these scalars fill the SGPR file)
         const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + RAW_INSTR * w_ * 1024 + (j == 4 ? 4096 : 0)));
-        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
     };
     // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves pieces [9 w / 2, ...): 5 for even waves, 4 for odd
     auto w_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
@@ -277,6 +285,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         }
     };
 
+#ifdef S16_PRIO
+    if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
+#endif
     // ---- prologue: bias, chunk 0 of the first tile
     if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
     set_fetch_tile(t_first);

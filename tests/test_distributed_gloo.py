@@ -155,6 +155,26 @@ def test_bench_strong_scaling_mode_two_ranks():
     assert rec["allgather_bytes_per_step"] == 2 * 3 * 16 * 12 * 8 * 4
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 2 ...` - bench.py must then run as ONE rank of the existing job (no second launcher), rank 0 prints the one line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from deqsci_amd.distributed import free_port
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-selftest", "--batch-per-gpu", "2",
+           "--size", "16x12x8", "--steps", "1", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["scaling"] == "weak" and rec["allgather_ms_per_step"] > 0
+
+
 def test_launch_ranks_propagates_failure(capfd):
     import sys
     import time
