@@ -1144,6 +1144,47 @@ def test_conv64_rounding_on_the_networks_own_data():
         assert worst["f44"] < (1.2e-6 if name == "x0" else 3.5e-7), (name, worst)
 
 
+def test_denoiser_rounding_along_the_loop():
+    """One whole denoiser call on the ACTUAL inputs of a real run (z1 = GAP(X_k) captured at f-calls 0, 8, 40 of FFDNet + Anderson on
+    traffic m0) against the same folded network in float64: the default path (split-fp16 64->64 layers, matrix-core head and tail) is no
+    noisier than the all-fp32 Winograd F(2x2,3x3) path and well below the network run on MIOpen's fp32 convolutions
+    (profiles/r03_fcall_error_along_loop.json: 0.85x and 0.5x)."""
+    import torch.nn.functional as Fn
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"][None, ..., 0].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 45)[0].nonlinear_op
+    eng = DEQSCIEngine(net, max_iter=45, use_graph=False, conv64="f22")
+    den, captured = eng.den, {}
+    orig = den.run
+
+    def spy(z1, call):
+        if call in (0, 8, 40):
+            captured[call] = z1.clone()
+        return orig(z1, call)
+    den.run = spy
+    eng.reconstruct(y, Phi)
+    den.run = orig
+    assert sorted(captured) == [0, 8, 40]
+    mi = DEQSCIEngine(net, max_iter=45, use_graph=False, winograd=False)
+    mi.den.prepare(60, DEV)
+    for call, z1 in captured.items():
+        x = z1.view(8, 1, 256, 256)
+        sig = den.sigma_table[call:call + 1]
+        h = torch.cat((sig.double().view(1, 1, 1, 1).expand(8, 1, 128, 128), Fn.pixel_unshuffle(x.double(), 2)), 1)
+        for w, b, relu in den.fast:
+            h = Fn.conv2d(h, w.double(), None if b is None else b.double(), padding=1)
+            h = torch.relu(h) if relu else h
+        ref = Fn.pixel_shuffle(h, 2)
+        err = {}
+        for pol in ("f22", "fast"):
+            den.conv64 = den._policy = pol
+            err[pol] = float((den.run(z1, call)[0].double().view_as(ref) - ref).norm() / ref.norm())
+        err["miopen"] = float((mi.den.run(z1, call)[0].double().view_as(ref) - ref).norm() / ref.norm())
+        print(call, {k: "%.2e" % v for k, v in err.items()})
+        assert err["fast"] < 1.05 * err["f22"] and err["fast"] < 0.7 * err["miopen"], (call, err)
+
+
 def test_engine_conv_layout_and_kernel_choice():
     """The engine's 64->64 layers under its conv64 policies: the F(4x4,3x3) kernel with the activations kept in its own blk32 layout
     between layers is BIT-identical to the same kernel on channels_last tensors (same arithmetic, other addresses); the kernels
