@@ -396,26 +396,29 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
 #pragma unroll 1
     for (int mb = wave; mb < TL_MB; mb += 4) {
         fetch(mb, A);
-        f32x16 acc[NT], acs[NT];                               // hi x hi chain / cross-term chain (as in the 64 -> 64 kernel)
+        f32x16 acc[NT];                                        // (K = 64 per tap column: twelve MFMAs per accumulator - one chain, cross terms first)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[nt][i] = acs[nt][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                acs[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][1], Bw[c][0][nt], acs[nt], 0, 0, 0);
-                acs[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][1][nt], acs[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][0][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][1], Bw[c][0][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][1][nt], acc[nt], 0, 0, 0);
             }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][0][nt], acc[nt], 0, 0, 0);
         // D: row (pixel) 8 (i >> 2) + 4 kb + (i & 3) of the block, column pl of the N tile
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int colp = 32 * nt + pl;
             if (colp < NCOL) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) P[(32 * mb + 8 * (i >> 2) + 4 * kb + (i & 3)) * PS + colp] = (acc[nt][i] + acs[nt][i]) * oscale;
+                for (int i = 0; i < 16; ++i) P[(32 * mb + 8 * (i >> 2) + 4 * kb + (i & 3)) * PS + colp] = acc[nt][i] * oscale;
             }
         }
     }
@@ -523,19 +526,22 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                 Bl[ks][2 * e] = ll.x; Bl[ks][2 * e + 1] = ll.y;
             }
         }
-        f32x16 acc[2], acs[2];
+        f32x16 acc[2];                                          // (K = 48: nine MFMAs per accumulator - one chain, cross terms first)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[g][i] = acs[g][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                acs[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][1][g], Bh[ks], acs[g], 0, 0, 0);
-                acs[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bl[ks], acs[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bh[ks], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][1][g], Bh[ks], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bl[ks], acc[g], 0, 0, 0);
             }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bh[ks], acc[g], 0, 0, 0);
         // D[g][i]: cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of position (r0 + lr, c0 + pl): ReLU, x 2^8, split, lane exchange, sp16 stores
         const int r = r0 + lr, c = c0 + pl;
         const uint32_t pix = (r < H && c < W) ? (uint32_t)((kb * (int)HW + r * W + c) * 16) : RAW_OOB;
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
-                    f32x2 t = ((f32x2){acc[g][i], acc[g][i + 1]} + (f32x2){acs[g][i], acs[g][i + 1]}) * (f32x2){oscale, oscale};
+                    f32x2 t = (f32x2){acc[g][i], acc[g][i + 1]} * (f32x2){oscale, oscale};
                     t.x = __builtin_elementwise_maximum(t.x, 0.0f);
                     t.y = __builtin_elementwise_maximum(t.y, 0.0f);
                     const h2 hh = __builtin_convertvector(t, h2);
