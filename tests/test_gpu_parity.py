@@ -1303,13 +1303,21 @@ def test_bench_two_ranks_on_one_gpu_real_engine():
     from conftest import ROOT
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-share-gpu0", "--batch-per-gpu", "2", "--iters", "12",
-                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-stream"], capture_output=True, text=True, timeout=600, env=env)
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-stream", "--no-graph"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 4 and rec["config"]["f_calls_per_step"] == 13
     assert rec["allgather_ms_per_step"] > 0 and rec["value"] > 0 and 0 < rec["final_res"] < 1
+    assert rec["scaling"] == "weak" and "roofline" in rec and rec["roofline"]["bound"] in ("mfma", "hbm")        # N > 1 lines keep the roofline (per-launch timing needs --no-graph at this size)
+    # the strong-scaling mode on the same rig, ragged: 3 measurements over 2 ranks (2 + 1, the tail padded and masked)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-share-gpu0", "--global-batch", "3", "--iters", "12",
+                          "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-hbm-stream"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["scaling"] == "strong" and rec["config"]["global_batch"] == 3 and rec["config"]["batch_per_gpu"] == 2
+    assert rec["allgather_bytes_per_step"] == 2 * 2 * 256 * 256 * 8 * 4 and rec["value"] > 0 and 0 < rec["final_res"] < 1
 
 
 def test_engine_512x512x16_ffdnet_vs_oracle():
