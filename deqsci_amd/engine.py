@@ -29,6 +29,7 @@ reference's own usage: sigma restarts at every reconstruct() call (the reference
 y.mean() changes); the dead second f-call of DEQFixedPoint.forward (:271-272, only feeds the
 backward hook) is skipped unless `extra_call=True`.
 """
+import math
 import numpy as np
 import os
 
@@ -278,7 +279,7 @@ class DEQSCIEngine:
         # What the choice does to the result was measured where it can matter - FFDNet under Anderson beyond ~30 iterations is chaotic
         #  - as 25-start ensembles over the six traffic measurements (tools/config2_ensemble.py,
         # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.008 (as it is 21.446); F(2x2,3x3)
-        # 21.420; split-fp16 21.415; F(2x2,3x3) for 40 f-calls then F(4x4,3x3) 21.417; MIOpen's direct fp32 convolution 21.410;
+        # 21.420; split-fp16 21.428; F(2x2,3x3) for 40 f-calls then F(4x4,3x3) 21.417; MIOpen's direct fp32 convolution 21.410;
         # F(4x4,3x3) throughout 21.395.  Single measurements move by up to 0.09 dB under ANY change of arithmetic (the reference's own two
         # Gram variants: RMS 0.06 dB), so only the pooled mean separates kernels; it puts split-fp16 and F(2x2,3x3) together, nearest
         # the reference, which is why "auto" uses exactly those two.  Well-conditioned configurations (SimpleCNN, Picard, <= 30
@@ -339,7 +340,15 @@ class DEQSCIEngine:
         if not (isinstance(y, torch.Tensor) and y.is_cuda):
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
         with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
-            return self._reconstruct(y, Phi, Phi_sum, initial_point)
+            rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+            if self.conv64 == "auto" and self.conv64_policy == "fast" and not math.isfinite(self.last_info["res"]):
+                # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
+                # about) is redone once on the fp32 MFMA kernels, and this engine stays on them.  A run that diverges by itself comes
+                # back non-finite again and is returned as it is.
+                self.conv64_policy = self.den.conv64 = self.den._policy = "fast32"
+                self._graph = None
+                rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+            return rec
 
     def _reconstruct(self, y, Phi, Phi_sum, initial_point):
         y = _hip.f32c(y)
@@ -372,12 +381,13 @@ class DEQSCIEngine:
     def _warn_if_not_finite(self):
         """A non-finite residual is what an fp16 overflow inside the split-fp16 layers (activations beyond |x| = 255.9: csrc/conv_s16.hip keeps
         it inf / NaN all the way to the output on purpose) looks like from here - as does a genuinely diverging run.  Say so, loudly."""
-        import math
         import warnings
         if not math.isfinite(self.last_info["res"]) and self.conv64_policy in ("fast", "s16"):
+            what = ("redoing it with conv64='fast32' (fp32 MFMA kernels, no such limit), which this engine now keeps" if self.conv64 == "auto"
+                    else "rerun with conv64='fast32' (fp32 MFMA kernels, no such limit)")
             warnings.warn("DEQSCIEngine: the reconstruction's residual is not finite.  If the iteration itself is not diverging, an activation of "
                           "the denoiser has left fp16's range inside the split-fp16 64->64 layers (|x| >= 255.9; inputs are expected in [0, 1]): "
-                          "rerun with conv64='fast32' (fp32 MFMA kernels, no such limit).", RuntimeWarning, stacklevel=3)
+                          + what + ".", RuntimeWarning, stacklevel=4)
 
     def _enqueue(self, ws, y, Phi4, Phi_sum, initial_point, poll):
         """Every launch of one reconstruction on the current stream.  poll: True = lagged residual read-back with early stop,

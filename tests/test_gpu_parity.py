@@ -3,6 +3,7 @@ inputs, against the committed golden vectors generated from the reference, and -
 through size-independent properties.  Tolerances: the path is fp32 floating point; north_star
 asks <= 1e-4 relative L2 / 0.01 dB end to end; single kernels are held to ~1 ulp-level bounds."""
 import json
+import math
 import os
 
 import numpy as np
@@ -754,20 +755,28 @@ def test_engine_split16_on_ragged_sizes(kind, weights):
 
 def test_engine_warns_when_split16_overflows():
     """The engine end of the same promise: measurements 255x too large (the classic forgotten /255) push FFDNet's activations beyond fp16's
-    range inside the split-fp16 layers; the reconstruction comes back non-finite and the engine says why - and conv64='fast32' has no limit."""
+    range inside the split-fp16 layers; the reconstruction comes back non-finite and the engine says why - conv64='fast32' has no limit, and the default policy falls back to it by itself."""
     d = _clip("traffic_cacti.mat")
     Phi = d["mask"][None].to(DEV)
     y = (d["meas"][None, ..., 0] * 2000.0).contiguous().to(DEV)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 6)[0].nonlinear_op
-    eng = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    eng = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="fast")          # the explicit policy: told, not rescued
     with pytest.warns(RuntimeWarning, match="fp16's range"):
         rec = eng.reconstruct(y, Phi)
-    assert not bool(torch.isfinite(rec).all())
+    assert not bool(torch.isfinite(rec).all()) and eng.conv64_policy == "fast"
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         rec32 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="fast32").reconstruct(y, Phi)
     assert bool(torch.isfinite(rec32).all())
+    # the default ("auto") keeps the reference's fp32 range: it says what happened, redoes the run on the fp32 MFMA kernels and stays there
+    auto = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    with pytest.warns(RuntimeWarning, match="fp16's range"):
+        rec_auto = auto.reconstruct(y, Phi)
+    assert torch.equal(rec_auto, rec32) and auto.conv64_policy == "fast32" and math.isfinite(auto.last_info["res"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(auto.reconstruct(y, Phi), rec32)
 
 
 def test_split16_overflow_is_loud():
