@@ -38,6 +38,26 @@
 #else
 #define S16_NT ""
 #endif
+#ifndef S16_EPI_LOCKSTEP
+#define S16_EPI_LOCKSTEP 0  // 1: both waves of a SIMD run their epilogue behind the last stage's barrier (the form before the out-of-step one; A/B)
+#endif
+#ifndef S16_INTERLEAVE
+#define S16_INTERLEAVE 1    // 0: a group's operand reads and DMA instruction in front of its six MFMAs, order left to hipcc (A/B)
+#endif
+#ifndef S16_ST_SEL
+#define S16_ST_SEL 0        // cache policy of the output stores (A/B, tools/s16_variants.sh): 0 nt, 1 default, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
+#endif
+#if S16_ST_SEL == 0
+#define S16_ST " nt"
+#elif S16_ST_SEL == 1
+#define S16_ST ""
+#elif S16_ST_SEL == 2
+#define S16_ST " sc1"
+#elif S16_ST_SEL == 3
+#define S16_ST " sc0 sc1"
+#else
+#define S16_ST " sc0 sc1 nt"
+#endif
 #ifndef S16_ABL
 #define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
                       // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
@@ -56,7 +76,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) h8 lds_h8;
 
-constexpr int WAVES = 8, TBW = 64 * WAVES, NCHUNK = 4;
+constexpr int WAVES = 8, TBW = 64 * WAVES;
 constexpr int OUT_ROWS = 16, OUT_COLS = 32, RAW_ROWS = 18, RAW_COLS = 34, RAW_PIX = RAW_ROWS * RAW_COLS;     // 612
 constexpr int PLANE_B = RAW_PIX * 16;                          // 9792 bytes of one staged plane
 constexpr int RAW_SLOTS = 4 * RAW_PIX;                         // 2448 units of 16 bytes per chunk tile
@@ -97,8 +117,19 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // ---- halo tile by LDS-DMA: slot s = 64 (5 wave + j) + lane of the chunk tile is plane p = s / 612 (p = 2 hl + kb), pixel
     // (row, col) = ((s % 612) / 34, (s % 612) % 34): lane-linear in LDS, a per-lane byte offset on the global side.
     i32x4 rsrc;
-    uint32_t vo[RAW_INSTR];
-    auto set_fetch_tile = [&](int t) {
+    // Split in two so that it can be spread over MFMA groups (see `shadow` below): the wave-uniform part (descriptor, tile origin) and
+    // the per-instruction lane offsets.  The slot -> (plane, row, col) arithmetic does not depend on the tile: done once, packed.
+    uint32_t slot_rc[RAW_INSTR];                               // row | plane << 5 | col << 8 (col = 2^24 - 1 for slots beyond the tile: never inside an image)
+#pragma unroll
+    for (int j = 0; j < RAW_INSTR; ++j) {
+        const int s = 64 * (RAW_INSTR * wave + j) + lane;
+        const int p = (s * 857) >> 19;                         // s / 612 for s < 2560
+        const int q = s - p * RAW_PIX;
+        const int row = (q * 1928) >> 16, col = q - row * RAW_COLS;          // q / 34 for q < 768
+        slot_rc[j] = s < RAW_SLOTS ? (uint32_t)(row | (p << 5) | (col << 8)) : 0xFFFFFF00u;
+    }
+    int ft_py0 = 0, ft_px0 = 0;
+    auto fetch_tile_uniform = [&](int t) __attribute__((always_inline)) {
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         // the descriptor starts RAW_BIAS bytes BELOW the image: four of a wave's instructions differ only in their immediate offset, which
@@ -108,17 +139,17 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         rsrc.y = (int)uniform((uint32_t)(base >> 32));
         rsrc.z = (int)uniform((uint32_t)(HW * 256) + RAW_BIAS);
         rsrc.w = 0x00020000;
-        const int py0 = OUT_ROWS * by - 1, px0 = OUT_COLS * bx - 1;
-#pragma unroll
-        for (int j = 0; j < RAW_INSTR; ++j) {
-            const int s = 64 * (RAW_INSTR * wave + j) + lane;
-            const int p = (s * 857) >> 19;                     // s / 612 for s < 2560
-            const int q = s - p * RAW_PIX;
-            const int row = (q * 1928) >> 16, col = q - row * RAW_COLS;      // q / 34 for q < 768
-            const int iy = py0 + row, ix = px0 + col;
-            const bool ok = s < RAW_SLOTS && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            vo[j] = ok ? (uint32_t)(p * (int)HW + iy * W + ix) * 16u + (RAW_BIAS - 1024u * (j & 3)) : RAW_OOB;
-        }
+        ft_py0 = OUT_ROWS * by - 1;
+        ft_px0 = OUT_COLS * bx - 1;
+    };
+    auto fetch_lane_offset = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        uint32_t rc = slot_rc[j];
+        asm volatile("" : "+v"(rc));                           // (opaque: hoisted out of the tile loop, the pieces of this arithmetic spill)
+        const int iy = ft_py0 + (int)(rc & 31u), ix = ft_px0 + (int)(rc >> 8);
+        const bool ok = (uint32_t)iy < (uint32_t)H && (uint32_t)ix < (uint32_t)W;
+        uint32_t off = (((rc >> 5) & 7u) * (uint32_t)HW + (uint32_t)(iy * W + ix)) * 16u + (RAW_BIAS - 1024u * (j & 3));
+        asm volatile("" : "+v"(off));                          // (a select, not a branch around the arithmetic)
+        return ok ? off : RAW_OOB;
     };
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
     auto raw_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
@@ -126,17 +157,18 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         asm volatile("" : "+s"(w_));                           // (recomputed at every use: hoisted out of the tile loop, these scalars fill the SGPR file)
         const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + RAW_INSTR * w_ * 1024 + (j == 4 ? 4096 : 0)));
-        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
-        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072" S16_NT " lds" ::"s"(m0v), "v"(vo[j]), "s"(rsrc), "s"(soff) : "m0");
+        const uint32_t voj = fetch_lane_offset(j);             // (a dozen vector instructions, in the shadow of the group's MFMAs)
+        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
     };
-    // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves pieces [9 w / 2, ...): 5 for even waves, 4 for odd
+    // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves the five pieces from 9 w / 2 on
     auto w_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
         int w_ = wave;
         asm volatile("" : "+s"(w_));
-        const int first = (9 * w_) >> 1, count = ((9 * (w_ + 1)) >> 1) - first;
-        if (j >= count) return;
+        const int first = (9 * w_) >> 1;                       // (odd waves own four pieces: their fifth is the next wave's first, fetched twice -
+                                                               // the same bytes to the same place - rather than branched around)
         const uint32_t off = (uint32_t)((first + j) * 1024);
         const uint64_t g = (uint64_t)(Wp + (int64_t)c * W_CHUNK) + off;
         const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_CHUNK) + off);
@@ -145,6 +177,14 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lv), "s"(gs) : "m0");
     };
 
+#ifdef S16_STAMP   // profiling build (tools/s16_stamps.py): cycles per phase, summed over the launch, written over the bias array: [workgroup][wave][5]
+    uint32_t st_sum[5] = {0, 0, 0, 0, 0};
+    uint64_t st_t = __builtin_readcyclecounter();
+#define S16_MARK(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(now_ - st_t); st_t = now_; } while (0)
+    uint32_t* st_out = reinterpret_cast<uint32_t*>(const_cast<float*>(bias));
+#else
+#define S16_MARK(i) do { } while (0)
+#endif
     // [chain][cout group g][pixel row r].  TWO accumulation chains per output: chain 0 takes the hi x hi products, chain 1 the two
     // cross products (2^-11 of the size).  Every MFMA rounds its accumulator once, and the rounding error of a sum of n such steps grows
     // like sqrt(n) ulps OF THAT ACCUMULATOR: with the cross terms out of the way the big chain is 144 steps long instead of 432 (and
@@ -158,9 +198,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 
     // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of the next one) is
     // fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
-    // ---- epilogue of one (r, g, gp) piece of accumulator set S: acc[S][g][r][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of pixel (2 wave + r, pl)
-    auto ep_piece = [&](auto set_c, const Done& d, int k) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
+    // ---- epilogue of one (r, g, gp) piece: acc[.][g][r][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of pixel (2 wave + r, pl)
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    auto ep_piece = [&](const Done& d, int k, const f32x4 (&bz4)[2][4]) __attribute__((always_inline)) {
         const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1;
         // values in PAIRS (k, k + 1): every step below is one packed instruction per pair where the hardware has one.  ReLU is the
         // NaN-propagating maximum (v_maximum3_f32) against 0, or against -inf when the layer has none: an overflow upstream (inf in the
@@ -171,7 +211,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
             const f32x2 a0 = {acc[0][g][r][i], acc[0][g][r][i + 1]}, a1 = {acc[1][g][r][i], acc[1][g][r][i + 1]};
-            const f32x2 bz = *reinterpret_cast<const f32x2*>(bias_s + 32 * g + 8 * (2 * gp + (e >> 1)) + 4 * kb + 2 * (e & 1));
+            const f32x4 b4 = bz4[g][2 * gp + (e >> 1)];
+            const f32x2 bz = (e & 1) ? (f32x2){b4.z, b4.w} : (f32x2){b4.x, b4.y};
             f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
             t.x = __builtin_elementwise_maximum(t.x, floor_);
             t.y = __builtin_elementwise_maximum(t.y, floor_);
@@ -183,7 +224,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             for (int q = 0; q < 2; ++q) {
                 const f32x4 o = {v2[2 * q].x, v2[2 * q].y, v2[2 * q + 1].x, v2[2 * q + 1].y};
                 const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
             }
         } else {
             // sp16: split, pack, and trade halves with the lane 32 away so that each lane holds one whole 16-byte pixel of
@@ -208,8 +249,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
             const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
             const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(oh), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_h) : "memory");
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_l) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_h) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_l) : "memory");
         }
     };
     auto tile_done = [&](int t) -> Done {
@@ -232,10 +273,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     };
 
     // One stage = chunk c of the current tile (accumulator set S): Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
-    // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.  `flush`: the previous
-    // tile's epilogue (the other accumulator set) rides along, one piece behind every other group.
-    auto stage = [&](auto set_c, int c, bool more, bool flush, const Done& prev) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
+    // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
+    // `before_barrier` runs between the stage's last MFMA and its barrier, `shadow(i)` inside group i behind four of its MFMAs.
+    auto stage = [&](int c, bool more, auto&& before_barrier, auto&& shadow) __attribute__((always_inline)) {
         const int buf = c & 1, nb = buf ^ 1, cn = (c + 1) & 3;
         const lds_char* bb = bbase + buf * RAW_BUF;
         const lds_char* ab = abase + buf * W_CHUNK;
@@ -257,40 +297,63 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 }
             }
         };
+        S16_MARK(4);
         loads(0);
         loads(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 18; ++i) {
             const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1;
+            // (hipcc left to itself issues a group's six MFMAs first and everything else behind them: the wave's next MFMA then waits for
+            // its own operand reads, DMA set-up and scalar arithmetic to issue - pinned here in the MFMAs' shadow instead)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             loads(i + 2);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (more && i < 2 * RAW_INSTR && !(S16_ABL & 1)) {   // the next chunk: 10 DMA instructions, one per group in the FIRST half of the
                                                                // stage - the last one needs the second half (an HBM round trip) to land
                 if (i < RAW_INSTR) raw_piece(cn, nb, i); else w_piece(cn, nb, i - RAW_INSTR);
             }
-            if (c == 0 && (i & 1) && i < 16 && (!(S16_ABL & 4) || relu == 77)) {
-                if (flush) ep_piece(set_c, prev, i >> 1);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+            shadow(i);                                         // (tile bookkeeping rides here, behind four of the group's MFMAs)
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int r = 0; r < 2; ++r) acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        S16_MARK(0);
         if (!(S16_ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S16_MARK(1);
+            before_barrier();
             lds_barrier();
+            S16_MARK(2);
         }
     };
+    auto nothing = [] {};
+    auto no_shadow = [](int) {};
 
 #ifdef S16_PRIO
     if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
 #endif
     // ---- prologue: bias, chunk 0 of the first tile
-    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
-    set_fetch_tile(t_first);
+#ifdef S16_STAMP
+    if (wave == 0) bias_s[lane] = 0.0f;
+#else
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;
+#endif     // (the sp16 output carries 2^8 y: so does its bias)
+    fetch_tile_uniform(t_first);
 #pragma unroll
     for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -301,9 +364,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // register budget stays 256 and only one accumulation chain fits; and a wave alone on its SIMD has nobody to cover its stalls.)
     // (Spreading a tile's epilogue over the MFMA stream of the next tile - a second accumulator set, one piece behind every other group -
     // was built and measured: 192 us against 187 us at 64 x 128 x 128.  On random data this kernel runs against the chip's POWER limit
-    // (1.87-1.97 GHz instead of 2.4; all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles.)
+    // (all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles: the out-of-step epilogue, the
+    // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
+    // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}};
-    constexpr std::integral_constant<int, 0> S0{};
+    S16_MARK(4);
 #pragma unroll 1
     for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
 #pragma unroll
@@ -312,19 +377,49 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[1][g][r][i] = 0.0f;
-        stage(S0, 0, true, false, none);
-        stage(S0, 1, true, false, none);
-        stage(S0, 2, true, false, none);
+        stage(0, true, nothing, no_shadow);
+        stage(1, true, nothing, no_shadow);
         const bool next = t_cur + t_step < t_end;
-        if (next) set_fetch_tile(t_cur + t_step);             // (the fetches of chunks 1..3 of this tile have been issued)
-        stage(S0, 3, next, false, none);
-        if (!(S16_ABL & 4) || relu == 77) {
-            const Done d = tile_done(t_cur);
+        // the NEXT tile's fetch descriptor and origin, in the shadow of this stage's MFMA group 10 (its own DMA instructions - the last ones
+        // that use this tile's - sit in groups 0..9; the per-lane offsets are formed where each DMA instruction is issued).  Between the
+        // tiles this arithmetic cost every wave 1.5 us with the matrix pipe idle
+        stage(2, true, nothing, [&](int i) __attribute__((always_inline)) {
+            if (i == 10) fetch_tile_uniform(t_cur + t_step);
+        });
+        // The epilogue, out of step between the two waves of a SIMD.  Waves 0-3 (one per SIMD, dispatched first: the issue arbiter favours
+        // them, they finish a stage's MFMAs in 55 % of its time and idle at the barrier) run their epilogue BEFORE the last stage's barrier,
+        // under the MFMAs their SIMD partner is still issuing; waves 4-7 run theirs BEHIND it, under the partner's first MFMAs of the next
+        // tile.  The matrix pipe always has a wave feeding it; in lockstep both epilogues of a SIMD ran together with the pipe idle (21 % of
+        // a tile: tools/s16_stamps.py, profiles/r03_s16_stamps_before.txt).
+        Done d = none;
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            if (!(S16_ABL & 4) || relu == 77) {
+                // the lane's 32 bias values in one burst of LDS reads (operand registers are free here): read piece by piece, each read
+                // was a round trip through an LDS the partner wave keeps busy - 16 of them made the epilogue twice as long
+                f32x4 bz4[2][4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ep_piece(S0, d, k);
-        }
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ep_piece(d, k, bz4);
+            }
+        };
+#if S16_EPI_LOCKSTEP
+        stage(3, next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
+        epilogue();
+#else
+        stage(3, next, [&]() __attribute__((always_inline)) { if (wave < 4) epilogue(); },
+              [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
+        if (wave >= 4) epilogue();
+#endif
+        S16_MARK(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef S16_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
+#endif
 }
 
 // fp32 channels_last (n, H, W, 64) -> sp16, activations scaled by `scale` (the engine's 2^8): one lane per (pixel, 8-channel block)
