@@ -58,6 +58,9 @@
 #else
 #define S16_ST " sc0 sc1 nt"
 #endif
+#ifndef S16_TAIL_XCD
+#define S16_TAIL_XCD 1      // 0: the last layer's tiles dealt round-robin over the XCDs (A/B)
+#endif
 #ifndef S16_ABL
 #define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
                       // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
@@ -456,10 +459,20 @@ constexpr int TL_H = 8, TL_W = 32, TL_IW = TL_W + 2, TL_IH = TL_H + 2, TL_PIX = 
 constexpr int TL_MB = (TL_PIX + 31) / 32;                                                      // 11 blocks of 32 halo pixels
 template <int COUT>
 __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
-                                                       float oscale) {
+                                                       float oscale, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
     __shared__ __attribute__((aligned(16))) float P[TL_PIX * PS + 32 * 36];       // (+ slack: the last pixel block writes 352 rows)
-    const int n = blockIdx.z, r0 = blockIdx.y * TL_H, c0 = blockIdx.x * TL_W;
+    // Workgroup b runs on XCD b % 8: every XCD takes a contiguous range of tiles (image-major, then rows), so that the two halo rows a
+    // tile shares with the tile above and below it are re-read from THAT XCD's L2 while they are hot - with tiles dealt round-robin
+    // over the XCDs every halo row came from HBM again (10 rows fetched per 8 produced)
+#if S16_TAIL_XCD
+    const int per_xcd = (n_tiles + 7) >> 3, t = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+#else
+    const int t = (int)blockIdx.x;
+#endif
+    if (t >= n_tiles) return;
+    const int n = t / (tiles_x * tiles_y), rt = t - n * (tiles_x * tiles_y), by = rt / tiles_x;
+    const int r0 = by * TL_H, c0 = (rt - by * tiles_x) * TL_W;
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
     const int64_t HW = (int64_t)H * W;
     const char* xn = x + (int64_t)n * HW * 256;
@@ -728,9 +741,11 @@ static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, i
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
     if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
-    const dim3 grid((unsigned)ceil_div(W, s16::TL_W), (unsigned)ceil_div(H, s16::TL_H), (unsigned)n);
+    const int64_t tiles_x = ceil_div(W, s16::TL_W), tiles_y = ceil_div(H, s16::TL_H), n_tiles = n * tiles_x * tiles_y;
+    if (n_tiles > (1 << 30)) return DEQSCI_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(8 * ceil_div(n_tiles, 8)));
     hipLaunchKernelGGL(s16::tail_s16_kernel<COUT>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
-                       static_cast<const char*>(w_packed), out, (int)H, (int)W, out_scale);
+                       static_cast<const char*>(w_packed), out, (int)H, (int)W, out_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles);
     return launch_status();
 }
 
