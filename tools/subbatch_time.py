@@ -40,6 +40,29 @@ def main():
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 5 * 1e3)
         out[f"{parts} x {step} measurements: us per denoiser call over the batch"] = round(statistics.median(ts[1:]), 1)
+    # the same halves / quarters on CONCURRENT streams: does one stream's kernel fill the other's launch ramp, drain and cache write-back?
+    for parts in (2, 4):
+        if bsz % parts:
+            continue
+        step = bsz // parts
+        streams = [torch.cuda.Stream() for _ in range(parts)]
+        ts = []
+        for rep in range(6):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for st in streams:
+                st.wait_event(e0)
+            for _ in range(5):
+                for p, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        den.run(z1[p * step:(p + 1) * step], 20)
+            for st in streams:
+                torch.cuda.current_stream().wait_stream(st)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 5 * 1e3)
+        out[f"{parts} concurrent streams x {step} measurements: us per denoiser call over the batch"] = round(statistics.median(ts[1:]), 1)
     print(json.dumps(out))
 
 
