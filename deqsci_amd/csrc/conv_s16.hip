@@ -275,7 +275,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         return d;
     };
 
-    // One stage = chunk c of the current tile (accumulator set S): Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
+    // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
     // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
     // `before_barrier` runs between the stage's last MFMA and its barrier, `shadow(i)` inside group i behind four of its MFMAs.
     auto stage = [&](int c, bool more, auto&& before_barrier, auto&& shadow) __attribute__((always_inline)) {
@@ -352,10 +352,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #endif
     // ---- prologue: bias, chunk 0 of the first tile
 #ifdef S16_STAMP
-    if (wave == 0) bias_s[lane] = 0.0f;
+    if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
 #else
-    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;
-#endif     // (the sp16 output carries 2^8 y: so does its bias)
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
+#endif
     fetch_tile_uniform(t_first);
 #pragma unroll
     for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
