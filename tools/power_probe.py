@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Socket power and shader clock while the split-fp16 conv kernel (or a variant library, DEQSCI_HIP_LIB) runs back to back for a few seconds:
+is the launch time energy / power?  Samples the amdgpu hwmon files (power1_average / power1_input in uW, freq1_input in Hz) from a thread;
+prints what it finds when the files are missing (then `rocm-smi` is tried once per phase)."""
+import glob
+import json
+import os
+import statistics
+import subprocess
+import sys
+import threading
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deqsci_amd import _hip  # noqa: E402
+
+
+def hwmon_files():
+    out = {}
+    for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        for name in ("power1_average", "power1_input", "freq1_input", "power1_cap"):
+            f = os.path.join(d, name)
+            if os.path.exists(f):
+                out.setdefault(name, f)
+    return out
+
+
+class Sampler(threading.Thread):
+    def __init__(self, files):
+        super().__init__(daemon=True)
+        self.files, self.rows, self.stop = files, [], False
+
+    def run(self):
+        while not self.stop:
+            row = {}
+            for k, f in self.files.items():
+                try:
+                    row[k] = int(open(f).read().strip())
+                except (OSError, ValueError):
+                    pass
+            self.rows.append(row)
+            time.sleep(0.02)
+
+
+def main():
+    files = hwmon_files()
+    print(json.dumps({"hwmon": files}))
+    zero = bool(os.environ.get("S16_ZERO"))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    b = torch.randn(64, device="cuda", generator=g)
+    x = torch.randn(64, 64, 128, 128, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    if zero:
+        x.zero_(); w.zero_()
+    xs = _hip.to_split16(x); out = _hip.Sp16.empty(64, 128, 128, "cuda"); Wsp = _hip.Split16Weights(w)
+    for _ in range(50):
+        _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=out)
+    torch.cuda.synchronize()
+    time.sleep(1.0)
+    idle = {k: int(open(f).read().strip()) for k, f in files.items() if k != "power1_cap"} if files else {}
+    s = Sampler({k: f for k, f in files.items() if k != "power1_cap"})
+    s.start()
+    n = 12000
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    s.stop = True
+    us = e0.elapsed_time(e1) / n * 1e3
+    rows = s.rows[len(s.rows) // 4:]                     # steady part
+    res = {"lib": os.environ.get("DEQSCI_HIP_LIB", "product"), "zero_operands": zero, "launch_us": round(us, 1), "samples": len(rows), "idle": idle}
+    for k in ("power1_average", "power1_input", "freq1_input"):
+        v = [r[k] for r in rows if k in r]
+        if v:
+            res[k + "_median"] = statistics.median(v)
+    if "power1_cap" in files:
+        res["power1_cap"] = int(open(files["power1_cap"]).read().strip())
+    p = res.get("power1_average_median") or res.get("power1_input_median")
+    if p:
+        res["energy_per_launch_mJ"] = round(p * 1e-6 * us * 1e-6 * 1e3, 2)
+    if not files:
+        try:
+            res["rocm_smi"] = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=30).stdout[-1500:]
+        except Exception as e:  # noqa: BLE001
+            res["rocm_smi"] = repr(e)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
