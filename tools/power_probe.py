@@ -19,12 +19,24 @@ from deqsci_amd import _hip  # noqa: E402
 
 
 def hwmon_files():
-    out = {}
+    """hwmon files of the GPU this process computes on (a box shows every card of its node in sysfs): matched by PCI address."""
+    want = None
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        pass
+    cands = []
     for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
-        for name in ("power1_average", "power1_input", "freq1_input", "power1_cap"):
-            f = os.path.join(d, name)
-            if os.path.exists(f):
-                out.setdefault(name, f)
+        addr = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+        files = {name: os.path.join(d, name) for name in ("power1_average", "power1_input", "freq1_input", "power1_cap") if os.path.exists(os.path.join(d, name))}
+        if files:
+            cands.append((addr == want, addr, files))
+    cands.sort(key=lambda c: not c[0])
+    if not cands:
+        return {}
+    out = dict(cands[0][2])
+    out["_pci"] = cands[0][1] + ("" if cands[0][0] else " (no PCI match for %s: first card)" % want)
     return out
 
 
@@ -48,6 +60,7 @@ class Sampler(threading.Thread):
 def main():
     files = hwmon_files()
     print(json.dumps({"hwmon": files}))
+    pci = files.pop("_pci", None)
     zero = bool(os.environ.get("S16_ZERO"))
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
@@ -73,7 +86,7 @@ def main():
     s.stop = True
     us = e0.elapsed_time(e1) / n * 1e3
     rows = s.rows[len(s.rows) // 4:]                     # steady part
-    res = {"lib": os.environ.get("DEQSCI_HIP_LIB", "product"), "zero_operands": zero, "launch_us": round(us, 1), "samples": len(rows), "idle": idle}
+    res = {"lib": os.environ.get("DEQSCI_HIP_LIB", "product"), "zero_operands": zero, "launch_us": round(us, 1), "samples": len(rows), "idle": idle, "pci": pci}
     for k in ("power1_average", "power1_input", "freq1_input"):
         v = [r[k] for r in rows if k in r]
         if v:

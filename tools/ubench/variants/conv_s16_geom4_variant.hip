@@ -1,0 +1,836 @@
+// EXPERIMENT RECORD, not product (round 3): csrc/conv_s16.hip with the 64->64 kernel parametrised by its geometry - conv_s16_kernel<OUT, NW, ROWS>:
+// <8, 2> is the shipped form, <4, 4> (-DS16_GEOM_NW=4) runs FOUR waves, one per SIMD at 512 registers, each owning 4 pixel rows x 64 couts x two
+// accumulation chains (256 accumulator registers): 40 % less LDS operand traffic, which tools/power_probe.py shows to be a quarter of the launch's
+// energy at the 1400 W cap.  Its own work sliced behind each of a group's twelve MFMAs (operand reads two at a time, the 19 DMA instructions of
+// a stage, tile bookkeeping).  Measured (profiles/r03_s16_ablations.jsonl, group K): correct, 340 k cycles per wave against 280 k - a stage's MFMA
+// phase takes 8 680 cycles against the 6 912 of its MFMAs (every LDS-DMA instruction holds the wave's issue for 60-100 cycles and nobody
+// else feeds the SIMD), the unoverlapped epilogue 6 700 per tile - and 210 us against 201 us on random operands, 154 against 140 on zeros.
+// Build: S16_SRC=tools/ubench/variants/conv_s16_geom4_variant.hip tools/s16_variants.sh "g4:-DS16_GEOM_NW=4"; stamps: S16_NW=4 tools/s16_stamps.py.
+// 3x3 convolution 64 -> 64 channels (pad 1, stride 1) as a DIRECT convolution on the f16 matrix cores of MI355X with fp32-class
+// accuracy: every fp32 operand is split into two fp16 pieces, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits),
+// and the product is formed from three f16 MFMAs with fp32 accumulation
+//        w x  ~=  w_hi x_hi + w_lo x_hi + w_hi x_lo            (the dropped w_lo x_lo term is 2^-22 relative)
+// The f16 matrix pipe is 16x faster than the f32 one (v_mfma_f32_32x32x16_f16: 32768 flops per 32 cycles against 2048 for
+// v_mfma_f32_16x16x4_f32), so three f16 products of a direct convolution (3 x 9 taps) cost 0.42 of the f32 MFMA time of Winograd
+// F(4x4,3x3) (2.25 taps-equivalent) - and there is NO transform: no input transform (13 % of the F(4x4,3x3) kernel), no output
+// transform, no exchange, none of the cancellation that makes Winograd forms noisy on rough inputs.  Measured rounding against a
+// float64 convolution on FFDNet's own data: see tools/conv_error_real.py (on par with the fp32 forms, below MIOpen's direct fp32
+// convolution), tools/ubench/mfma_f16_numerics.hip for what the f16 MFMA does with its 16 products (fp16 subnormals kept, one
+// rounding per instruction).
+//
+// Scaling: fp16 has 5 exponent bits.  Activations are stored multiplied by 2^8 (|v| < 255: FFDNet's stay below 10; an overflow shows
+// as inf/NaN in the output, never silently) and each layer's weights by a power of two chosen at pack time so that max |w| lands in
+// [2^13, 2^14); the lo pieces then stay normal fp16 numbers for every value that matters.  The epilogue multiplies the fp32
+// accumulator by the exact inverse power of two.
+//
+// Activation layout between layers ("sp16"): [n][cin chunk c (4)][piece hl (2: hi, lo)][k block kb (2)][H][W][8 halfs] - 16 planes
+// of 16-byte pixels (256 bytes per pixel in all, as fp32 NHWC).  A pixel's 16 bytes in plane (c, hl, kb) are exactly one lane's
+// B operand of v_mfma_f32_32x32x16_f16 (channels 16 c + 8 kb .. + 8), a staged tile row is 544 contiguous bytes per plane, and a
+// tap (dy, dx) is a constant offset into the staged plane: conflict-free ds_read_b128 for every tap, no per-tap address arithmetic.
+//
+// Block tile = 16 x 32 output pixels x 64 couts, one persistent 8-wave workgroup per CU (as csrc/winograd44.hip); wave w owns pixel
+// rows 2 w, 2 w + 1 (two N tiles of 32 pixels) x both cout groups of 32 (two M tiles): four accumulators of 16 registers.  Input
+// channels in chunks of 16 (= K of one MFMA): per chunk the 18 x 34 pixel halo tile (4 planes, 39 KB) and the chunk's weights
+// (9 taps x 2 pieces x 2 cout groups x 1 KB = 36 KB, host-packed in LDS order) are double-buffered and fetched by the LDS-DMA path
+// one stage ahead; out-of-image pixels are zeros the buffer hardware writes for out-of-range lanes.  One barrier per stage.
+#include "common.hpp"
+#include <hip/hip_ext.h>
+#include <type_traits>
+#pragma clang diagnostic ignored "-Winline-asm"
+
+#ifndef S16_RAW_NT
+#define S16_RAW_NT 0  // 1: the halo-tile DMA with the non-temporal hint (A/B: tools/s16_variants.sh)
+#endif
+#if S16_RAW_NT
+#define S16_NT " nt"
+#else
+#define S16_NT ""
+#endif
+#ifndef S16_EPI_LOCKSTEP
+#define S16_EPI_LOCKSTEP 0  // 1: both waves of a SIMD run their epilogue behind the last stage's barrier (the form before the out-of-step one; A/B)
+#endif
+#ifndef S16_INTERLEAVE
+#define S16_INTERLEAVE 1    // 0: a group's operand reads and DMA instruction in front of its six MFMAs, order left to hipcc (A/B)
+#endif
+#ifndef S16_ST_SEL
+#define S16_ST_SEL 0        // cache policy of the output stores (A/B, tools/s16_variants.sh): 0 nt, 1 default, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt
+#endif
+#if S16_ST_SEL == 0
+#define S16_ST " nt"
+#elif S16_ST_SEL == 1
+#define S16_ST ""
+#elif S16_ST_SEL == 2
+#define S16_ST " sc1"
+#elif S16_ST_SEL == 3
+#define S16_ST " sc0 sc1"
+#else
+#define S16_ST " sc0 sc1 nt"
+#endif
+#ifndef S16_TAIL_XCD
+#define S16_TAIL_XCD 1      // 0: the last layer's tiles dealt round-robin over the XCDs (A/B)
+#endif
+#ifndef S16_GEOM_NW
+#define S16_GEOM_NW 8       // waves per workgroup of the 64->64 kernel: 8 (x 2 pixel rows, two waves per SIMD) or 4 (x 4 rows, one wave per SIMD at 512 registers)
+#endif
+#ifndef S16_ABL
+#define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
+                      // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
+#endif
+
+namespace deqsci {
+namespace s16 {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) h8 lds_h8;
+
+constexpr int WAVES = 8, TBW = 64 * WAVES;                     // the shipped geometry: 8 waves x 2 pixel rows (conv_s16_kernel<., 8, 2>)
+constexpr int OUT_ROWS = 16, OUT_COLS = 32, RAW_ROWS = 18, RAW_COLS = 34, RAW_PIX = RAW_ROWS * RAW_COLS;     // 612
+constexpr int PLANE_B = RAW_PIX * 16;                          // 9792 bytes of one staged plane
+constexpr int RAW_SLOTS = 4 * RAW_PIX;                         // 2448 units of 16 bytes per chunk tile
+constexpr int RAW_BUF = 40 * 1024;                             // 40960 bytes: 40 LDS-DMA instructions of 64 units per chunk (2560 slots), 40 / NW per wave
+constexpr int W_CHUNK = 9 * 2 * 2 * 1024;                      // 36864 bytes: [tap][hl][cout group][lane][8 halfs]
+constexpr uint32_t RAW_BIAS = 4096;                            // the descriptor starts this far below the image (see set_fetch_tile)
+constexpr uint32_t RAW_OOB = 0x80000000u;                      // beyond num_records: the hardware writes zeros
+constexpr float SP_SCALE = 256.0f;                             // sp16 activations hold 2^8 x
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
+
+// OUT_F32 = 0: sp16 output (the next 64->64 layer's input); 1: fp32 channels_last (n, H, W, 64) output (the consumer is not this kernel)
+// NW waves x ROWS pixel rows each = the 16 rows of a block tile: <8, 2> two waves per SIMD at 256 registers; <4, 4> one wave per SIMD at 512
+// (twice the register tile: 40 % less LDS operand traffic - the largest consumer of the launch's energy after the MFMAs, tools/power_probe.py)
+template <int OUT_F32, int NW, int ROWS>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
+                                                          char* __restrict__ y, int H, int W, int relu, float oscale, float bscale, int tiles_x, int tiles_y,
+                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+    __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
+    __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
+    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    static_assert(NW * ROWS == OUT_ROWS && 40 % NW == 0 && 36 % (NW / 2) == 0, "geometry");
+    constexpr int RAW_INSTR = 40 / NW;                         // halo-tile DMA instructions per wave and chunk
+    constexpr int W_INSTR = NW == 8 ? 5 : 36 / NW;             // weight DMA instructions per wave and chunk (8 waves: 4.5, one fetched twice)
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
+    int t_first, t_step, t_end;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        if ((nb & 7) == 0) {                                   // block b runs on XCD b % 8: give every XCD a contiguous range of tiles
+            const int per_xcd = (n_tiles + 7) >> 3;
+            t_first = (b & 7) * per_xcd + (b >> 3);
+            t_step = nb >> 3;
+            t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
+        } else { t_first = b; t_step = nb; t_end = n_tiles; }
+    }
+    if (t_first >= t_end) return;
+    const int64_t HW = (int64_t)H * W;
+
+    // ---- halo tile by LDS-DMA: slot s = 64 (5 wave + j) + lane of the chunk tile is plane p = s / 612 (p = 2 hl + kb), pixel
+    // (row, col) = ((s % 612) / 34, (s % 612) % 34): lane-linear in LDS, a per-lane byte offset on the global side.
+    i32x4 rsrc;
+    // Split in two so that it can be spread over MFMA groups (see `shadow` below): the wave-uniform part (descriptor, tile origin) and
+    // the per-instruction lane offsets, formed where each DMA instruction is issued.
+    int ft_py0 = 0, ft_px0 = 0;
+    auto fetch_tile_uniform = [&](int t) __attribute__((always_inline)) {
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        // the descriptor starts RAW_BIAS bytes BELOW the image: four of a wave's instructions differ only in their immediate offset, which
+        // the hardware adds to the LDS AND the global address; the per-lane offsets take it back out
+        const uint64_t base = (uint64_t)(x + (int64_t)n * HW * 256) - RAW_BIAS;
+        rsrc.x = (int)uniform((uint32_t)base);
+        rsrc.y = (int)uniform((uint32_t)(base >> 32));
+        rsrc.z = (int)uniform((uint32_t)(HW * 256) + RAW_BIAS);
+        rsrc.w = 0x00020000;
+        ft_py0 = OUT_ROWS * by - 1;
+        ft_px0 = OUT_COLS * bx - 1;
+    };
+    auto fetch_lane_offset = [&](int j) __attribute__((always_inline)) -> uint32_t {
+        int l_ = lane, w_ = wave;
+        asm volatile("" : "+v"(l_), "+s"(w_));                 // (opaque: hoisted out of the tile loop, the pieces of this arithmetic spill; it
+                                                               // costs a dozen vector instructions in the shadow of the group's MFMAs)
+        const int s = 64 * (RAW_INSTR * w_ + j) + l_;
+        const int p = (s * 857) >> 19;                         // s / 612 for s < 2560
+        const int q = s - p * RAW_PIX;
+        const int row = (q * 1928) >> 16, col = q - row * RAW_COLS;          // q / 34 for q < 768
+        const int iy = ft_py0 + row, ix = ft_px0 + col;
+        const bool ok = s < RAW_SLOTS && (uint32_t)iy < (uint32_t)H && (uint32_t)ix < (uint32_t)W;
+        uint32_t off = ((uint32_t)p * (uint32_t)HW + (uint32_t)(iy * W + ix)) * 16u + (RAW_BIAS - 1024u * (j & 3));
+        asm volatile("" : "+v"(off));                          // (a select, not a branch around the arithmetic)
+        return ok ? off : RAW_OOB;
+    };
+    const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
+    auto raw_piece = [&](int c, int buf, int j, uint32_t voj_in = 0) __attribute__((always_inline)) {
+        int w_ = wave;
+        asm volatile("" : "+s"(w_));                           // (recomputed at every use: hoisted out of the tile loop, these scalars fill the SGPR file)
+        const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
+        const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + RAW_INSTR * w_ * 1024 + (j >> 2) * 4096));
+        const uint32_t voj = NW == 4 ? voj_in : fetch_lane_offset(j);
+        if ((j & 3) == 0) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else if ((j & 3) == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else if ((j & 3) == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+    };
+    // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves the five pieces from 9 w / 2 on
+    auto w_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
+        int w_ = wave;
+        asm volatile("" : "+s"(w_));
+        const int first = NW == 8 ? (9 * w_) >> 1 : W_INSTR * w_;   // (8 waves: odd waves own four pieces, their fifth is the next wave's first, fetched
+                                                               // twice - the same bytes to the same place - rather than branched around)
+        const uint32_t off = (uint32_t)((first + j) * 1024);
+        const uint64_t g = (uint64_t)(Wp + (int64_t)c * W_CHUNK) + off;
+        const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_CHUNK) + off);
+        const uint64_t gs = ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
+        const uint32_t lv = (uint32_t)lane * 16u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(lv), "s"(gs) : "m0");
+    };
+
+#ifdef S16_STAMP   // profiling build (tools/s16_stamps.py): cycles per phase, summed over the launch, written over the bias array: [workgroup][wave][5]
+    uint32_t st_sum[5] = {0, 0, 0, 0, 0};
+    uint64_t st_t = __builtin_readcyclecounter();
+#define S16_MARK(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(now_ - st_t); st_t = now_; } while (0)
+    uint32_t* st_out = reinterpret_cast<uint32_t*>(const_cast<float*>(bias));
+#else
+#define S16_MARK(i) do { } while (0)
+#endif
+    // [chain][cout group g][pixel row r].  TWO accumulation chains per output: chain 0 takes the hi x hi products, chain 1 the two
+    // cross products (2^-11 of the size).  Every MFMA rounds its accumulator once, and the rounding error of a sum of n such steps grows
+    // like sqrt(n) ulps OF THAT ACCUMULATOR: with the cross terms out of the way the big chain is 144 steps long instead of 432 (and
+    // the small chain's ulps are 2^-11 of the big one's), which takes the per-layer error against float64 from 2.5e-7 to 1.6e-7 - below
+    // the fp32 Winograd forms - for 64 more registers and one addition per output in the epilogue.
+    f32x16 acc[2][2][ROWS];
+    struct Done { i32x4 orsrc; uint32_t pix[ROWS]; };             // where the finished tile goes: descriptor of its image, per-lane offsets of rows r
+    const int pl = lane & 31, kb = lane >> 5;
+    const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (ROWS * wave * RAW_COLS + pl) * 16;
+    const lds_char* abase = (const lds_char*)Wt + lane * 16;
+
+    // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of the next one) is
+    // fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
+    // ---- epilogue of one (r, g, gp) piece: acc[.][g][r][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of pixel (2 wave + r, pl)
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    auto ep_piece = [&](const Done& d, int k, const f32x4 (&bz4)[2][4]) __attribute__((always_inline)) {
+        const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1;   // k < 4 ROWS
+        // values in PAIRS (k, k + 1): every step below is one packed instruction per pair where the hardware has one.  ReLU is the
+        // NaN-propagating maximum (v_maximum3_f32) against 0, or against -inf when the layer has none: an overflow upstream (inf in the
+        // fp16 pieces -> inf - inf in the accumulators) stays a NaN all the way to the output instead of being clamped to 0.
+        const float floor_ = relu ? 0.0f : -__builtin_inff();
+        f32x2 v2[4];                                           // [gq = 2 gp, 2 gp + 1][k pair]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
+            const f32x2 a0 = {acc[0][g][r][i], acc[0][g][r][i + 1]}, a1 = {acc[1][g][r][i], acc[1][g][r][i + 1]};
+            const f32x4 b4 = bz4[g][2 * gp + (e >> 1)];
+            const f32x2 bz = (e & 1) ? (f32x2){b4.z, b4.w} : (f32x2){b4.x, b4.y};
+            f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
+            t.x = __builtin_elementwise_maximum(t.x, floor_);
+            t.y = __builtin_elementwise_maximum(t.y, floor_);
+            v2[e] = t;
+        }
+        if (OUT_F32) {
+            // fp32 channels_last: the lane's four consecutive couts of each group are 16 contiguous bytes (pix = byte offset of the pixel)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 o = {v2[2 * q].x, v2[2 * q].y, v2[2 * q + 1].x, v2[2 * q + 1].y};
+                const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
+            }
+        } else {
+            // sp16: split, pack, and trade halves with the lane 32 away so that each lane holds one whole 16-byte pixel of
+            // plane (chunk 2 g + gp, hl, kb) - even couts-of-8 block for lanes < 32, odd block for lanes >= 32
+            unsigned hi[4], lo[4];                             // [block parity (gq & 1)][k pair]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const h2 hh = __builtin_convertvector(v2[e], h2);                          // v_cvt_pk_f16_f32 (round to nearest even)
+                const f32x2 rem = v2[e] - __builtin_convertvector(hh, f32x2);               // exact in fp32
+                hi[e] = __builtin_bit_cast(unsigned, hh);
+                lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(rem, h2));
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {                      // (E, O) = (block 0, block 1) registers e: swap E[32..63] with O[0..31]
+                auto sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
+                hi[e] = sh[0]; hi[2 + e] = sh[1];
+                auto sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
+                lo[e] = sl[0]; lo[2 + e] = sl[1];
+            }
+            // now lanes < 32 hold couts [0, 8) of block 0 as (hi[0], hi[1], hi[2], hi[3]) = (own 0..3, partner's 4..7); lanes >= 32
+            // hold block 1 of pixel lane - 32 likewise: plane kb of the lane (inside pix), pixel pl
+            const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
+            const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
+            const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_h) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_l) : "memory");
+        }
+    };
+    auto tile_done = [&](int t) -> Done {
+        Done d;
+        const int n = mdiv(t, mg_img, sh_img), rr_ = t - n * (tiles_x * tiles_y);
+        const int by = mdiv(rr_, mg_tx, sh_tx), bx = rr_ - by * tiles_x;
+        const int ox = OUT_COLS * bx + pl;
+        const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
+        d.orsrc.x = (int)uniform((uint32_t)ob);
+        d.orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+        d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
+        d.orsrc.w = 0x00020000;
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const int oy = OUT_ROWS * by + ROWS * wave + r;
+            const bool ok = oy < H && ox < W;
+            d.pix[r] = !ok ? RAW_OOB : OUT_F32 ? (uint32_t)((oy * W + ox) * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + oy * W + ox) * 16);
+        }
+        return d;
+    };
+
+    // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
+    // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
+    // `before_barrier` runs between the stage's last MFMA and its barrier, `shadow(i)` inside group i behind four of its MFMAs.
+    auto stage = [&](int c, bool more, auto&& before_barrier, auto&& shadow) __attribute__((always_inline)) {
+        const int buf = c & 1, nb = buf ^ 1, cn = (c + 1) & 3;
+        const lds_char* bb = bbase + buf * RAW_BUF;
+        const lds_char* ab = abase + buf * W_CHUNK;
+        // 18 groups (dx, dy, g) of 6 MFMAs: the two pixel rows x three products of one tap and cout group.  Operands are read from LDS
+        // TWO groups ahead (software pipeline pinned by sched_barriers: left to itself hipcc reads each fragment one MFMA before its use
+        // and waits for it): per group two weight fragments (hi, lo) and, when a new halo row comes into play, its hi and lo fragments
+        // (rows 0, 1 at dy = 0, row 2 at dy = 1, row 3 at dy = 2 of every dx; kept per dx parity).
+        h8 Ah[3], Al[3], Bh[2][ROWS + 2], Bl[2][ROWS + 2];
+        auto loads = [&](int i) __attribute__((always_inline)) {
+            if (i >= 18 || ((S16_ABL & 8) && i >= 2)) return;
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1, tap = dy * 3 + dx;
+            Ah[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 0) * 2 + g) * 1024);
+            Al[i % 3] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 1) * 2 + g) * 1024);
+            if (g == 0) {
+#pragma unroll
+                for (int rr = (dy == 0 ? 0 : dy + ROWS - 1); rr <= dy + ROWS - 1; ++rr) {
+                    Bh[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + (rr * RAW_COLS + dx) * 16);
+                    Bl[dx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + 2 * PLANE_B + (rr * RAW_COLS + dx) * 16);
+                }
+            }
+        };
+        S16_MARK(4);
+        loads(0);
+        loads(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NW == 4) {
+            // One wave per SIMD: whatever this wave issues between two of its MFMAs is time the matrix pipe may stand still, so the work of
+            // a group is cut into slices of a few instructions, one slice behind each of the group's twelve MFMAs: operand reads of group
+            // i + 2 two at a time (gaps 0-4), the stage's 19 DMA instructions two per group in groups 0-9 (offset arithmetic in gaps 5 / 7,
+            // issue in gaps 6 / 8), tile bookkeeping in gap 10.
+#pragma unroll
+            for (int i = 0; i < 18; ++i) {
+                const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1;
+                const int L = i + 2, Ldx = L / 6, Ldy = (L % 6) >> 1, Lg = L & 1, Ltap = Ldy * 3 + Ldx;
+                const int Lr0 = Ldy == 0 ? 0 : Ldy + ROWS - 1, Lnr = (L < 18 && Lg == 0) ? Ldy + ROWS - Lr0 : 0;      // new halo rows of group L
+                uint32_t vq[2] = {0, 0};
+#pragma unroll
+                for (int m = 0; m < 3 * ROWS; ++m) {
+                    const int part = m / ROWS, r = m % ROWS;
+                    if (part == 0) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+                    else if (part == 1) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+                    else acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (L < 18 && !((S16_ABL & 8) && L >= 2)) {
+#pragma unroll
+                        for (int it = 2 * m; it < 2 * m + 2; ++it) {       // read `it` of group L: 0 Ah, 1 Al, then (hi, lo) of each new halo row
+                            if (it == 0) Ah[L % 3] = *reinterpret_cast<const lds_h8*>(ab + ((Ltap * 2 + 0) * 2 + Lg) * 1024);
+                            else if (it == 1) Al[L % 3] = *reinterpret_cast<const lds_h8*>(ab + ((Ltap * 2 + 1) * 2 + Lg) * 1024);
+                            else if (it < 2 + 2 * Lnr) {
+                                const int rr = Lr0 + ((it - 2) >> 1);
+                                if ((it & 1) == 0) Bh[Ldx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + (rr * RAW_COLS + Ldx) * 16);
+                                else Bl[Ldx & 1][rr] = *reinterpret_cast<const lds_h8*>(bb + 2 * PLANE_B + (rr * RAW_COLS + Ldx) * 16);
+                            }
+                        }
+                    }
+                    if (more && !(S16_ABL & 1)) {
+                        const int q0 = 2 * i, q1 = 2 * i + 1;
+                        if (m == 5 && q0 < RAW_INSTR) vq[0] = fetch_lane_offset(q0);
+                        if (m == 7 && q1 < RAW_INSTR) vq[1] = fetch_lane_offset(q1);
+                        if (m == 6) { if (q0 < RAW_INSTR) raw_piece(cn, nb, q0, vq[0]); else if (q0 < RAW_INSTR + W_INSTR) w_piece(cn, nb, q0 - RAW_INSTR); }
+                        if (m == 8) { if (q1 < RAW_INSTR) raw_piece(cn, nb, q1, vq[1]); else if (q1 < RAW_INSTR + W_INSTR) w_piece(cn, nb, q1 - RAW_INSTR); }
+                    }
+                    if (m == 10) shadow(i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int dx = i / 6, dy = (i % 6) >> 1, g = i & 1;
+            // (hipcc left to itself issues a group's six MFMAs first and everything else behind them: the wave's next MFMA then waits for
+            // its own operand reads, DMA set-up and scalar arithmetic to issue - pinned here in the MFMAs' shadow instead)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            loads(i + 2);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (more && !(S16_ABL & 1)) {                      // the next chunk's DMA instructions (8 waves: 10 per wave, one per group; 4 waves: 19, two
+                                                               // per group) in the FIRST groups of the stage - the last one needs the rest (an HBM round trip) to land
+                constexpr int PER = NW == 8 ? 1 : 2;
+#pragma unroll
+                for (int q = PER * i; q < PER * i + PER; ++q) {
+                    if (q < RAW_INSTR) raw_piece(cn, nb, q);
+                    else if (q < RAW_INSTR + W_INSTR) w_piece(cn, nb, q - RAW_INSTR);
+                }
+            }
+            shadow(i);                                         // (tile bookkeeping rides here, behind four of the group's MFMAs)
+#if S16_INTERLEAVE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        S16_MARK(0);
+        if (!(S16_ABL & 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S16_MARK(1);
+            before_barrier();
+            lds_barrier();
+            S16_MARK(2);
+        }
+    };
+    auto nothing = [] {};
+    auto no_shadow = [](int) {};
+
+#ifdef S16_PRIO
+    if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
+#endif
+    // ---- prologue: bias, chunk 0 of the first tile
+#ifdef S16_STAMP
+    if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
+#else
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
+#endif
+    fetch_tile_uniform(t_first);
+#pragma unroll
+    for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j, fetch_lane_offset(j));
+#pragma unroll
+    for (int j = 0; j < W_INSTR; ++j) w_piece(0, 0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (A "loader + 4" form - four compute waves, one per SIMD, each 4 pixel rows x 64 couts, and a fifth wave issuing all 76 DMA
+    // instructions of a stage: 40 % less LDS operand traffic, no compute wave ever at the memory pipeline's door - was built and measured
+    // (tools/ubench/variants/conv_s16_with_loader_variant.hip, -DS16_V2): 212 us against 193 us.  Five waves put two on one SIMD, so the
+    // register budget stays 256 and only one accumulation chain fits; and a wave alone on its SIMD has nobody to cover its stalls.)
+    // (Spreading a tile's epilogue over the MFMA stream of the next tile - a second accumulator set, one piece behind every other group -
+    // was built and measured: 192 us against 187 us at 64 x 128 x 128.  On random data this kernel runs against the chip's POWER limit
+    // (all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles: the out-of-step epilogue, the
+    // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
+    // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
+    Done none;
+    none.orsrc = (i32x4){0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) none.pix[r] = RAW_OOB;
+    S16_MARK(4);
+#pragma unroll 1
+    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[1][g][r][i] = 0.0f;
+        stage(0, true, nothing, no_shadow);
+        stage(1, true, nothing, no_shadow);
+        const bool next = t_cur + t_step < t_end;
+        // the NEXT tile's fetch descriptor and origin, in the shadow of this stage's MFMA group 10 (its own DMA instructions - the last ones
+        // that use this tile's - sit in groups 0..9; the per-lane offsets are formed where each DMA instruction is issued).  Between the
+        // tiles this arithmetic cost every wave 1.5 us with the matrix pipe idle
+        stage(2, true, nothing, [&](int i) __attribute__((always_inline)) {
+            if (i == 10) fetch_tile_uniform(t_cur + t_step);
+        });
+        // The epilogue, out of step between the two waves of a SIMD.  Waves 0-3 (one per SIMD, dispatched first: the issue arbiter favours
+        // them, they finish a stage's MFMAs in 55 % of its time and idle at the barrier) run their epilogue BEFORE the last stage's barrier,
+        // under the MFMAs their SIMD partner is still issuing; waves 4-7 run theirs BEHIND it, under the partner's first MFMAs of the next
+        // tile.  The matrix pipe always has a wave feeding it; in lockstep both epilogues of a SIMD ran together with the pipe idle (21 % of
+        // a tile: tools/s16_stamps.py, profiles/r03_s16_stamps_before.txt).
+        Done d = none;
+        auto epilogue = [&]() __attribute__((always_inline)) {
+            if (!(S16_ABL & 4) || relu == 77) {
+                // the lane's 32 bias values in one burst of LDS reads (operand registers are free here): read piece by piece, each read
+                // was a round trip through an LDS the partner wave keeps busy - 16 of them made the epilogue twice as long
+                f32x4 bz4[2][4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb);
+#pragma unroll
+                for (int k = 0; k < 4 * ROWS; ++k) ep_piece(d, k, bz4);
+            }
+        };
+#if S16_EPI_LOCKSTEP
+        stage(3, next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
+        epilogue();
+#else
+        stage(3, next, [&]() __attribute__((always_inline)) { if (NW == 8 && wave < 4) epilogue(); },
+              [&](int i) __attribute__((always_inline)) { if (NW == 8 && i == 12) d = tile_done(t_cur); });
+        if (NW != 8) d = tile_done(t_cur);                    // (one wave per SIMD: its output offsets would sit in registers the stage needs)
+        if (NW != 8 || wave >= 4) epilogue();
+#endif
+        S16_MARK(3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef S16_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * NW + wave) * 5 + i] = st_sum[i];
+#endif
+}
+
+// fp32 channels_last (n, H, W, 64) -> sp16, activations scaled by `scale` (the engine's 2^8): one lane per (pixel, 8-channel block)
+__global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restrict__ x, char* __restrict__ y, int64_t HW, int64_t total, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over n * HW * 8
+    if (i >= total) return;
+    const int blk = (int)(i & 7);
+    const int64_t pix = i >> 3, n = pix / HW, p = pix - n * HW;
+    const float4 a = ld4s(x + pix * 64 + blk * 8), b = ld4s(x + pix * 64 + blk * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = v[k] * scale;
+        hi[k] = (_Float16)t;
+        lo[k] = (_Float16)(t - (float)hi[k]);
+    }
+    const int c = blk >> 1, kb = blk & 1;
+    char* base = y + n * HW * 256;
+    *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 0 + kb) * HW + p) * 16) = hi;
+    *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 2 + kb) * HW + p) * 16) = lo;
+}
+
+
+// ---- the denoisers' LAST layer on the same arithmetic: conv3x3 64 -> COUT (4: FFDNet, followed by its 2x2 pixel shuffle; 1: SimpleCNN), no bias,
+// reading the sp16 activation of the last 64->64 layer.  As a matrix product it is tiny in N, so the taps go INTO N:
+//     P[pixel q][col = 4 tap + cout] = sum_cin a[q][cin] w[tap][cin][cout]          one 32 x 32 x 16 f16 MFMA tile row per 32 pixels, K = 64 x 3 products
+//     out[pixel][cout]               = sum_tap P[pixel + (dy, dx)][4 tap + cout]      nine float4 reads of P from LDS per output pixel
+// The activation fragments go from global memory straight into the MFMA's A operand (a lane's 16 bytes of plane (c, hl, kb) ARE its
+// operand), the 36-column weight operands (16 KB as hi + lo) stay in registers for the whole workgroup, and the only LDS traffic is P.
+// The vector-ALU form of this layer (ffdnet_edges.hip: edge_tail_kernel) was bound by its scalar weight loads: 95-108 us at 64 images of
+// 128 x 128 against 45 us for reading its input once.
+constexpr int TL_H = 8, TL_W = 32, TL_IW = TL_W + 2, TL_IH = TL_H + 2, TL_PIX = TL_IH * TL_IW;      // 8 x 32 outputs, 10 x 34 = 340 halo pixels
+constexpr int TL_MB = (TL_PIX + 31) / 32;                                                      // 11 blocks of 32 halo pixels
+template <int COUT>
+__global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
+                                                       float oscale, int tiles_x, int tiles_y, int n_tiles) {
+    constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
+    __shared__ __attribute__((aligned(16))) float P[TL_PIX * PS + 32 * 36];       // (+ slack: the last pixel block writes 352 rows)
+    // Workgroup b runs on XCD b % 8: every XCD takes a contiguous range of tiles (image-major, then rows), so that the two halo rows a
+    // tile shares with the tile above and below it are re-read from THAT XCD's L2 while they are hot - with tiles dealt round-robin
+    // over the XCDs every halo row came from HBM again (10 rows fetched per 8 produced)
+#if S16_TAIL_XCD
+    const int per_xcd = (n_tiles + 7) >> 3, t = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+#else
+    const int t = (int)blockIdx.x;
+#endif
+    if (t >= n_tiles) return;
+    const int n = t / (tiles_x * tiles_y), rt = t - n * (tiles_x * tiles_y), by = rt / tiles_x;
+    const int r0 = by * TL_H, c0 = (rt - by * tiles_x) * TL_W;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
+    const int64_t HW = (int64_t)H * W;
+    const char* xn = x + (int64_t)n * HW * 256;
+    // weight operands (B: column = lane % 32 of N tile nt, k block = lane / 32): [chunk][hl][nt][lane][8 halfs]
+    h8 Bw[4][2][NT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Bw[c][hl][nt] = *reinterpret_cast<const h8*>(Wp + ((((c * 2 + hl) * NT + nt) * 64 + lane) * 16));
+    // a wave's pixel blocks mb = wave, wave + 4, wave + 8.  (Requesting the NEXT block's fragments before multiplying the current one was
+    // measured: 74.0 vs 72.3 us - the extra 32 registers cost a workgroup per CU; three resident workgroups already overlap each other.)
+    auto fetch = [&](int mb, h8 (&A)[4][2]) __attribute__((always_inline)) {
+        const int q = 32 * mb + pl, row = q / TL_IW, col = q - row * TL_IW;
+        const int gr = r0 - 1 + row, gc = c0 - 1 + col;
+        const bool ok = mb < TL_MB && q < TL_PIX && gr >= 0 && gr < H && gc >= 0 && gc < W;
+        const char* px = xn + ((int64_t)kb * HW + (int64_t)gr * W + gc) * 16;   // plane (c, hl, kb): + (4 c + 2 hl) HW 16 bytes
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ok) v = *reinterpret_cast<const h8*>(px + (int64_t)(4 * c + 2 * hl) * HW * 16);
+                A[c][hl] = v;
+            }
+    };
+    h8 A[4][2];
+#pragma unroll 1
+    for (int mb = wave; mb < TL_MB; mb += 4) {
+        fetch(mb, A);
+        f32x16 acc[NT];                                        // (K = 64 per tap column: twelve MFMAs per accumulator - one chain, cross terms first)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][1], Bw[c][0][nt], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][1][nt], acc[nt], 0, 0, 0);
+            }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[c][0], Bw[c][0][nt], acc[nt], 0, 0, 0);
+        // D: row (pixel) 8 (i >> 2) + 4 kb + (i & 3) of the block, column pl of the N tile
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int colp = 32 * nt + pl;
+            if (colp < NCOL) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) P[(32 * mb + 8 * (i >> 2) + 4 * kb + (i & 3)) * PS + colp] = acc[nt][i] * oscale;
+            }
+        }
+    }
+    __syncthreads();
+    const int lr = (int)threadIdx.x / TL_W, lc = (int)threadIdx.x % TL_W, r = r0 + lr, cc = c0 + lc;
+    float o[COUT];
+#pragma unroll
+    for (int k = 0; k < COUT; ++k) o[k] = 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const float* pp = P + ((lr + tap / 3) * TL_IW + lc + tap % 3) * PS + COUT * tap;
+        if (COUT == 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(pp);
+            o[0] += v.x; o[COUT > 1 ? 1 : 0] += v.y; o[COUT > 2 ? 2 : 0] += v.z; o[COUT > 3 ? 3 : 0] += v.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < COUT; ++k) o[k] += pp[k];
+        }
+    }
+    if (r < H && cc < W) {
+        if (COUT == 4) {        // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
+            float* op = out + (int64_t)n * 4 * HW + (int64_t)(2 * r) * (2 * W) + 2 * cc;
+            *reinterpret_cast<f32x2*>(op) = (f32x2){o[0], o[COUT > 1 ? 1 : 0]};
+            *reinterpret_cast<f32x2*>(op + 2 * W) = (f32x2){o[COUT > 2 ? 2 : 0], o[COUT > 3 ? 3 : 0]};
+        } else {
+            out[(int64_t)n * HW + (int64_t)r * W + cc] = o[0];
+        }
+    }
+}
+
+
+// ---- FFDNet's FIRST layer on the same arithmetic, writing sp16: concatenate_input_noise_map (functions.py:16-53: sigma map + 2x2
+// pixel-unshuffle, channel 2i+j) + conv3x3(5 -> 64, pad 1, no bias) + ReLU.  K = 5 channels x 9 taps = 45 (padded to 48 = three MFMA k
+// steps); the B operand (k x 32 positions) is GATHERED: lane (position, k block) reads its eight taps from the full-resolution patch /
+// the sigma plane in LDS, multiplies by 2^8 and splits them into hi + lo fp16 on the fly; the weight operands (12 fragments) stay in
+// registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
+constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
+__global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
+                                                       int sigma_stride, char* __restrict__ y, int H, int W, float oscale) {
+    __shared__ __attribute__((aligned(16))) float patch[HS_P * HS_QS + (HS_H + 2) * HS_SS];
+    constexpr int SGM = HS_P * HS_QS;
+    const int n = blockIdx.z, r0 = blockIdx.y * HS_H, c0 = blockIdx.x * HS_W;
+    const int H2 = 2 * H, W2 = 2 * W;
+    const float* xn = x + (int64_t)n * H2 * W2;
+    // full-resolution pixels (2 r0 - 2 + pr, 2 c0 - 2 + pc): half-res position (r, c), sub-pixel (i, j), tap (dy, dx) reads
+    // (2 (r + dy - 1) + i, 2 (c + dx - 1) + j); zero outside the image = the conv's zero padding of the unshuffled channels
+    for (int e = threadIdx.x; e < HS_P * HS_Q; e += 256) {
+        const int pr = e / HS_Q, pc = e - pr * HS_Q;
+        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
+        patch[pr * HS_QS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
+    }
+    const float sig = sigma[(int64_t)n * sigma_stride];
+    for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
+        const int pr = e / HS_SW, pc = e - pr * HS_SW;
+        const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
+        patch[SGM + pr * HS_SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+    }
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
+    // this lane's 24 taps: k = 16 ks + 8 kb + j = 9 ch + tap (k >= 45: zero weight, any address): LDS float offset relative to the
+    // position's patch origin (2 lr, 2 lc) / sigma origin (lr, lc)
+    int off[3][8];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * kb + j, kk = k < 45 ? k : 0;
+            const int ch = kk / 9, tap = kk - 9 * ch, dy = tap / 3, dx = tap - 3 * dy;
+            off[ks][j] = ch == 0 ? SGM + dy * HS_SS + dx + pl : (2 * dy + ((ch - 1) >> 1)) * HS_QS + 2 * dx + ((ch - 1) & 1) + 2 * pl;
+        }
+    h8 Aw[3][2][2];                                            // weights: [k step][hi, lo][cout group]
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) Aw[ks][hl][g] = *reinterpret_cast<const h8*>(Wp + ((((ks * 2 + hl) * 2 + g) * 64 + lane) * 16));
+    __syncthreads();
+    const int64_t HW = (int64_t)H * W;
+    i32x4 orsrc;
+    {
+        const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
+        orsrc.x = (int)uniform((uint32_t)ob);
+        orsrc.y = (int)uniform((uint32_t)(ob >> 32));
+        orsrc.z = (int)uniform((uint32_t)(HW * 256));
+        orsrc.w = 0x00020000;
+    }
+#pragma unroll 1
+    for (int lr = wave; lr < HS_H; lr += 4) {
+        const int sbase = lr * HS_SS, pbase = 2 * lr * HS_QS;
+        h8 Bh[3], Bl[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            f32x2 v[4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * kb + j;
+                const bool is_sigma = (k < 45 ? k : 0) < 9;      // (sigma taps live in their own plane; per lane: k depends on its k block)
+                v[j >> 1][j & 1] = patch[off[ks][j] + (is_sigma ? sbase : pbase)] * SP_SCALE;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const h2 hh = __builtin_convertvector(v[e], h2);
+                const h2 ll = __builtin_convertvector(v[e] - __builtin_convertvector(hh, f32x2), h2);
+                Bh[ks][2 * e] = hh.x; Bh[ks][2 * e + 1] = hh.y;
+                Bl[ks][2 * e] = ll.x; Bl[ks][2 * e + 1] = ll.y;
+            }
+        }
+        f32x16 acc[2];                                          // (K = 48: nine MFMAs per accumulator - one chain, cross terms first)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[g][i] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][1][g], Bh[ks], acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bl[ks], acc[g], 0, 0, 0);
+            }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bh[ks], acc[g], 0, 0, 0);
+        // D[g][i]: cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of position (r0 + lr, c0 + pl): ReLU, x 2^8, split, lane exchange, sp16 stores
+        const int r = r0 + lr, c = c0 + pl;
+        const uint32_t pix = (r < H && c < W) ? (uint32_t)((kb * (int)HW + r * W + c) * 16) : RAW_OOB;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
+                    f32x2 t = (f32x2){acc[g][i], acc[g][i + 1]} * (f32x2){oscale, oscale};
+                    t.x = __builtin_elementwise_maximum(t.x, 0.0f);
+                    t.y = __builtin_elementwise_maximum(t.y, 0.0f);
+                    const h2 hh = __builtin_convertvector(t, h2);
+                    hi[e] = __builtin_bit_cast(unsigned, hh);
+                    lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t - __builtin_convertvector(hh, f32x2), h2));
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    auto sh = __builtin_amdgcn_permlane32_swap(hi[e], hi[2 + e], false, false);
+                    hi[e] = sh[0]; hi[2 + e] = sh[1];
+                    auto sl = __builtin_amdgcn_permlane32_swap(lo[e], lo[2 + e], false, false);
+                    lo[e] = sl[0]; lo[2 + e] = sl[1];
+                }
+                const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
+                const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
+                const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(oh), "v"(pix), "s"(orsrc), "s"(so_h) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
+            }
+    }
+}
+
+}  // namespace s16
+}  // namespace deqsci
+
+using namespace deqsci;
+
+static void s16_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
+    uint32_t s = 0;
+    while ((1ull << s) < d) ++s;
+    *sh = 31 + s;
+    *mg = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
+}
+
+extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y, int64_t n, int64_t H, int64_t W,
+                                          int relu, float out_scale, float bias_scale, int out_f32, deqsci_stream_t stream, void* start_event,
+                                          void* stop_event) {
+    if (!x_sp16 || !w_packed || !y) return DEQSCI_ERR_NULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (x_sp16 == y || (out_f32 != 0 && out_f32 != 1)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    // 32-bit byte offsets inside one image, and the out-of-range sentinel 2^31 must lie beyond the descriptor's range
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t resident = (int64_t)num_cus();
+    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
+    hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
+#define S16_LAUNCH(KERNEL)                                                                                                                  \
+    hipExtLaunchKernelGGL(KERNEL, grid, dim3(64 * S16_GEOM_NW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
+                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, bias_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img,    \
+                          sh_img, \
+                          mg_tx, sh_tx)
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, S16_GEOM_NW, 16 / S16_GEOM_NW>)); else S16_LAUNCH((s16::conv_s16_kernel<0, S16_GEOM_NW, 16 / S16_GEOM_NW>));
+#undef S16_LAUNCH
+    return launch_status();
+}
+
+extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream) {
+    if (!x_nhwc || !y_sp16) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (!aligned16(x_nhwc) || !aligned16(y_sp16)) return DEQSCI_ERR_ALIGN;
+    const int64_t total = n * H * W * 8;
+    hipLaunchKernelGGL(s16::f32_to_sp16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_nhwc,
+                       static_cast<char*>(y_sp16), H * W, total, scale);
+    return launch_status();
+}
+
+template <int COUT>
+static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+    if (!x_sp16 || !w_packed || !out) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, s16::TL_W), tiles_y = ceil_div(H, s16::TL_H), n_tiles = n * tiles_x * tiles_y;
+    if (n_tiles > (1 << 30)) return DEQSCI_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)(8 * ceil_div(n_tiles, 8)));
+    hipLaunchKernelGGL(s16::tail_s16_kernel<COUT>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
+                       static_cast<const char*>(w_packed), out, (int)H, (int)W, out_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles);
+    return launch_status();
+}
+
+extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                                          deqsci_stream_t stream) {
+    return tail_s16_impl<4>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+}
+
+extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
+                                               deqsci_stream_t stream) {
+    return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+}
+
+extern "C" int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
+                                          int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+    if (!x || !w_packed || !sigma || !h_sp16) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || H * W * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(w_packed) || !aligned16(h_sp16)) return DEQSCI_ERR_ALIGN;
+    const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
+    hipLaunchKernelGGL(s16::head_s16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                       (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, out_scale);
+    return launch_status();
+}
