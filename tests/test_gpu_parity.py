@@ -777,6 +777,16 @@ def test_engine_warns_when_split16_overflows():
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         assert torch.equal(auto.reconstruct(y, Phi), rec32)
+    # the same through the hipGraph path (one measurement per call, the reference's usage): eager + fallback, then capture, then replay
+    g = DEQSCIEngine(net, max_iter=6, use_graph=True)
+    with pytest.warns(RuntimeWarning, match="fp16's range"):
+        first = g.reconstruct(y, Phi)
+    assert torch.equal(first, rec32) and g.conv64_policy == "fast32"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for _ in range(3):
+            assert torch.equal(g.reconstruct(y, Phi), rec32)
+    assert g.last_info["graph"] is True
 
 
 def test_split16_overflow_is_loud():
