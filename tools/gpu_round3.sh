@@ -19,6 +19,7 @@ timeout 300 python tools/s16_check.py both 2>&1 | grep -v amdgpu > $O/r03_s16_ch
 timeout 600 python tools/conv_error_real.py 2>/dev/null > /dev/null; cp gpurun_out/conv_error_real.json $O/r03_conv_error_real.json
 timeout 600 python tools/fcall_error_along_loop.py 2>/dev/null > /dev/null; cp gpurun_out/fcall_error_along_loop.json $O/r03_fcall_error_along_loop.json
 ./build/ub/mfma_f16_numerics > $O/r03_mfma_f16_numerics.txt 2>&1
+for k in s16 f44 f22; do PROBE_KERNEL=$k timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1; done > $O/r03_power_probe_kernels.jsonl
 if ! skip ensembles; then
   DEQSCI_ENSEMBLE_HYBRID=40 DEQSCI_ENSEMBLE_SEEDS=25 DEQSCI_ENSEMBLE_TRAFFIC_ONLY=1 timeout 2400 python tools/config2_ensemble.py > $O/r03_config2_ensembles.log 2>&1
   cp gpurun_out/config2_ensemble.json $O/r03_config2_ensembles.json
