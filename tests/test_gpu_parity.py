@@ -1042,16 +1042,16 @@ def test_config2_ffdnet_anderson_180_all_measurements():
       build: 25 starts per measurement through the engine.
     Bounds are STATISTICAL, computed from the two ensembles themselves, not hand-set:
       * the mean over the six chaotic measurements of the per-measurement ensemble means: within 3 standard errors of the
-        difference from the exact-Gram reference (observed -0.014 dB at SE 0.0086), and from the reference AS IT IS within 3 SE
-        plus the shift the reference itself shows between its two Gram variants (0.012 dB);
+        difference from the exact-Gram reference (observed -0.006 dB at SE 0.0087), and from the reference AS IT IS within 3 SE
+        plus the shift the reference itself shows between its two Gram variants (0.021 dB);
       * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean PLUS the distance between the
         reference's own two variants on that measurement.  (The x0-ensemble samples the chaos, not the implementation: ANY change of
         arithmetic moves single measurements by more than their ensemble SE of ~0.01-0.02 dB, in both directions - the reference's
-        Gram variants differ by -0.03 .. +0.14 dB per measurement (RMS 0.06), this build with F(2x2,3x3) / with MIOpen's direct
+        Gram variants differ by -0.03 .. +0.15 dB per measurement (RMS 0.065), this build with F(2x2,3x3) / with MIOpen's direct
         convolution sits at +0.01 / -0.09 dB on m0 and -0.09 / +0.00 dB on m2 (profiles/r03_config2_ensembles.json); the six-measurement
         mean above averages that out and is the statistic with power.)  Median PSNR / residual inside the hull of both reference
         ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than 1.5 hull widths outside;
-      * the RMS over the six of (build mean - exact-Gram reference mean) no larger than the same RMS for the reference as it is (0.060 dB):
+      * the RMS over the six of (build mean - exact-Gram reference mean) no larger than the same RMS for the reference as it is (0.065 dB):
         the build deviates from the exact-arithmetic reference less than the shipped reference does;
       * well-conditioned measurements (drop8, runner8: reference bands of 2 and 25 mdB): ensemble mean within 0.01 dB (+ 3 SE) of the
         reference's, every one of the 25 runs within 1.5 reference hull widths of the reference's 9-10 run hull;
@@ -1078,9 +1078,14 @@ def test_config2_ffdnet_anderson_180_all_measurements():
                 ps.append(psnr(rec.clamp(0, 1).cpu().numpy()[0], gt))
                 rs.append(eng.last_info["res"])
             base_by_clip.setdefault(clip["file"], []).append(ps[0])
-            ra = [v["psnr"] for v in a["measurements"][mid]["variants"].values()]
-            rb = [v["psnr"] for v in b["measurements"][mid]["variants"].values()]
-            ea = [v["res"] for v in a["measurements"][mid]["variants"].values()] + [v["res"] for v in b["measurements"][mid]["variants"].values()]
+            # (the as-is file carries one extra row, "gram_fp64": the unperturbed start with an exact Gram - it belongs to the other ensemble)
+            va = {k: v for k, v in a["measurements"][mid]["variants"].items() if k != "gram_fp64"}
+            vb = dict(b["measurements"][mid]["variants"])
+            if "gram_fp64" in a["measurements"][mid]["variants"] and "g64_base" not in vb:
+                vb["gram_fp64"] = a["measurements"][mid]["variants"]["gram_fp64"]
+            ra = [v["psnr"] for v in va.values()]
+            rb = [v["psnr"] for v in vb.values()]
+            ea = [v["res"] for v in va.values()] + [v["res"] for v in vb.values()]
             report.append((mid, ps, rs, ra, rb, ea))
     chaotic = []
     for mid, ps, rs, ra, rb, ea in report:
@@ -1114,7 +1119,7 @@ def test_config2_ffdnet_anderson_180_all_measurements():
     assert abs(mb - mx) <= 3 * se_x, (mb, mx, se_x)
     assert abs(mb - ma_) <= 3 * se_a + abs(ma_ - mx), (mb, ma_, se_a)
     # and measurement by measurement the build sits closer to the exact-Gram reference than the reference AS IT IS does (RMS over the six
-    # of the differences of ensemble means; the reference's own two variants: 0.060 dB): the yardstick for "implementation-level" offsets
+    # of the differences of ensemble means; the reference's own two variants: 0.065 dB): the yardstick for "implementation-level" offsets
     rms = lambda k: float(np.sqrt(np.mean([(np.mean(c[k]) - np.mean(c[2])) ** 2 for c in chaotic])))
     print("per-measurement offsets from the exact-Gram reference, RMS: build %.4f dB, reference as it is %.4f dB" % (rms(0), rms(1)))
     assert rms(0) <= rms(1) + pooled_se(0), (rms(0), rms(1))
