@@ -282,5 +282,11 @@ def test_config2_exact_gram_spread_file():
     for mid, m in g["measurements"].items():
         assert "g64_base" in m["variants"] and len([k for k in m["variants"] if k.startswith("g64_seed")]) >= 8
         assert m["f_calls"] == 182 and m["psnr_min"] <= m["variants"]["g64_base"]["psnr"] <= m["psnr_max"]
-    m2a, m2g = a["measurements"]["traffic_cacti.mat:2"], g["measurements"]["traffic_cacti.mat:2"]
-    assert m2g["psnr_max"] < min(v["psnr"] for k, v in m2a["variants"].items() if k != "gram_fp64")   # disjoint from the fp32 runs
+    # on measurement 2 the two variants of the reference are different populations (25 runs each: 21.53 vs 21.40 dB, > 5 standard errors of
+    # the difference; with the first 9 runs each the hulls were even disjoint): an implementation-level change of arithmetic moves a single
+    # chaotic measurement by more than its ensemble error - the point of having the second ensemble, and of gating on pooled means
+    import numpy as np
+    pa = np.array([v["psnr"] for k, v in a["measurements"]["traffic_cacti.mat:2"]["variants"].items() if k != "gram_fp64"])
+    pg = np.array([v["psnr"] for v in g["measurements"]["traffic_cacti.mat:2"]["variants"].values()])
+    se = float(np.hypot(pa.std(ddof=1) / np.sqrt(len(pa)), pg.std(ddof=1) / np.sqrt(len(pg))))
+    assert pa.mean() - pg.mean() > 5 * se and pa.mean() - pg.mean() > 0.08, (pa.mean(), pg.mean(), se)
