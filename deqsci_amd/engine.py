@@ -278,7 +278,7 @@ class DEQSCIEngine:
         # F(2x2,3x3)); "f22" / "f44" / "s16" one kernel always.  `conv64_f22_calls=K` additionally runs the first K f-calls on F(2x2,3x3).
         # What the choice does to the result was measured where it can matter - FFDNet under Anderson beyond ~30 iterations is chaotic
         #  - as 25-start ensembles over the six traffic measurements (tools/config2_ensemble.py,
-        # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.008 (as it is 21.454); F(2x2,3x3)
+        # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.008 (as it is 21.439 +- 0.005); F(2x2,3x3)
         # 21.420; split-fp16 21.428; F(2x2,3x3) for 40 f-calls then F(4x4,3x3) 21.417; MIOpen's direct fp32 convolution 21.410;
         # F(4x4,3x3) throughout 21.395.  Single measurements move by up to 0.09 dB under ANY change of arithmetic (the reference's own two
         # Gram variants: RMS 0.065 dB), so only the pooled mean separates kernels; it puts split-fp16 and F(2x2,3x3) together, nearest

@@ -1007,8 +1007,8 @@ def test_png_payloads_vs_reference(kind):
 
 
 def _config2_reference():
-    """The two reference ensembles of make_golden g10 (FFDNet, Anderson @180): the reference as it is (fp32 torch.bmm Gram, 9 runs per
-    measurement) and with the Gram matrix of :178 computed exactly (25 runs per `traffic` measurement, 9 on drop8 / runner8)."""
+    """The two reference ensembles of make_golden g10 (FFDNet, Anderson @180): the reference as it is (fp32 torch.bmm Gram) and
+    with the Gram matrix of :178 computed exactly (25 runs per `traffic` measurement each, 9-10 on drop8 / runner8)."""
     with open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")) as fh:
         a = json.load(fh)
     with open(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json")) as fh:
@@ -1035,15 +1035,15 @@ def test_config2_ffdnet_anderson_180_all_measurements():
     The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0),
     so one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and
     x0 (1 + 1e-7 randn), seeds 1.. - on both sides:
-      reference (generated by importing it, make_golden g10): as it is (9 runs per measurement), and with the Gram matrix of :178
-        computed exactly (25 runs per chaotic measurement: seeds 1-24).  The second exists because the reference's fp32 torch.bmm Gram carries ~1e-6 of rounding error at
+      reference (generated by importing it, make_golden g10): as it is, and with the Gram matrix of :178
+        computed exactly (25 runs per chaotic measurement each: seeds 1-24; 9-10 on drop8 / runner8).  The second exists because the reference's fp32 torch.bmm Gram carries ~1e-6 of rounding error at
         N = 2^19, which the ill-conditioned Anderson system turns into ~5e-4 of noise on alpha; this build sums the Gram partials
         in float64 and belongs to the second ensemble (deviation 3).
       build: 25 starts per measurement through the engine.
     Bounds are STATISTICAL, computed from the two ensembles themselves, not hand-set:
       * the mean over the six chaotic measurements of the per-measurement ensemble means: within 3 standard errors of the
         difference from the exact-Gram reference (observed -0.006 dB at SE 0.0057: 3 SE = 0.017), and from the reference AS IT IS within 3 SE
-        plus the shift the reference itself shows between its two Gram variants (0.021 dB);
+        plus the shift the reference itself shows between its two Gram variants (0.005 dB);
       * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean PLUS the distance between the
         reference's own two variants on that measurement.  (The x0-ensemble samples the chaos, not the implementation: ANY change of
         arithmetic moves single measurements by more than their ensemble SE of ~0.01-0.02 dB, in both directions - the reference's
