@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py - headline metric of BASELINE.json on MI355X: reconstructed frames/s at 256x256x8,
 180 DEQ (Anderson) iterations, FFDNet denoiser, plus the MFMA roofline of the dominant kernel (the
-Winograd 64->64 conv of the denoiser), the HBM roofline of the fused Phi/Phi^T + GAP-update kernel and the
-reference algorithm timed on the host CPU.
+denoiser's 64->64 layers: the split-fp16 direct convolution on the f16 matrix cores under the default policy), the HBM
+roofline of the fused Phi/Phi^T + GAP-update kernel, a parity spot check of the very configuration that is timed against
+the CPU oracle, and the reference algorithm timed on the host CPU.
 
     python bench.py --gpus N --steps K --warmup W          # N > 1: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -60,6 +61,38 @@ def make_batch(lo, hi, H, W, B, seed, device):
         x[j] = torch.rand(H, W, B, device=device, generator=g)
     y = (x * Phi).sum(3)
     return y, Phi, x
+
+
+def parity_spot_check(args, dev, H, W, B, n_meas=2, iters=10):
+    """Outside the timed region: the first `n_meas` measurements of the synthetic batch that is timed (same seeds, same size, same
+    denoiser), `iters` Anderson iterations on a fresh default engine (its 64->64 layers on the kernel the policy picks at this size:
+    named in the result), against the CPU oracle's restatement of the reference (video_sci_proxgrad.py:210-245 wiring)."""
+    from oracle import deqsci_oracle as orc
+    from deqsci_amd import _hip
+    saved = args.iters
+    args.iters = iters
+    try:
+        eng = build_engine(args, dev)
+    finally:
+        args.iters = saved
+    y, Phi, _ = make_batch(0, n_meas, H, W, B, 1234, dev)
+    kinds = set()
+    hook, _hip.CONV64_EVENT_HOOK = _hip.CONV64_EVENT_HOOK, (lambda k, n, h, w: kinds.add(k))
+    try:
+        rec = eng.reconstruct(y, Phi).cpu()
+    finally:
+        _hip.CONV64_EVENT_HOOK = hook
+    yc, Pc = y.cpu(), Phi.cpu()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    worst = 0.0
+    for i in range(n_meas):
+        Ps = orc.phi_sum(Pc[i:i + 1])
+        want, _ = orc.deq_forward(orc.ProxGradSCI(args.denoiser), orc.andersonexp, yc[i:i + 1], Pc[i:i + 1], Ps, orc.initial_point(yc[i:i + 1], Pc[i:i + 1]),
+                                  m=5, beta=1.0, lam=1e-2, max_iter=iters, tol=1e-5)
+        worst = max(worst, float((rec[i:i + 1] - want).norm() / want.norm()))
+    return {"rel_l2": worst, "bound": 1e-4, "ok": worst < 1e-4, "conv64_kernels": sorted(kinds),
+            "what": f"measurements 0..{n_meas - 1} of the timed synthetic batch ({H}x{W}x{B}, {args.denoiser}), and_maxiters={iters}, default engine "
+                    f"vs the CPU oracle (worst rel-L2 over the measurements; chaos-free horizon, SURVEY F9)"}
 
 
 def cpu_baseline(iters_sample, full_calls, H, W, B, kind):
@@ -156,7 +189,9 @@ def parse_args(argv=None):
                     help="kernel of the 64->64 layers (DEQSCIEngine): auto = fast = split-fp16 direct convolution on the f16 matrix cores "
                          "where it is faster, Winograd F(2x2,3x3) below; fast32 = fp32 MFMA arithmetic only (F(4x4,3x3) / F(2x2,3x3))")
     ap.add_argument("--conv64-f22-calls", type=int, default=None, help="run the first K f-calls on F(2x2,3x3) whatever the policy")
-    ap.add_argument("--no-other-kernel", action="store_true", help="skip the one extra step with the other conv64 policy")
+    ap.add_argument("--no-other-kernel", action="store_true", help="skip the extra steps under the other conv64 policies")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other conv64 policy (behind one warm-up step)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the timed configuration (2 measurements, 10 iterations)")
     ap.add_argument("--iters", type=int, default=180)
     ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
     ap.add_argument("--size", default="256x256x8")
@@ -276,6 +311,7 @@ def run_rank(args):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     if timing:
         timing_on[0] = False
     if world > 1:
@@ -283,6 +319,19 @@ def run_rank(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: what proves, on the first hardware run, that the collective library saw N ranks on N different devices - gathered once,
+    # outside the timed region
+    ranks_info = None
+    if world > 1:
+        mine = {"rank": rank, "local_rank": local_rank, "device": str(dev), "ms_per_step": 1e3 * local_elapsed / max(args.steps, 1),
+                "measurements": [lo, hi]}
+        if dev.type == "cuda":
+            props = torch.cuda.get_device_properties(dev)
+            mine.update({"name": props.name, "uuid": str(getattr(props, "uuid", "")), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                         "pci_device_id": getattr(props, "pci_device_id", None), "compute_units": props.multi_processor_count})
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = gathered
     frames = M * B * args.steps
     value = frames / elapsed
     info = eng.last_info or {}                                               # (an idle rank - more GPUs than measurements - never ran)
@@ -291,25 +340,31 @@ def run_rank(args):
         "metric": "reconstructed frames/sec at 256x256x8, 180 DEQ iters",
         "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (tensors and accumulation; the 64->64 layers' products as split-fp16 MFMAs, see arithmetic)", "data": "synthetic",
         "config": {"workload": (f"synthetic batch of {M} measurements sharded over {world} GPU(s) ({per} per GPU; BASELINE config 3 as stated), "
                                 if strong else f"synthetic batch of {per} measurements per GPU, ") + f"{H}x{W}x{B}, Bernoulli(0.5) masks "
                                f"(BASELINE config 3 per-GPU shard = config 2's 8 measurements at N=1); "
                                f"{args.denoiser} denoiser ({'net_gray.pth weights, substitute for the missing ffdnet.ckpt' if args.denoiser == 'ffdnet' else 'cnn.ckpt'}), "
                                f"Anderson m=5 lam=1e-2 beta=1, and_maxiters={args.iters}, tol=1e-5",
                    "global_batch": M, "batch_per_gpu": per, "frames_per_measurement": B, "f_calls_per_step": f_calls,
+                   "f_calls_reference": args.iters + 2,            # new_equilibrium_utils_yaping.py:259-272: max_iter + 2, the last one dead (:271-272)
                    "conv64_policy": None if selftest else (f"{eng.conv64} -> F(2x2,3x3) for f-calls < {eng.conv64_f22_calls}, then {eng.conv64_policy}"
                                                            if eng.conv64_f22_calls else f"{eng.conv64} -> {eng.conv64_policy}"),
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU",
                    "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches"},
         "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  64->64 conv layers under conv64 policy 'fast' (default): products on the f16 matrix "
                        "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, two fp32 accumulation "
-                       "chains); rounding per layer against float64 on FFDNet's own data 1.6e-7 (fp32 Winograd F(2x2,3x3) 2.0e-7, MIOpen's fp32 direct "
-                       "convolution 3.5e-7: profiles/r03_conv_error_real.json).  other_conv64_policies gives the same step on fp32-MFMA kernels only."),
+                       "chains; the power-of-two scale of every activation follows max |activation| measured on the device at the first f-call, so "
+                       "the path is scale-free like fp32); rounding per layer against float64 on FFDNet's own data 1.6e-7 (fp32 Winograd F(2x2,3x3) "
+                       "2.0e-7, MIOpen's fp32 direct convolution 3.5e-7: profiles/r03_conv_error_real.json).  other_conv64_policies gives the same "
+                       "step on fp32-MFMA kernels only."),
         "final_res": info.get("res"),
         "allgather_ms_per_step": 1e3 * gather_timer.total_seconds() / max(args.steps, 1) if world > 1 else 0.0,
         "allgather_bytes_per_step": world * per * H * W * B * 4 if world > 1 else 0,      # what every rank receives: (R*per,H,W,B) fp32
     }
+    if world > 1:
+        out["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": ranks_info,
+                              "distinct_devices": len({(r.get("uuid") or r.get("pci_bus_id") or r["device"]) for r in ranks_info})}
     if args.ranks_share_gpu0:
         out["data"] = "synthetic; TEST RIG: all ranks share cuda:0 over gloo - not a throughput measurement"
     if selftest:
@@ -321,7 +376,7 @@ def run_rank(args):
             avg_s = 1e-3 * sum(ms) / len(ms)
             nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
             traffic = None
-            for tname in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
+            for tname in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
                 tfile = os.path.join(ROOT, "profiles", tname)
                 if traffic is None and os.path.exists(tfile):
                     with open(tfile) as fh:
@@ -351,7 +406,7 @@ def run_rank(args):
             cavg = 1e-3 * sum(cms) / len(cms)
             share = cavg * conv_launches[kind] / elapsed
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            for wname in {"s16": ("r03_pmc_conv_s16.json",), "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
+            for wname in {"s16": ("r04_pmc_conv_s16.json", "r03_pmc_conv_s16.json"), "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
                           "f22": ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")}[kind]:
                 wfile = os.path.join(ROOT, "profiles", wname)
                 if wtraffic is None and os.path.exists(wfile):
@@ -366,7 +421,10 @@ def run_rank(args):
             forms[kind] = {"kernel": kname,
                            "bound": "mfma", "achieved": direct * mult / cavg / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": direct * mult / cavg / 1e12 / peak, "traffic": wtraffic,
-                           "algorithmic_flops_per_launch": direct * mult, "direct_conv_equivalent_TFLOPs": direct / cavg / 1e12,
+                           # executed = the MFMA flops the kernel's algorithm issues (what `achieved` / `frac` price: matrix-pipe utilisation);
+                           # algorithmic = the direct-convolution flops of the layer, SURVEY 8(d) / section 6 (`frac_useful`)
+                           "executed_mfma_flops_per_launch": direct * mult, "algorithmic_flops_per_launch": direct,
+                           "achieved_useful": direct / cavg / 1e12, "frac_useful": direct / cavg / 1e12 / peak,
                            "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "launches_per_step": conv_launches[kind] // max(args.steps, 1),
                            "share_of_step_time": round(share, 3),
                            "note": {"s16": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; on random operands the kernel runs against the chip's power limit "
@@ -388,8 +446,9 @@ def run_rank(args):
                 ct.close()
         if world == 1 and not selftest:
             if not args.no_other_kernel and not args.no_winograd:
-                # the same step under the OTHER conv64 policies, once each, outside the timed region: what the all-fp32-MFMA paths deliver on
-                # this very box (the reader who does not accept split-fp16 operands as fp32 arithmetic takes "fast32 + F(2x2) for 40 f-calls")
+                # the same step under the OTHER conv64 policies, `--other-steps` timed steps each behind a warm-up step, outside the timed region:
+                # what the all-fp32-MFMA paths deliver on this very box, sustained (the reader who does not accept split-fp16 operands as fp32
+                # arithmetic takes "fast32")
                 out["other_conv64_policies"] = {}
                 for name, pol, k in (("fast32", "fast32", None), ("fast32, first 40 f-calls on F(2x2,3x3)", "fast32", 40), ("f22", "f22", None)):
                     if pol == eng.conv64_policy and k == eng.conv64_f22_calls:
@@ -399,14 +458,18 @@ def run_rank(args):
                     step2()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    step2()
+                    for _ in range(args.other_steps):
+                        step2()
                     torch.cuda.synchronize()
-                    dt2 = time.perf_counter() - t1
-                    out["other_conv64_policies"][name] = {"value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": 1}
+                    dt2 = (time.perf_counter() - t1) / args.other_steps
+                    out["other_conv64_policies"][name] = {"value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": args.other_steps,
+                                                          "warmup": 1}
                     del eng2, step2
             if not args.no_hbm_stream:
                 del y, Phi
                 out["hbm_stream_roofline"] = hbm_stream_roofline(H, W, B, eng.m, dev)
+            if not args.no_parity_check:
+                out["parity_spot_check"] = parity_spot_check(args, dev, H, W, B)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_iters, f_calls, H, W, B, args.denoiser)
         print(json.dumps(out), flush=True)

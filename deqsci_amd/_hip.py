@@ -45,15 +45,13 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _f32, _f32, _int, _ptr, _ptr, _ptr],
-    "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
-    "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
-    "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _f32, _ptr],
-    "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _f32, _ptr],
-    "deqsci_ffdnet_head_sp16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
-    "deqsci_ffdnet_tail_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
-    "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr],
-    "deqsci_conv3x3_c64_to_1_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
+    "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
+    "deqsci_absmax_f32": [_ptr, _i64, _ptr, _ptr],
+    "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
+    "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr, _ptr],
+    "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
+    "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
@@ -312,15 +310,9 @@ def pack_tail_weights(w):
 
 
 def ffdnet_tail(h, w_packed, out=None, in_bias=None):
-    """h (n,64,H,W) channels_last, or an Sp16 -> planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h', w, pad=1), 2) with
-    h' = h, or relu(h + in_bias[c]) when in_bias is given (previous layer's epilogue fused into the read; fp32 input only)."""
-    if isinstance(h, Sp16):
-        if in_bias is not None:
-            raise DeqsciHipError("ffdnet_tail: in_bias is not supported with an Sp16 input")
-        o = out if out is not None else torch.empty((h.n, 1, 2 * h.H, 2 * h.W), device=h.t.device, dtype=torch.float32)
-        with _dev(h.t):
-            _check(load().deqsci_ffdnet_tail_sp16(h.t.data_ptr(), _p(w_packed, "w_packed"), _p(o, "out"), h.n, h.H, h.W, _stream()), "ffdnet_tail_sp16")
-        return o
+    """h (n,64,H,W) channels_last -> planar noise (n,1,2H,2W) = pixel_shuffle(conv3x3(h', w, pad=1), 2) with
+    h' = h, or relu(h + in_bias[c]) when in_bias is given (previous layer's epilogue fused into the read).  (An Sp16 activation goes to
+    tail_split16.)"""
     n, c, H, W = h.shape
     if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
         raise DeqsciHipError("ffdnet_tail: fp32 channels_last GPU activation with 64 channels required")
@@ -339,14 +331,8 @@ def pack_c64_to_1_weights(w):
 
 
 def conv3x3_c64_to_1(h, w_packed, out=None, in_bias=None):
-    """h (n,64,H,W) channels_last, or an Sp16 -> planar (n,1,H,W) = conv3x3(h', w, pad=1), h' = h or relu(h + in_bias[c])."""
-    if isinstance(h, Sp16):
-        if in_bias is not None:
-            raise DeqsciHipError("conv3x3_c64_to_1: in_bias is not supported with an Sp16 input")
-        o = out if out is not None else torch.empty((h.n, 1, h.H, h.W), device=h.t.device, dtype=torch.float32)
-        with _dev(h.t):
-            _check(load().deqsci_conv3x3_c64_to_1_sp16(h.t.data_ptr(), _p(w_packed, "w_packed"), _p(o, "out"), h.n, h.H, h.W, _stream()), "conv3x3_c64_to_1_sp16")
-        return o
+    """h (n,64,H,W) channels_last -> planar (n,1,H,W) = conv3x3(h', w, pad=1), h' = h or relu(h + in_bias[c]).  (An Sp16 activation
+    goes to tail_split16.)"""
     n, c, H, W = h.shape
     if c != 64 or not h.is_contiguous(memory_format=torch.channels_last) or h.dtype != torch.float32 or not h.is_cuda:
         raise DeqsciHipError("conv3x3_c64_to_1: fp32 channels_last GPU activation with 64 channels required")
@@ -364,16 +350,18 @@ def pack_c1_to_64_weights(w):
     return w.detach().float().reshape(16, 4, 9).permute(2, 0, 1).contiguous()
 
 
-def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False):
-    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True)."""
+def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False, out_rng=None, out_exp=None, track=None):
+    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True) with the
+    range (out_rng, out_exp); track: a range slot that receives max |output| (the measurement of the first f-call)."""
     n, c, H, W = x.shape
     if c != 1:
         raise DeqsciHipError(f"conv3x3_c1_to_64: (n,1,H,W) image required, got {tuple(x.shape)}")
     if sp16:
         o = out if out is not None else Sp16.empty(n, H, W, x.device)
+        o.rng, o.exp = out_rng, SP16_DEFAULT_EXP if out_exp is None else int(out_exp)
         with _dev(x):
             _check(load().deqsci_conv3x3_c1_to_64_sp16(_p(x, "x"), _p(w_packed, "w_packed"), o.t.data_ptr(), n, H, W, 1 if relu else 0,
-                                                       _stream()), "conv3x3_c1_to_64_sp16")
+                                                       _rng(o.rng), o.exp, _rng(track), _stream()), "conv3x3_c1_to_64_sp16")
         return o
     o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     with _dev(x):
@@ -389,21 +377,15 @@ def pack_head_weights(w):
     return w.detach().float().reshape(16, 4, 45).permute(2, 0, 1).contiguous()
 
 
-def ffdnet_head(x, w_packed, sigma, out=None, sp16=False):
+def ffdnet_head(x, w_packed, sigma, out=None):
     """x (n,1,2H,2W) planar, sigma (n,) or (1,) -> relu(conv3x3(cat(sigma map, pixel_unshuffle(x,2)), w)) as a
-    channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True: what a run of split-fp16 64->64 layers consumes)."""
+    channels_last (n,64,H,W) activation.  (In front of a run of split-fp16 layers: ffdnet_head_split16.)"""
     n, c, H2, W2 = x.shape
     if c != 1 or H2 % 2 or W2 % 2:
         raise DeqsciHipError(f"ffdnet_head: (n,1,even,even) image required, got {tuple(x.shape)}")
     if sigma.numel() not in (1, n) or sigma.dtype != torch.float32 or not sigma.is_cuda:
         raise DeqsciHipError("ffdnet_head: sigma must be a fp32 GPU tensor with 1 or n elements")
     H, W = H2 // 2, W2 // 2
-    if sp16:
-        o = out if out is not None else Sp16.empty(n, H, W, x.device)
-        with _dev(x):
-            _check(load().deqsci_ffdnet_head_sp16(_p(x, "x"), _p(w_packed, "w_packed"), sigma.data_ptr(),
-                                                  0 if sigma.numel() == 1 else sigma.stride(0), o.t.data_ptr(), n, H, W, _stream()), "ffdnet_head_sp16")
-        return o
     o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32,
                                                   memory_format=torch.channels_last)
     with _dev(x):
@@ -555,16 +537,54 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
 
 
 # ----------------------------------------------------------------------------- split-fp16 direct convolution (csrc/conv_s16.hip)
-SP16_ACT_SCALE = 256.0     # activations are stored as fp16 pieces of 2^8 x: |x| < 255 (FFDNet's stay below 10); an overflow shows as inf / NaN
+# An sp16 activation holds the fp16 pieces hi + lo of 2^e x.  fp32 is scale-free, fp16 is not, so e follows the data: the RANGE of an
+# activation is (rng, exp) - `rng` a 1-element fp32 GPU tensor holding max |x| of that activation as a kernel measured it (every kernel
+# that writes or reads the activation derives e = act_exp(max |x|) from that device word: nothing crosses to the host, a captured
+# hipGraph follows its inputs), or None: the fixed exponent `exp`.  The mirror of csrc/common.hpp: sp16_act_exp.
+SP16_DEFAULT_EXP, SP16_TARGET_EXP, SP16_EXP_LIMIT = 8, 11, 64
+SP16_ACT_SCALE = 2.0 ** SP16_DEFAULT_EXP     # the fixed default: 2^8 x suits activations of a few units (|x| < 255.9)
+
+
+def act_exp(amax):
+    """The exponent e the kernels derive from max |x| = amax: 2^e amax in [2^11, 2^12) (a factor 16 below fp16's overflow; an element
+    keeps all 22 bits of its split down to 2^-14 of the maximum).  amax zero / subnormal / not finite: the default 8."""
+    import math
+    import struct
+    b = struct.unpack("<I", struct.pack("<f", float(amax)))[0]
+    e = (b >> 23) & 0xff
+    if e == 0 or e == 255 or math.isnan(float(amax)):
+        return SP16_DEFAULT_EXP
+    return max(-SP16_EXP_LIMIT, min(SP16_EXP_LIMIT, SP16_TARGET_EXP - (e - 127)))
+
+
+def _rng(t):
+    """Device pointer of a range slot (1-element fp32 GPU tensor), or None."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1:
+        raise DeqsciHipError("a range slot must be a 1-element fp32 GPU tensor")
+    return t.data_ptr()
+
+
+def absmax(x, slot):
+    """slot = max(slot, max |x|) on the device (zero the slot first): the range of an activation no sp16-writing kernel produced."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
+        raise DeqsciHipError("absmax: fp32 GPU tensor required")
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):    # any dense order does
+        x = x.contiguous()
+    with _dev(x):
+        _check(load().deqsci_absmax_f32(x.data_ptr(), x.numel(), _rng(slot), _stream()), "absmax")
+    return slot
 
 
 class Sp16:
     """An activation (n,64,H,W) in the "sp16" layout of csrc/conv_s16.hip: t is (n, 4, 2, 2, H, W, 8) float16 =
-    [cin chunk][piece: hi, lo][8-channel block][H][W][8 channels], holding 2^8 x as hi + lo.  Only exists between 64->64 layers."""
-    __slots__ = ("t", "n", "H", "W")
+    [cin chunk][piece: hi, lo][8-channel block][H][W][8 channels], holding 2^e x as hi + lo, e from the range (rng, exp) (see above).
+    Only exists between 64->64 layers."""
+    __slots__ = ("t", "n", "H", "W", "rng", "exp")
 
-    def __init__(self, t, n, H, W):
-        self.t, self.n, self.H, self.W = t, n, H, W
+    def __init__(self, t, n, H, W, rng=None, exp=SP16_DEFAULT_EXP):
+        self.t, self.n, self.H, self.W, self.rng, self.exp = t, n, H, W, rng, exp
 
     is_cuda = property(lambda self: self.t.is_cuda)
     device = property(lambda self: self.t.device)
@@ -574,36 +594,45 @@ class Sp16:
     def empty(n, H, W, device):
         return Sp16(torch.empty((n, 4, 2, 2, H, W, 8), dtype=torch.float16, device=device), n, H, W)
 
+    def exponent(self):
+        """(host sync when the range is a device slot: tests / tools)"""
+        return self.exp if self.rng is None else act_exp(float(self.rng))
+
     def to_nchw(self):
-        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: (hi + lo) / 2^8, exactly."""
-        v = (self.t[:, :, 0].float() + self.t[:, :, 1].float()) / SP16_ACT_SCALE       # (n, 4, 2, H, W, 8)
+        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: (hi + lo) / 2^e, exactly."""
+        v = (self.t[:, :, 0].float() + self.t[:, :, 1].float()) * 2.0 ** (-self.exponent())       # (n, 4, 2, H, W, 8)
         return v.permute(0, 1, 2, 5, 3, 4).reshape(self.n, 64, self.H, self.W).contiguous(memory_format=torch.channels_last)
 
 
-def to_split16(x, out=None):
-    """x (n,64,H,W) fp32 channels_last -> Sp16 (HIP streaming kernel)."""
+def to_split16(x, out=None, rng=None, exp=SP16_DEFAULT_EXP):
+    """x (n,64,H,W) fp32 channels_last -> Sp16 with the range (rng, exp) (HIP streaming kernel)."""
     n, c, H, W = x.shape
     if c != 64 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32 or not x.is_cuda:
         raise DeqsciHipError("to_split16: fp32 channels_last GPU activation with 64 channels required")
     o = out if out is not None else Sp16.empty(n, H, W, x.device)
+    o.rng, o.exp = rng, int(exp)
     with _dev(x):
-        _check(load().deqsci_f32_to_split16(x.data_ptr(), o.t.data_ptr(), n, H, W, SP16_ACT_SCALE, _stream()), "f32_to_split16")
+        _check(load().deqsci_f32_to_split16(x.data_ptr(), o.t.data_ptr(), n, H, W, _rng(rng), o.exp, _stream()), "f32_to_split16")
     return o
+
+
+def _weight_exp(w):
+    """The power of two that puts max |w| into [2^13, 2^14): the lo pieces of every weight that matters are then normal fp16 numbers."""
+    import math
+    amax = float(w.abs().max())
+    return 0 if amax == 0.0 or not math.isfinite(amax) else 13 - math.floor(math.log2(amax))
 
 
 class Split16Weights:
     """(64,64,3,3) fp32 conv weight as two fp16 pieces of 2^sw w in the LDS order of csrc/conv_s16.hip:
-    [cin chunk c (4)][tap (9)][piece: hi, lo (2)][cout group g (2)][lane (64)][j (8)], cout = 32 g + lane % 32, cin = 16 c + 8 (lane // 32) + j.
-    sw is the power of two that puts max |w| into [2^13, 2^14): the lo pieces of every weight that matters are then normal fp16 numbers."""
-    __slots__ = ("packed", "sw", "out_scale_sp16", "out_scale_f32")
+    [cin chunk c (4)][tap (9)][piece: hi, lo (2)][cout group g (2)][lane (64)][j (8)], cout = 32 g + lane % 32, cin = 16 c + 8 (lane // 32) + j."""
+    __slots__ = ("packed", "sw")
 
     def __init__(self, w):
         if tuple(w.shape) != (64, 64, 3, 3):
             raise DeqsciHipError(f"split16 conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
         w = w.detach().float()
-        amax = float(w.abs().max())
-        import math
-        self.sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        self.sw = _weight_exp(w)
         ws = w * (2.0 ** self.sw)
         hi = ws.half()
         lo = (ws - hi.float()).half()
@@ -612,60 +641,53 @@ class Split16Weights:
         p = torch.stack((hi, lo), 0)                                   # (hl, cout, cin, ky, kx)
         p = p.reshape(2, 2, 32, 4, 2, 8, 9)                            # [hl][g][m][c][kb][j][tap]
         self.packed = p.permute(3, 6, 0, 1, 4, 2, 5).contiguous()      # [c][tap][hl][g][kb][m][j]  (lane = 32 kb + m)
-        self.out_scale_sp16 = 2.0 ** (-self.sw)                        # acc = 2^(8+sw) sum w x  ->  2^8 (sum w x): the next layer's sp16 scale
-        self.out_scale_f32 = 2.0 ** (-self.sw) / SP16_ACT_SCALE
 
 
 class TailSplit16Weights:
     """The last layer's (COUT,64,3,3) weight, COUT = 4 (FFDNet) or 1 (SimpleCNN), for the MFMA tail of csrc/conv_s16.hip: the taps go into
     the matrix N dimension - column 32 nt + lane % 32 = COUT tap + cout - as two fp16 pieces of 2^sw w in the order
     [cin chunk c (4)][piece (2)][N tile nt][lane (64)][j (8)], cin = 16 c + 8 (lane // 32) + j; columns >= 9 COUT are zero."""
-    __slots__ = ("packed", "cout", "out_scale")
+    __slots__ = ("packed", "cout", "sw")
 
     def __init__(self, w):
         cout = w.shape[0]
         if tuple(w.shape) != (cout, 64, 3, 3) or cout not in (1, 4):
             raise DeqsciHipError(f"split16 tail expects a (4,64,3,3) or (1,64,3,3) weight, got {tuple(w.shape)}")
-        import math
         w = w.detach().float()
-        amax = float(w.abs().max())
-        sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        self.sw = _weight_exp(w)
         nt = (9 * cout + 31) // 32
         cols = torch.zeros(32 * nt, 64, dtype=torch.float32, device=w.device)             # [col][cin]
-        cols[:9 * cout] = (w * 2.0 ** sw).permute(2, 3, 0, 1).reshape(9 * cout, 64)      # col = cout_count * tap + cout
+        cols[:9 * cout] = (w * 2.0 ** self.sw).permute(2, 3, 0, 1).reshape(9 * cout, 64)  # col = cout_count * tap + cout
         hi = cols.half()
         lo = (cols - hi.float()).half()
         p = torch.stack((hi, lo), 0).reshape(2, nt, 32, 4, 2, 8)                         # [hl][nt][m][c][kb][j]
         self.packed = p.permute(3, 0, 1, 4, 2, 5).contiguous()                           # [c][hl][nt][kb][m][j]  (lane = 32 kb + m)
         self.cout = cout
-        self.out_scale = 2.0 ** (-sw) / SP16_ACT_SCALE
 
 
 class HeadSplit16Weights:
     """FFDNet's first-layer (64,5,3,3) weight for the MFMA head of csrc/conv_s16.hip: two fp16 pieces of 2^sw w as
     [k step (3)][piece (2)][cout group g (2)][lane (64)][j (8)], cout = 32 g + lane % 32, k = 16 ks + 8 (lane // 32) + j = 9 ch + tap
     (k >= 45: zero)."""
-    __slots__ = ("packed", "out_scale")
+    __slots__ = ("packed", "sw")
 
     def __init__(self, w):
         if tuple(w.shape) != (64, 5, 3, 3):
             raise DeqsciHipError(f"split16 head expects a (64,5,3,3) weight, got {tuple(w.shape)}")
-        import math
         w = w.detach().float()
-        amax = float(w.abs().max())
-        sw = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))
+        self.sw = _weight_exp(w)
         wk = torch.zeros(64, 48, dtype=torch.float32, device=w.device)
-        wk[:, :45] = (w * 2.0 ** sw).reshape(64, 45)                                    # k = 9 ch + tap
+        wk[:, :45] = (w * 2.0 ** self.sw).reshape(64, 45)                               # k = 9 ch + tap
         hi = wk.half()
         lo = (wk - hi.float()).half()
         p = torch.stack((hi, lo), 0).reshape(2, 2, 32, 3, 2, 8)                           # [hl][g][m][ks][kb][j]
         self.packed = p.permute(3, 0, 1, 4, 2, 5).contiguous()                           # [ks][hl][g][kb][m][j]
-        self.out_scale = 2.0 ** (-sw)          # acc = 2^(8+sw) y  ->  the sp16 output holds 2^8 y
 
 
-def ffdnet_head_split16(x, weights, sigma, out=None):
+def ffdnet_head_split16(x, weights, sigma, out=None, in_rng=None, in_exp=SP16_DEFAULT_EXP, out_rng=None, out_exp=SP16_DEFAULT_EXP, track=None):
     """x (n,1,2H,2W) planar, sigma (n,) or (1,) -> relu(conv3x3(cat(sigma map, pixel_unshuffle(x,2)), w)) as an Sp16, on the f16 matrix
-    cores with the split-fp16 arithmetic (`weights` = HeadSplit16Weights(w))."""
+    cores with the split-fp16 arithmetic (`weights` = HeadSplit16Weights(w)).  in_rng: range slot holding max |x| of the image (the
+    kernel adds sigma itself); (out_rng, out_exp): the range of the output; track: a slot that receives max |output|."""
     n, c, H2, W2 = x.shape
     if c != 1 or H2 % 2 or W2 % 2 or not isinstance(weights, HeadSplit16Weights):
         raise DeqsciHipError(f"ffdnet_head_split16: (n,1,even,even) image and HeadSplit16Weights required, got {tuple(x.shape)}")
@@ -673,10 +695,12 @@ def ffdnet_head_split16(x, weights, sigma, out=None):
         raise DeqsciHipError("ffdnet_head_split16: sigma must be a fp32 GPU tensor with 1 or n elements")
     H, W = H2 // 2, W2 // 2
     o = out if out is not None else Sp16.empty(n, H, W, x.device)
+    o.rng, o.exp = out_rng, int(out_exp)
     wp = weights.packed if weights.packed.device == x.device else weights.packed.to(x.device)
     with _dev(x):
         _check(load().deqsci_ffdnet_head_split16(_p(x, "x"), wp.data_ptr(), sigma.data_ptr(), 0 if sigma.numel() == 1 else sigma.stride(0),
-                                                 o.t.data_ptr(), n, H, W, float(weights.out_scale), _stream()), "ffdnet_head_split16")
+                                                 o.t.data_ptr(), n, H, W, weights.sw, _rng(in_rng), int(in_exp), _rng(out_rng), o.exp,
+                                                 _rng(track), _stream()), "ffdnet_head_split16")
     return o
 
 
@@ -690,42 +714,56 @@ def tail_split16(h, weights, out=None):
     wp = weights.packed if weights.packed.device == h.t.device else weights.packed.to(h.t.device)
     fn = load().deqsci_ffdnet_tail_split16 if weights.cout == 4 else load().deqsci_conv3x3_c64_to_1_split16
     with _dev(h.t):
-        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, float(weights.out_scale), _stream()), "tail_split16")
+        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng), h.exp, _stream()), "tail_split16")
     return o
 
 
-def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=False, events=None):
-    """x Sp16 -> relu(conv3x3(x, w, pad=1) + bias) as an Sp16 (out_f32=False) or an fp32 channels_last (n,64,H,W) tensor: the
-    direct convolution on the f16 matrix cores with split operands (csrc/conv_s16.hip).  `weights` = Split16Weights(w)."""
+def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=False, events=None, out_rng=None, out_exp=SP16_DEFAULT_EXP,
+                        track=None):
+    """x Sp16 -> relu(conv3x3(x, w, pad=1) + bias) as an Sp16 with the range (out_rng, out_exp) (out_f32=False) or an fp32 channels_last
+    (n,64,H,W) tensor: the direct convolution on the f16 matrix cores with split operands (csrc/conv_s16.hip).  `weights` =
+    Split16Weights(w).  track: a range slot - a MEASURING launch: max |output| is folded into the slot, nothing else is written, None is
+    returned (run it, then the real launch with out_rng = that slot)."""
     if not isinstance(x, Sp16) or tuple(x.t.shape) != (x.n, 4, 2, 2, x.H, x.W, 8) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
         raise DeqsciHipError("conv3x3_c64_split16: a contiguous Sp16 GPU activation is required")
     if not isinstance(weights, Split16Weights) or weights.packed.numel() != 4 * 9 * 2 * 2 * 64 * 8:
         raise DeqsciHipError("conv3x3_c64_split16: weights must be a Split16Weights")
     n, H, W, dev = x.n, x.H, x.W, x.t.device
+    wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
+    if track is not None:
+        if out_f32:
+            raise DeqsciHipError("conv3x3_c64_split16: a measuring launch (track=) serves the sp16 output")
+        with _dev(x.t):
+            _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), None, n, H, W, 1 if relu else 0,
+                                                     weights.sw, _rng(x.rng), x.exp, None, 0, _rng(track), 0, _stream(), None, None),
+                   "conv3x3_c64_split16 (measuring)")
+        return None
     if out_f32:
         o = out if out is not None else torch.empty((n, 64, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
-        ot, bscale = o, 1.0
-        scale = weights.out_scale_f32
+        ot = o
     else:
         o = out if out is not None else Sp16.empty(n, H, W, dev)
-        ot, bscale = o.t, SP16_ACT_SCALE
-        scale = weights.out_scale_sp16
+        o.rng, o.exp = out_rng, int(out_exp)
+        ot = o.t
     ev = _hook_events("s16", n, H, W, events) or (None, None)
-    wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
     with _dev(x.t):
         _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), ot.data_ptr(), n, H, W, 1 if relu else 0,
-                                                 float(scale), float(bscale), 1 if out_f32 else 0, _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
+                                                 weights.sw, _rng(x.rng), x.exp, _rng(out_rng), int(out_exp), None, 1 if out_f32 else 0,
+                                                 _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
     return o
 
 
 class Conv64Weights:
-    """The weights of one 64->64 layer for all three kernels (the split-fp16 pack is made on first use)."""
+    """The weights of one 64->64 layer for all three kernels.  The split-fp16 pack (a host sync: max |w|) is made here when `s16` is set
+    - the engine does whenever its policy can pick that kernel, so that the pack never falls inside a hipGraph capture - or on first use."""
     __slots__ = ("f22", "f44", "_w", "_s16")
 
-    def __init__(self, w):
+    def __init__(self, w, s16=False):
         self.f22 = pack_winograd_weights(w)
         self.f44 = pack_winograd44_weights(w)
         self._w, self._s16 = w.detach(), None
+        if s16:
+            self._s16 = Split16Weights(self._w)
 
     @property
     def s16(self):
@@ -734,8 +772,8 @@ class Conv64Weights:
         return self._s16
 
 
-def pack_conv64_weights(w):
-    return Conv64Weights(w)
+def pack_conv64_weights(w, s16=False):
+    return Conv64Weights(w, s16=s16)
 
 
 # launch time of one block tile per CU, us (tools/w44_check.py, tools/s16_check.py; profiles/r02_w44_shapes.jsonl, r03_s16_*): the F(4x4,3x3)
@@ -743,8 +781,9 @@ def pack_conv64_weights(w):
 _T_TILE_F22, _T_TILE_F44, _T_TILE_S16 = 21.5, 33.5, 29.5
 
 
-W44_MAX_PIXELS = (0x80000000 - 4096 - 2048 - 16) // 256   # per image, width padded to 32 columns
-FORCE_CONV64 = os.environ.get("DEQSCI_CONV64")          # "f22" / "f44" / "s16": A/B runs of the tools; overrides every policy below
+W44_MAX_PIXELS = (0x80000000 - 4096 - 2048 - 16) // 256   # per image, width padded to 32 columns: the F(4x4,3x3) launcher's limit
+S16_MAX_PIXELS = (0x80000000 - 4096 - 4096 - 16) // 256   # per image (H * W): the split-fp16 launcher's (csrc/conv_s16.hip: RAW_BIAS + 4096 + 16)
+FORCE_CONV64 = None                                     # "f22" / "f44" / "s16": set by the tools for A/B runs (never by the package or the environment); overrides every policy below
 
 
 _CUS = {}
@@ -766,14 +805,15 @@ def conv64_kernel_for(n, H, W, device=None, policy="fast"):
       "fast32"  fp32 MFMA arithmetic only: the faster of F(4x4,3x3) (csrc/winograd44.hip) and F(2x2,3x3)
       "f22" / "f44" / "s16"   that kernel whatever the size.
     Rounding per layer against a float64 convolution on FFDNet's own data (tools/conv_error_real.py, profiles/r03_conv_error_real.json):
-    F(2x2,3x3) 2.0e-7, F(4x4,3x3) 2.2e-7 (5.6e-7 on the blocky first iterate), split-fp16 2.5e-7, MIOpen's direct fp32 convolution 3.5e-7."""
+    split-fp16 1.6e-7, F(2x2,3x3) 2.0e-7, F(4x4,3x3) 2.2e-7 (5.6e-7 on the blocky first iterate), MIOpen's direct fp32 convolution 3.5e-7."""
     if FORCE_CONV64 in ("f22", "f44", "s16"):
         return FORCE_CONV64
     if policy in ("f22", "f44", "s16"):
         return policy
     if policy not in ("fast", "fast32"):
         raise DeqsciHipError(f"conv64 policy {policy!r}: expected 'fast', 'fast32', 'f22', 'f44' or 's16'")
-    if H * (-(-W // 32)) * 32 > W44_MAX_PIXELS:          # beyond the 32-bit buffer offsets of the two 16 x 32-tile kernels (their launchers refuse)
+    # beyond the 32-bit buffer offsets of the 16 x 32-tile kernel this policy would pick (its launcher refuses): F(2x2,3x3)
+    if (H * (-(-W // 32)) * 32 > W44_MAX_PIXELS) if policy == "fast32" else (H * W > S16_MAX_PIXELS):
         return "f22"
     cus = _cus(device)
     t22 = -(-(n * (-(-H // 16)) * (-(-W // 16))) // cus) * _T_TILE_F22

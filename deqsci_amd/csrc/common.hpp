@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "deqsci_hip.h"
 
@@ -87,6 +88,56 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
     return v;
+}
+
+// ---- power-of-two scales of the "sp16" activations (csrc/conv_s16.hip: a tensor stored as the fp16 pieces hi + lo of 2^e x).
+// fp32 is scale-free, fp16 is not, so the exponent e FOLLOWS THE DATA: an activation's range is the pair (amax, exp) - `amax` a device
+// pointer to max |x| of that activation as measured by the kernel that produced it (NULL: the fixed exponent `exp`), from which every
+// kernel that writes or reads the activation derives the same e = SP16_TARGET_EXP - floor(log2(amax)): 2^e max|x| lies in [2^11, 2^12),
+// a factor 16 below fp16's overflow, and an element keeps all 22 bits of its split down to 2^-14 of the maximum (below that the lo
+// piece goes subnormal: the ABSOLUTE error stays 2^-36 of the maximum).  Powers of two: every scaling is exact.
+constexpr int SP16_DEFAULT_EXP = 8, SP16_TARGET_EXP = 11, SP16_EXP_LIMIT = 64;
+__host__ __device__ inline int sp16_act_exp(float amax) {
+    uint32_t b;
+    __builtin_memcpy(&b, &amax, 4);
+    const int e = (int)((b >> 23) & 0xffu);
+    if (e == 0 || e == 255) return SP16_DEFAULT_EXP;          // all zeros (or subnormal) / not finite: any exponent does; an overflow shows downstream
+    const int a = SP16_TARGET_EXP - (e - 127);
+    return a < -SP16_EXP_LIMIT ? -SP16_EXP_LIMIT : a > SP16_EXP_LIMIT ? SP16_EXP_LIMIT : a;
+}
+__device__ __forceinline__ int sp16_resolve_exp(const float* amax, int exp) { return amax ? sp16_act_exp(*amax) : exp; }
+// 2^e as a float; NaN beyond the normal range, so that an absurd combination of ranges is loud instead of silently mis-scaled
+__device__ __forceinline__ float sp16_pow2(int e) {
+    return (e < -126 || e > 127) ? __builtin_nanf("") : __builtin_bit_cast(float, (uint32_t)(e + 127) << 23);
+}
+// max over the 64 lanes of a per-lane value v >= 0, as the (wave-uniform) bit pattern of the float: four DPP steps inside each row of 16
+// lanes, then the four row results through scalar registers - no LDS, no per-lane address registers
+__device__ __forceinline__ uint32_t sp16_wave_max_bits(float v) {
+    auto step = [](float x, auto ctrl) {
+        return fmaxf(x, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true)));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{});          // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{});          // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{});         // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{});         // row_mirror
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const uint32_t r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16), r2 = __builtin_amdgcn_readlane(b, 32),
+                   r3 = __builtin_amdgcn_readlane(b, 48);
+    const uint32_t m01 = r0 > r1 ? r0 : r1, m23 = r2 > r3 ? r2 : r3;
+    return m01 > m23 ? m01 : m23;
+}
+// max over the workgroup of a per-lane value v >= 0, times `unscale`, folded into *track by ONE atomic (non-negative floats order like
+// their bit patterns).  `lds`: one word per wave.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void sp16_track_block_max(float v, float unscale, float* track, uint32_t* lds) {
+    const uint32_t wm = sp16_wave_max_bits(v);
+    const int nw = (int)((blockDim.x + WAVE - 1) / WAVE);
+    if ((threadIdx.x & (WAVE - 1)) == 0) lds[threadIdx.x / WAVE] = wm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t m = lds[0];
+        for (int w = 1; w < nw; ++w) m = lds[w] > m ? lds[w] : m;
+        atomicMax(reinterpret_cast<unsigned int*>(track), __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, m) * unscale));
+    }
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

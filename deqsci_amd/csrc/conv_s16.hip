@@ -10,10 +10,14 @@
 // convolution), tools/ubench/mfma_f16_numerics.hip for what the f16 MFMA does with its 16 products (fp16 subnormals kept, one
 // rounding per instruction).
 //
-// Scaling: fp16 has 5 exponent bits.  Activations are stored multiplied by 2^8 (|v| < 255: FFDNet's stay below 10; an overflow shows
-// as inf/NaN in the output, never silently) and each layer's weights by a power of two chosen at pack time so that max |w| lands in
-// [2^13, 2^14); the lo pieces then stay normal fp16 numbers for every value that matters.  The epilogue multiplies the fp32
-// accumulator by the exact inverse power of two.
+// Scaling: fp16 has 5 exponent bits, fp32 is scale-free - so the scales FOLLOW THE DATA.  An activation is stored multiplied by 2^e with
+// e = 11 - floor(log2(max |x|)) of that activation (common.hpp: sp16_act_exp; the maximum is measured on the device by the kernel that
+// produces the activation - `track_amax` below - at the first f-call of a reconstruction, and every kernel that writes or reads the
+// activation derives e from the same device word, so nothing crosses to the host and a captured hipGraph follows its inputs), or with
+// a fixed exponent the caller names (2^8 by default).  Each layer's weights carry a power of two chosen at pack time so that max |w|
+// lands in [2^13, 2^14).  The lo pieces then stay normal fp16 numbers for every value that matters (down to 2^-14 of the maximum), an
+// activation that grows 16-fold beyond the measured maximum shows as inf/NaN in the output, never silently, and the epilogue multiplies
+// the fp32 accumulator by the exact power of two that takes it to the output's scale.
 //
 // Activation layout between layers ("sp16"): [n][cin chunk c (4)][piece hl (2: hi, lo)][k block kb (2)][H][W][8 halfs] - 16 planes
 // of 16-byte pixels (256 bytes per pixel in all, as fp32 NHWC).  A pixel's 16 bytes in plane (c, hl, kb) are exactly one lane's
@@ -61,6 +65,10 @@
 #ifndef S16_TAIL_XCD
 #define S16_TAIL_XCD 1      // 0: the last layer's tiles dealt round-robin over the XCDs (A/B)
 #endif
+#ifndef S16_ROWS4
+#define S16_ROWS4 0   // wave geometry inside the 8-wave workgroup: 0 = two pixel rows x both cout groups (60 operand reads from LDS per stage and
+                      // wave: 36 weight + 24 activation fragments); 1 = FOUR pixel rows x ONE cout group (54: 18 + 36) - same accumulators, same MFMAs
+#endif
 #ifndef S16_ABL
 #define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
                       // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
@@ -88,20 +96,28 @@ constexpr int RAW_BUF = WAVES * RAW_INSTR * 1024;              // 40960 bytes
 constexpr int W_CHUNK = 9 * 2 * 2 * 1024;                      // 36864 bytes: [tap][hl][cout group][lane][8 halfs]
 constexpr uint32_t RAW_BIAS = 4096;                            // the descriptor starts this far below the image (see set_fetch_tile)
 constexpr uint32_t RAW_OOB = 0x80000000u;                      // beyond num_records: the hardware writes zeros
-constexpr float SP_SCALE = 256.0f;                             // sp16 activations hold 2^8 x
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (int)(((uint64_t)(uint32_t)t * mg) >> sh); }
 
 // OUT_F32 = 0: sp16 output (the next 64->64 layer's input); 1: fp32 channels_last (n, H, W, 64) output (the consumer is not this kernel)
-template <int OUT_F32>
+// TRACK = 1: the range MEASUREMENT - the same arithmetic, but instead of storing y the launch folds max |y| (true units, pixels of the
+// image only) into *track with one atomic per workgroup
+// The ranges (common.hpp): the input holds 2^e_in x, e_in from *in_amax (or in_exp); the sp16 output 2^e_out y, e_out from *out_amax (or out_exp)
+template <int OUT_F32, int TRACK>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
-                                                          char* __restrict__ y, int H, int W, int relu, float oscale, float bscale, int tiles_x, int tiles_y,
+                                                          char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
+                                                          const float* __restrict__ out_amax, int out_exp, float* __restrict__ track, int tiles_x, int tiles_y,
                                                           int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
+    __shared__ uint32_t trk_s[WAVES];
+    // acc = 2^(e_in + w_exp) sum w x  ->  2^e_out y; the bias likewise
+    const int e_out = OUT_F32 ? 0 : sp16_resolve_exp(out_amax, out_exp);
+    const float oscale = sp16_pow2(e_out - sp16_resolve_exp(in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
+    uint32_t trk_max = 0;                                      // (TRACK) the wave's running max |stored output| as float bits, wave-uniform
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     int t_first, t_step, t_end;
@@ -193,18 +209,38 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // like sqrt(n) ulps OF THAT ACCUMULATOR: with the cross terms out of the way the big chain is 144 steps long instead of 432 (and
     // the small chain's ulps are 2^-11 of the big one's), which takes the per-layer error against float64 from 2.5e-7 to 1.6e-7 - below
     // the fp32 Winograd forms - for 64 more registers and one addition per output in the epilogue.
-    f32x16 acc[2][2][2];
-    struct Done { i32x4 orsrc; uint32_t pix[2]; };             // where the finished tile goes: descriptor of its image, per-lane offsets of rows r
+    // (The measuring launch keeps ONE chain - it only has to find the binary exponent of max |y| - and has its registers to spare.)
+    constexpr int CH1 = TRACK ? 0 : 1;
+    f32x16 acc[CH1 + 1][2][2];
+    // where the finished tile goes: descriptor of its image, per-lane offsets of rows r (S16_ROWS4: of the lane's COLUMN - the rows of a wave
+    // are wave-uniform and go into the stores' scalar offset, an out-of-image row is a uniform branch), first pixel row of the wave
+    struct Done { i32x4 orsrc; uint32_t pix[2]; int oy0; };
     const int pl = lane & 31, kb = lane >> 5;
+#if S16_ROWS4
+    const int wg = wave & 1, wr4 = 4 * (wave >> 1);             // the wave's cout group and its first pixel row; acc[.][r >> 1][r & 1] is row r
+    const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (wr4 * RAW_COLS + pl) * 16;
+    const lds_char* abase = (const lds_char*)Wt + wg * 1024 + lane * 16;
+#else
     const lds_char* bbase = (const lds_char*)Raw + kb * PLANE_B + (2 * wave * RAW_COLS + pl) * 16;
     const lds_char* abase = (const lds_char*)Wt + lane * 16;
+#endif
 
     // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of the next one) is
     // fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
     // ---- epilogue of one (r, g, gp) piece: acc[.][g][r][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of pixel (2 wave + r, pl)
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
-    auto ep_piece = [&](const Done& d, int k, const f32x4 (&bz4)[2][4]) __attribute__((always_inline)) {
-        const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1;
+    auto ep_piece = [&](const Done& d, int k, const f32x4 (&bz4)[2][4], float& tmax) __attribute__((always_inline)) {
+#if S16_ROWS4
+        const int r = k >> 1, gp = k & 1, ga = r >> 1, ra = r & 1, gb = 0;   // (ga, ra): where row r sits in acc; gb: the bias set
+        const int g = wg;                                      // (wave-uniform, not a constant: the stores' scalar offsets)
+        const bool row_ok = d.oy0 + r < H;                     // (uniform)
+        const uint32_t pixv = d.pix[0];
+        const uint32_t rowoff = (uint32_t)((d.oy0 + r) * W) * (OUT_F32 ? 256u : 16u);
+#else
+        const int r = k >> 2, g = (k >> 1) & 1, gp = k & 1, ga = g, ra = r, gb = g;
+        const bool row_ok = true;
+        const uint32_t pixv = d.pix[r], rowoff = 0;
+#endif
         // values in PAIRS (k, k + 1): every step below is one packed instruction per pair where the hardware has one.  ReLU is the
         // NaN-propagating maximum (v_maximum3_f32) against 0, or against -inf when the layer has none: an overflow upstream (inf in the
         // fp16 pieces -> inf - inf in the accumulators) stays a NaN all the way to the output instead of being clamped to 0.
@@ -213,21 +249,28 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = 4 * (2 * gp + (e >> 1)) + 2 * (e & 1);
-            const f32x2 a0 = {acc[0][g][r][i], acc[0][g][r][i + 1]}, a1 = {acc[1][g][r][i], acc[1][g][r][i + 1]};
-            const f32x4 b4 = bz4[g][2 * gp + (e >> 1)];
+            const f32x2 a0 = {acc[0][ga][ra][i], acc[0][ga][ra][i + 1]}, a1 = TRACK ? (f32x2){0.0f, 0.0f} : (f32x2){acc[CH1][ga][ra][i], acc[CH1][ga][ra][i + 1]};
+            const f32x4 b4 = bz4[gb][2 * gp + (e >> 1)];
             const f32x2 bz = (e & 1) ? (f32x2){b4.z, b4.w} : (f32x2){b4.x, b4.y};
             f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
             t.x = __builtin_elementwise_maximum(t.x, floor_);
             t.y = __builtin_elementwise_maximum(t.y, floor_);
+            if (TRACK && row_ok && pixv != RAW_OOB) tmax = fmaxf(tmax, fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)));   // (pixels of the image only)
             v2[e] = t;
         }
+        if (TRACK) {                                           // (the measuring launch writes nothing; pieces one after the other, as the stores keep them)
+            asm volatile("" : "+v"(tmax));
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
+        if (!row_ok) return;
         if (OUT_F32) {
             // fp32 channels_last: the lane's four consecutive couts of each group are 16 contiguous bytes (pix = byte offset of the pixel)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const f32x4 o = {v2[2 * q].x, v2[2 * q].y, v2[2 * q + 1].x, v2[2 * q + 1].y};
-                const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4));
-                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(o), "v"(d.pix[r]), "s"(d.orsrc), "s"(so) : "memory");
+                const uint32_t so = uniform((uint32_t)((32 * g + 8 * (2 * gp + q)) * 4) + rowoff);
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(o), "v"(pixv), "s"(d.orsrc), "s"(so) : "memory");
             }
         } else {
             // sp16: split, pack, and trade halves with the lane 32 away so that each lane holds one whole 16-byte pixel of
@@ -250,10 +293,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             // now lanes < 32 hold couts [0, 8) of block 0 as (hi[0], hi[1], hi[2], hi[3]) = (own 0..3, partner's 4..7); lanes >= 32
             // hold block 1 of pixel lane - 32 likewise: plane kb of the lane (inside pix), pixel pl
             const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
-            const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u);
-            const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u);
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_h) : "memory");
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(d.pix[r]), "s"(d.orsrc), "s"(so_l) : "memory");
+            const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u + rowoff);
+            const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u + rowoff);
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(pixv), "s"(d.orsrc), "s"(so_h) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(pixv), "s"(d.orsrc), "s"(so_l) : "memory");
         }
     };
     auto tile_done = [&](int t) -> Done {
@@ -266,12 +309,18 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         d.orsrc.y = (int)uniform((uint32_t)(ob >> 32));
         d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
         d.orsrc.w = 0x00020000;
+#if S16_ROWS4
+        d.oy0 = OUT_ROWS * by + wr4;
+        d.pix[0] = d.pix[1] = ox >= W ? RAW_OOB : OUT_F32 ? (uint32_t)(ox * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + ox) * 16);
+#else
+        d.oy0 = 0;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int oy = OUT_ROWS * by + 2 * wave + r;
             const bool ok = oy < H && ox < W;
             d.pix[r] = !ok ? RAW_OOB : OUT_F32 ? (uint32_t)((oy * W + ox) * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + oy * W + ox) * 16);
         }
+#endif
         return d;
     };
 
@@ -282,6 +331,58 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         const int buf = c & 1, nb = buf ^ 1, cn = (c + 1) & 3;
         const lds_char* bb = bbase + buf * RAW_BUF;
         const lds_char* ab = abase + buf * W_CHUNK;
+#if S16_ROWS4
+        // 9 groups (dx, dy) of 12 MFMAs: the wave's four pixel rows x three products of one tap.  Operands are read from LDS ONE group
+        // ahead (= the same twelve MFMAs ahead as in the other geometry): per group the tap's two weight fragments (hi, lo) and the halo
+        // rows that come into play - rows 0..3 at dy = 0, row 4 at dy = 1, row 5 at dy = 2 of every dx - into a ring of EIGHT row slots
+        // (slot = (6 dx + row) mod 8: while (dx, 2) multiplies rows 2..5, the four dead slots take rows 0..3 of dx + 1).
+        h8 Ah[2], Al[2], Bh[8], Bl[8];
+        auto loads = [&](int i) __attribute__((always_inline)) {
+            if (i >= 9 || ((S16_ABL & 8) && i >= 1)) return;
+            const int dx = i / 3, dy = i % 3, tap = dy * 3 + dx;
+            Ah[i & 1] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 0) * 2) * 1024);
+            Al[i & 1] = *reinterpret_cast<const lds_h8*>(ab + ((tap * 2 + 1) * 2) * 1024);
+#pragma unroll
+            for (int rr = (dy == 0 ? 0 : dy + 3); rr <= dy + 3; ++rr) {
+                Bh[(6 * dx + rr) & 7] = *reinterpret_cast<const lds_h8*>(bb + (rr * RAW_COLS + dx) * 16);
+                Bl[(6 * dx + rr) & 7] = *reinterpret_cast<const lds_h8*>(bb + 2 * PLANE_B + (rr * RAW_COLS + dx) * 16);
+            }
+        };
+        auto dma = [&](int j) __attribute__((always_inline)) {    // the next chunk: 10 DMA instructions, two per group in the first five groups
+            if (more && j < 2 * RAW_INSTR && !(S16_ABL & 1)) {
+                if (j < RAW_INSTR) raw_piece(cn, nb, j); else w_piece(cn, nb, j - RAW_INSTR);
+            }
+        };
+        S16_MARK(4);
+        loads(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int dx = i / 3, dy = i % 3;
+#define S16_SLOT(r) ((6 * dx + dy + (r)) & 7)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[CH1][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i & 1], Bh[S16_SLOT(r)], acc[CH1][r >> 1][r & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            loads(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[CH1][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bl[S16_SLOT(r)], acc[CH1][r >> 1][r & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma(2 * i);
+            shadow(2 * i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], acc[0][r >> 1][r & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma(2 * i + 1);
+            shadow(2 * i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 2; r < 4; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], acc[0][r >> 1][r & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#undef S16_SLOT
+        }
+#else
         // 18 groups (dx, dy, g) of 6 MFMAs: the two pixel rows x three products of one tap and cout group.  Operands are read from LDS
         // TWO groups ahead (software pipeline pinned by sched_barriers: left to itself hipcc reads each fragment one MFMA before its use
         // and waits for it): per group two weight fragments (hi, lo) and, when a new halo row comes into play, its hi and lo fragments
@@ -310,7 +411,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             // (hipcc left to itself issues a group's six MFMAs first and everything else behind them: the wave's next MFMA then waits for
             // its own operand reads, DMA set-up and scalar arithmetic to issue - pinned here in the MFMAs' shadow instead)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) acc[CH1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i % 3], Bh[dx & 1][dy + r], acc[CH1][g][r], 0, 0, 0);
 #if S16_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -319,7 +420,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[1][g][r], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) acc[CH1][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bl[dx & 1][dy + r], acc[CH1][g][r], 0, 0, 0);
 #if S16_INTERLEAVE
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -335,6 +436,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             for (int r = 0; r < 2; ++r) acc[0][g][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i % 3], Bh[dx & 1][dy + r], acc[0][g][r], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         S16_MARK(0);
         if (!(S16_ABL & 2)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -370,7 +472,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // (all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles: the out-of-step epilogue, the
     // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
     // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
-    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}};
+    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0};
     S16_MARK(4);
 #pragma unroll 1
     for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
@@ -379,7 +481,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[1][g][r][i] = 0.0f;
+                for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[CH1][g][r][i] = 0.0f;
         stage(0, true, nothing, no_shadow);
         stage(1, true, nothing, no_shadow);
         const bool next = t_cur + t_step < t_end;
@@ -400,12 +502,22 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 // the lane's 32 bias values in one burst of LDS reads (operand registers are free here): read piece by piece, each read
                 // was a round trip through an LDS the partner wave keeps busy - 16 of them made the epilogue twice as long
                 f32x4 bz4[2][4];
+#if S16_ROWS4
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bz4[0][q] = bz4[1][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * wg + 8 * q + 4 * kb);
+#else
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb);
+#endif
+                float tmax = 0.0f;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) ep_piece(d, k, bz4);
+                for (int k = 0; k < 8; ++k) ep_piece(d, k, bz4, tmax);
+                if (TRACK) {                                   // (the measuring launch only: once per tile and wave)
+                    const uint32_t tb = sp16_wave_max_bits(tmax);
+                    trk_max = tb > trk_max ? tb : trk_max;
+                }
             }
         };
 #if S16_EPI_LOCKSTEP
@@ -419,16 +531,28 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         S16_MARK(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (TRACK) {
+        if (lane == 0) trk_s[wave] = trk_max;
+        __syncthreads();
+        if (threadIdx.x == 0 && track) {
+            uint32_t m = trk_s[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) m = trk_s[w] > m ? trk_s[w] : m;
+            atomicMax(reinterpret_cast<unsigned int*>(track), __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, m) * sp16_pow2(-e_out)));
+        }
+    }
 #ifdef S16_STAMP
     if (lane == 0)
         for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
 #endif
 }
 
-// fp32 channels_last (n, H, W, 64) -> sp16, activations scaled by `scale` (the engine's 2^8): one lane per (pixel, 8-channel block)
-__global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restrict__ x, char* __restrict__ y, int64_t HW, int64_t total, float scale) {
+// fp32 channels_last (n, H, W, 64) -> sp16 holding 2^e x, e from the range (amax, exp): one lane per (pixel, 8-channel block)
+__global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restrict__ x, char* __restrict__ y, int64_t HW, int64_t total,
+                                                          const float* __restrict__ amax, int exp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over n * HW * 8
     if (i >= total) return;
+    const float scale = sp16_pow2(sp16_resolve_exp(amax, exp));
     const int blk = (int)(i & 7);
     const int64_t pix = i >> 3, n = pix / HW, p = pix - n * HW;
     const float4 a = ld4s(x + pix * 64 + blk * 8), b = ld4s(x + pix * 64 + blk * 8 + 4);
@@ -446,6 +570,23 @@ __global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restric
     *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 2 + kb) * HW + p) * 16) = lo;
 }
 
+// max |x| over a tensor folded into *amax (one atomic per workgroup): the range of an activation that no sp16-writing kernel produced
+// (the denoiser's input image; an fp32 activation converted by f32_to_sp16_kernel)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t count, float* __restrict__ amax) {
+    __shared__ uint32_t wmax[4];
+    float m = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
+        if (i + 4 <= count) {
+            const float4 v = ld4(x + i);
+            m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+        } else {
+            for (int64_t k = i; k < count; ++k) m = fmaxf(m, __builtin_fabsf(x[k]));
+        }
+    }
+    sp16_track_block_max(m, 1.0f, amax, wmax);
+}
+
 
 // ---- the denoisers' LAST layer on the same arithmetic: conv3x3 64 -> COUT (4: FFDNet, followed by its 2x2 pixel shuffle; 1: SimpleCNN), no bias,
 // reading the sp16 activation of the last 64->64 layer.  As a matrix product it is tiny in N, so the taps go INTO N:
@@ -459,8 +600,9 @@ constexpr int TL_H = 8, TL_W = 32, TL_IW = TL_W + 2, TL_IH = TL_H + 2, TL_PIX = 
 constexpr int TL_MB = (TL_PIX + 31) / 32;                                                      // 11 blocks of 32 halo pixels
 template <int COUT>
 __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
-                                                       float oscale, int tiles_x, int tiles_y, int n_tiles) {
+                                                       int w_exp, const float* __restrict__ in_amax, int in_exp, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
+    const float oscale = sp16_pow2(-sp16_resolve_exp(in_amax, in_exp) - w_exp);   // acc = 2^(e_in + w_exp) sum w x  ->  true units
     __shared__ __attribute__((aligned(16))) float P[TL_PIX * PS + 32 * 36];       // (+ slack: the last pixel block writes 352 rows)
     // Workgroup b runs on XCD b % 8: every XCD takes a contiguous range of tiles (image-major, then rows), so that the two halo rows a
     // tile shares with the tile above and below it are re-read from THAT XCD's L2 while they are hot - with tiles dealt round-robin
@@ -565,8 +707,10 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
 // registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
 constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
 __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
-                                                       int sigma_stride, char* __restrict__ y, int H, int W, float oscale) {
+                                                       int sigma_stride, char* __restrict__ y, int H, int W, int w_exp, const float* __restrict__ in_amax,
+                                                       int in_exp, const float* __restrict__ out_amax, int out_exp, float* __restrict__ track) {
     __shared__ __attribute__((aligned(16))) float patch[HS_P * HS_QS + (HS_H + 2) * HS_SS];
+    __shared__ uint32_t trk_s[4];
     constexpr int SGM = HS_P * HS_QS;
     const int n = blockIdx.z, r0 = blockIdx.y * HS_H, c0 = blockIdx.x * HS_W;
     const int H2 = 2 * H, W2 = 2 * W;
@@ -579,6 +723,10 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
         patch[pr * HS_QS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
     }
     const float sig = sigma[(int64_t)n * sigma_stride];
+    // the operand gathered below holds 2^e_in (image | sigma): *in_amax is max |image| (the sigma plane is this kernel's own business)
+    const int e_in = in_amax ? sp16_act_exp(fmaxf(*in_amax, __builtin_fabsf(sig))) : in_exp, e_out = sp16_resolve_exp(out_amax, out_exp);
+    const float in_scale = sp16_pow2(e_in), oscale = sp16_pow2(e_out - e_in - w_exp);
+    float tmax = 0.0f;
     for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
         const int pr = e / HS_SW, pc = e - pr * HS_SW;
         const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
@@ -624,7 +772,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * ks + 8 * kb + j;
                 const bool is_sigma = (k < 45 ? k : 0) < 9;      // (sigma taps live in their own plane; per lane: k depends on its k block)
-                v[j >> 1][j & 1] = patch[off[ks][j] + (is_sigma ? sbase : pbase)] * SP_SCALE;
+                v[j >> 1][j & 1] = patch[off[ks][j] + (is_sigma ? sbase : pbase)] * in_scale;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -664,6 +812,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                     f32x2 t = (f32x2){acc[g][i], acc[g][i + 1]} * (f32x2){oscale, oscale};
                     t.x = __builtin_elementwise_maximum(t.x, 0.0f);
                     t.y = __builtin_elementwise_maximum(t.y, 0.0f);
+                    if (pix != RAW_OOB) tmax = fmaxf(tmax, fmaxf(t.x, t.y));                        // (positions of the image only)
                     const h2 hh = __builtin_convertvector(t, h2);
                     hi[e] = __builtin_bit_cast(unsigned, hh);
                     lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t - __builtin_convertvector(hh, f32x2), h2));
@@ -682,6 +831,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                 asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
             }
     }
+    if (track) sp16_track_block_max(tmax, sp16_pow2(-e_out), track, trk_s);      // (uniform: the range measurement of the first f-call)
 }
 
 }  // namespace s16
@@ -696,13 +846,16 @@ static void s16_magic(uint32_t d, uint32_t* mg, uint32_t* sh) {
     *mg = (uint32_t)(((1ull << (31 + s)) + d - 1) / d);
 }
 
+static bool bad_exp(int e) { return e < -SP16_EXP_LIMIT || e > SP16_EXP_LIMIT; }
+
 extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y, int64_t n, int64_t H, int64_t W,
-                                          int relu, float out_scale, float bias_scale, int out_f32, deqsci_stream_t stream, void* start_event,
-                                          void* stop_event) {
-    if (!x_sp16 || !w_packed || !y) return DEQSCI_ERR_NULL;
+                                          int relu, int w_exp, const float* in_amax, int in_exp, const float* out_amax, int out_exp,
+                                          float* track_amax, int out_f32, deqsci_stream_t stream, void* start_event, void* stop_event) {
+    if (!x_sp16 || !w_packed || (!y && !track_amax)) return DEQSCI_ERR_NULL;             // (a measuring launch writes no y: it may be NULL)
     if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
-    if (x_sp16 == y || (out_f32 != 0 && out_f32 != 1)) return DEQSCI_ERR_UNSUPPORTED;
+    if (x_sp16 == y || (out_f32 != 0 && out_f32 != 1) || bad_exp(w_exp) || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
+    if (track_amax && out_f32) return DEQSCI_ERR_UNSUPPORTED;        // (the range measurement serves the sp16 output)
     if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(y)) return DEQSCI_ERR_ALIGN;
     const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
@@ -717,56 +870,72 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
     hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
 #define S16_LAUNCH(KERNEL)                                                                                                                  \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
-                          bias, static_cast<char*>(y), (int)H, (int)W, relu, out_scale, bias_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles, mg_img,    \
-                          sh_img, \
-                          mg_tx, sh_tx)
-    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1>)); else S16_LAUNCH((s16::conv_s16_kernel<0>));
+                          bias, static_cast<char*>(y), (int)H, (int)W, relu, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, (int)tiles_x,       \
+                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx)
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0>));
+    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1>));
+    else S16_LAUNCH((s16::conv_s16_kernel<0, 0>));
 #undef S16_LAUNCH
     return launch_status();
 }
 
-extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream) {
+extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, const float* amax, int exp,
+                                     deqsci_stream_t stream) {
     if (!x_nhwc || !y_sp16) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
+    if (bad_exp(exp)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x_nhwc) || !aligned16(y_sp16)) return DEQSCI_ERR_ALIGN;
     const int64_t total = n * H * W * 8;
     hipLaunchKernelGGL(s16::f32_to_sp16_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), x_nhwc,
-                       static_cast<char*>(y_sp16), H * W, total, scale);
+                       static_cast<char*>(y_sp16), H * W, total, amax, exp);
+    return launch_status();
+}
+
+extern "C" int deqsci_absmax_f32(const float* x, int64_t count, float* amax, deqsci_stream_t stream) {
+    if (!x || !amax) return DEQSCI_ERR_NULL;
+    if (count <= 0) return DEQSCI_ERR_SHAPE;
+    if (!aligned16(x)) return DEQSCI_ERR_ALIGN;
+    const int64_t blocks = ceil_div(count, 256 * 4 * 8);             // eight float4 per lane
+    const int64_t cap = 8 * (int64_t)num_cus();
+    hipLaunchKernelGGL(s16::absmax_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, static_cast<hipStream_t>(stream), x, count, amax);
     return launch_status();
 }
 
 template <int COUT>
-static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax,
+                         int in_exp, deqsci_stream_t stream) {
     if (!x_sp16 || !w_packed || !out) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
-    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || bad_exp(w_exp) || bad_exp(in_exp)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x_sp16) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
     const int64_t tiles_x = ceil_div(W, s16::TL_W), tiles_y = ceil_div(H, s16::TL_H), n_tiles = n * tiles_x * tiles_y;
     if (n_tiles > (1 << 30)) return DEQSCI_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(8 * ceil_div(n_tiles, 8)));
     hipLaunchKernelGGL(s16::tail_s16_kernel<COUT>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
-                       static_cast<const char*>(w_packed), out, (int)H, (int)W, out_scale, (int)tiles_x, (int)tiles_y, (int)n_tiles);
+                       static_cast<const char*>(w_packed), out, (int)H, (int)W, w_exp, in_amax, in_exp, (int)tiles_x, (int)tiles_y, (int)n_tiles);
     return launch_status();
 }
 
-extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
-                                          deqsci_stream_t stream) {
-    return tail_s16_impl<4>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
+                                          const float* in_amax, int in_exp, deqsci_stream_t stream) {
+    return tail_s16_impl<4>(x_sp16, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
 }
 
-extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
-                                               deqsci_stream_t stream) {
-    return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, out_scale, stream);
+extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
+                                               const float* in_amax, int in_exp, deqsci_stream_t stream) {
+    return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
 }
 
 extern "C" int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
-                                          int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream) {
+                                          int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp, const float* out_amax,
+                                          int out_exp, float* track_amax, deqsci_stream_t stream) {
     if (!x || !w_packed || !sigma || !h_sp16) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
     if (n > 65535 || H > (1 << 20) || W > (1 << 20) || H * W * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    if (bad_exp(w_exp) || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h_sp16)) return DEQSCI_ERR_ALIGN;
     const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
     hipLaunchKernelGGL(s16::head_s16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
-                       (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, out_scale);
+                       (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
     return launch_status();
 }

@@ -31,24 +31,23 @@ constexpr int TT_CH = 32;                          // channels per LDS pass
 constexpr int TT_PS = TT_CH + 4;                   // LDS pixel stride (floats)
 
 
-// ---- "sp16" activations (csrc/conv_s16.hip): [n][chunk c (4)][piece hl (2)][block kb (2)][H][W][8 halfs] holding 2^8 x as hi + lo.
-// The 64->64 layers between the edge layers run on that layout when the engine picks the split-fp16 convolution; the heads then write it
-// and the tails read it directly (out_sp16 / in_sp16), instead of a conversion pass on either side.
+// ---- "sp16" activations (csrc/conv_s16.hip): [n][chunk c (4)][piece hl (2)][block kb (2)][H][W][8 halfs] holding 2^e x as hi + lo.
+// The 64->64 layers behind a head run on that layout when the engine picks the split-fp16 convolution; the 1 -> 64 stencil head then
+// writes it directly (OUT_SP16) instead of a conversion pass (FFDNet's head and both tails have matrix-core forms in conv_s16.hip).
 typedef _Float16 eh2 __attribute__((ext_vector_type(2)));
 typedef unsigned eu4 __attribute__((ext_vector_type(4)));
-constexpr float SP16_SCALE = 256.0f;
-__device__ __forceinline__ void sp16_split2(float a, float b, unsigned& hi, unsigned& lo) {
-    a *= SP16_SCALE; b *= SP16_SCALE;
+__device__ __forceinline__ void sp16_split2(float a, float b, float scale, unsigned& hi, unsigned& lo) {
+    a *= scale; b *= scale;
     const _Float16 ha = (_Float16)a, hb = (_Float16)b;
     hi = __builtin_bit_cast(unsigned, (eh2){ha, hb});
     lo = __builtin_bit_cast(unsigned, (eh2){(_Float16)(a - (float)ha), (_Float16)(b - (float)hb)});
 }
 // 16 lanes per position, lane cq owning couts 4 cq .. 4 cq + 3 (the vector-ALU heads): lanes cq and cq ^ 1 hold the two halves of one block
 // of 8 couts.  The even lane ends up with the block's hi piece, the odd lane with its lo piece: one 16-byte store each.
-__device__ __forceinline__ void sp16_store_quad(char* ysp, int64_t HW, int64_t pos, int cq, float4 v, bool ok) {
+__device__ __forceinline__ void sp16_store_quad(char* ysp, int64_t HW, int64_t pos, int cq, float4 v, float scale, bool ok) {
     unsigned h0, h1, l0, l1;
-    sp16_split2(v.x, v.y, h0, l0);
-    sp16_split2(v.z, v.w, h1, l1);
+    sp16_split2(v.x, v.y, scale, h0, l0);
+    sp16_split2(v.z, v.w, scale, h1, l1);
     const bool odd = cq & 1;
     const unsigned s0 = odd ? h0 : l0, s1 = odd ? h1 : l1;                 // what the partner stores: the even lane sends its lo, the odd its hi
     const unsigned r0 = (unsigned)__builtin_amdgcn_mov_dpp((int)s0, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
@@ -58,11 +57,9 @@ __device__ __forceinline__ void sp16_store_quad(char* ysp, int64_t HW, int64_t p
     if (ok) *reinterpret_cast<eu4*>(ysp + (((int64_t)((blk >> 1) * 4 + (odd ? 2 : 0) + (blk & 1))) * HW + pos) * 16) = o;
 }
 
-template <int COUT, int IN_SP16>   // COUT 4: FFDNet tail (2x2 pixel shuffle on the way out); 1: plain 64 -> 1 layer (SimpleCNN tail)
+template <int COUT>   // COUT 4: FFDNet tail (2x2 pixel shuffle on the way out); 1: plain 64 -> 1 layer (SimpleCNN tail)
 __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__ h, const float* __restrict__ wp,
                                                        const float* __restrict__ bias, float* __restrict__ out, int H, int W) {
-    // IN_SP16: h is an sp16 activation; the staging below reads, per (pixel, block of 8 channels), the 16-byte hi and lo pieces of two
-    // planes and writes (hi + lo) / 2^8 - exactly the fp32 value the split came from, to 2^-22 - into the same LDS tile
     __shared__ __attribute__((aligned(16))) float tile[TT_IH * TT_IW * TT_PS];
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * TT_H, c0 = blockIdx.x * TT_W;
@@ -74,64 +71,32 @@ __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__
     for (int o = 0; o < COUT; ++o) acc[o] = 0.0f;
     // staging: [TT_IH][TT_IW][32] per half (zero outside the image), 8 float4 per pixel, NST float4 per lane.  All loads of a
     // half are issued back to back into registers, and the second half is requested BEFORE the first is computed on.
-    constexpr int NE = IN_SP16 ? TT_IH * TT_IW * (TT_CH / 8) : TT_IH * TT_IW * (TT_CH / 4), NST = (NE + TB - 1) / TB;
-    float4 stg[IN_SP16 ? 2 * NST : NST];
+    constexpr int NE = TT_IH * TT_IW * (TT_CH / 4), NST = (NE + TB - 1) / TB;
+    float4 stg[NST];
     int sdst[NST];                                            // LDS float offset, -1 = no element
     int64_t soff[NST];                                        // global element offset, -1 = outside the image (zero)
-    const int64_t HW = (int64_t)H * W;
-    const char* hsp = reinterpret_cast<const char*>(h) + (int64_t)n * HW * 256;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int e = threadIdx.x + i * TB;
-        if (IN_SP16) {
-            // unit e = (block b of the half's four 8-channel blocks, tile pixel): consecutive lanes read consecutive pixels of one plane
-            const int b = e / (TT_IH * TT_IW), pix = e % (TT_IH * TT_IW);
-            const int pr = pix / TT_IW, pc = pix % TT_IW;
-            const int gr = r0 + pr - 1, gc = c0 + pc - 1;
-            sdst[i] = e < NE ? pix * TT_PS + 8 * b : -1;
-            soff[i] = (e < NE && gr >= 0 && gr < H && gc >= 0 && gc < W) ? (int64_t)gr * W + gc : -1;     // pixel index inside a plane
-        } else {
-            const int pix = e / (TT_CH / 4), q = e % (TT_CH / 4);
-            const int pr = pix / TT_IW, pc = pix % TT_IW;
-            const int gr = r0 + pr - 1, gc = c0 + pc - 1;
-            sdst[i] = e < NE ? pix * TT_PS + 4 * q : -1;
-            soff[i] = (e < NE && gr >= 0 && gr < H && gc >= 0 && gc < W) ? ((int64_t)gr * W + gc) * 64 + 4 * q : -1;
-        }
+        const int pix = e / (TT_CH / 4), q = e % (TT_CH / 4);
+        const int pr = pix / TT_IW, pc = pix % TT_IW;
+        const int gr = r0 + pr - 1, gc = c0 + pc - 1;
+        sdst[i] = e < NE ? pix * TT_PS + 4 * q : -1;
+        soff[i] = (e < NE && gr >= 0 && gr < H && gc >= 0 && gc < W) ? ((int64_t)gr * W + gc) * 64 + 4 * q : -1;
     }
     auto fetch_half = [&](int half) {
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            if (IN_SP16) {
-                const int b = (threadIdx.x + i * TB) / (TT_IH * TT_IW);                     // block of the half: chunk 2 half + (b >> 1), kb = b & 1
-                const int64_t plane = (int64_t)((2 * half + (b >> 1)) * 4 + (b & 1)) * HW;
-                stg[2 * i] = soff[i] >= 0 ? ld4(reinterpret_cast<const float*>(hsp + (plane + soff[i]) * 16)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                stg[2 * i + 1] = soff[i] >= 0 ? ld4(reinterpret_cast<const float*>(hsp + (plane + 2 * HW + soff[i]) * 16)) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            } else {
-                stg[i] = soff[i] >= 0 ? ld4(hn + soff[i] + half * TT_CH) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-        }
+        for (int i = 0; i < NST; ++i) stg[i] = soff[i] >= 0 ? ld4(hn + soff[i] + half * TT_CH) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
     auto store_half = [&](int half) {
 #pragma unroll
         for (int i = 0; i < NST; ++i) {
-            if (IN_SP16) {
-                typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-                const h8v hi = __builtin_bit_cast(h8v, stg[2 * i]), lo = __builtin_bit_cast(h8v, stg[2 * i + 1]);
-                float v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = ((float)hi[k] + (float)lo[k]) * (1.0f / SP16_SCALE);
-                if (sdst[i] >= 0) {
-                    *reinterpret_cast<float4*>(tile + sdst[i]) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(tile + sdst[i] + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                }
-            } else {
-                float4 v = stg[i];
-                if (bias && soff[i] >= 0) {   // the previous layer's folded-BN bias + ReLU applied on the way in (padding stays 0)
-                    const float4 b = ld4(bias + half * TT_CH + (sdst[i] % TT_PS));
-                    v.x = fmaxf(v.x + b.x, 0.0f); v.y = fmaxf(v.y + b.y, 0.0f); v.z = fmaxf(v.z + b.z, 0.0f); v.w = fmaxf(v.w + b.w, 0.0f);
-                }
-                if (sdst[i] >= 0) *reinterpret_cast<float4*>(tile + sdst[i]) = v;
+            float4 v = stg[i];
+            if (bias && soff[i] >= 0) {   // the previous layer's folded-BN bias + ReLU applied on the way in (padding stays 0)
+                const float4 b = ld4(bias + half * TT_CH + (sdst[i] % TT_PS));
+                v.x = fmaxf(v.x + b.x, 0.0f); v.y = fmaxf(v.y + b.y, 0.0f); v.z = fmaxf(v.z + b.z, 0.0f); v.w = fmaxf(v.w + b.w, 0.0f);
             }
+            if (sdst[i] >= 0) *reinterpret_cast<float4*>(tile + sdst[i]) = v;
         }
     };
     fetch_half(0);
@@ -172,10 +137,16 @@ __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__
 // Same mapping as the FFDNet head below: 16 lanes per position x 4 output channels each, 9 x 4 weights in
 // registers, a 34 x 34 patch in LDS read by broadcast; the kernel is bound by its 256 B/position store.
 constexpr int H1_T = 32, H1_P = H1_T + 2, H1_PS = H1_P + 1;
+// OUT_SP16: the output as an sp16 activation holding 2^e y, e from the range (out_amax, out_exp) (common.hpp); `track` (may be NULL):
+// max |y| of the launch folded into *track - the range measurement of the first f-call
 template <int OUT_SP16>
 __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restrict__ x, const float* __restrict__ wq,
-                                                           float* __restrict__ h, int H, int W, int relu) {
+                                                           float* __restrict__ h, int H, int W, int relu, const float* __restrict__ out_amax,
+                                                           int out_exp, float* __restrict__ track) {
     __shared__ float patch[H1_P * H1_PS];
+    __shared__ uint32_t trk_s[TB / WAVE];
+    const float oscale = OUT_SP16 ? sp16_pow2(sp16_resolve_exp(out_amax, out_exp)) : 1.0f;
+    float tmax = 0.0f;
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * H1_T, c0 = blockIdx.x * H1_T;
     const float* xn = x + (int64_t)n * H * W;
@@ -200,10 +171,13 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
         for (int tap = 0; tap < 9; ++tap) acc = fma4(patch[(lr + tap / 3) * H1_PS + lc + tap % 3], wr[tap], acc);
         if (r < H && c < W) {
             if (relu) { acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f); }
-            if (OUT_SP16) sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, acc, true);
-            else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
+            if (OUT_SP16) {
+                tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+                sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, acc, oscale, true);
+            } else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
         }
     }
+    if (OUT_SP16 && track) sp16_track_block_max(tmax, 1.0f, track, trk_s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,7 +191,7 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
 // padding of the unshuffled channels); the 16 lanes of a position read it by broadcast.
 // HD_T = tile side in half-res positions: 32, or 16 for grids that would leave CUs idle (8 images of 128 x 128 are 128 tiles of
 // 32 x 32 - half the chip - each a serial loop of 64 trips)
-template <int HD_T, int OUT_SP16>
+template <int HD_T>
 __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                          const float* __restrict__ sigma, int sigma_stride,
                                                          float* __restrict__ h, int H, int W) {
@@ -286,8 +260,7 @@ __global__ __launch_bounds__(TB) void ffdnet_head_kernel(const float* __restrict
         }
         if (r < H && c < W) {
             const float4 o4 = make_float4(fmaxf(al[0], 0.0f), fmaxf(al[1], 0.0f), fmaxf(ah[0], 0.0f), fmaxf(ah[1], 0.0f));
-            if (OUT_SP16) sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, o4, true);
-            else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, o4);
+            st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, o4);
         }
     }
 }
@@ -301,7 +274,6 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 #ifndef HEAD_ST
 #define HEAD_ST st4
 #endif
-template <int OUT_SP16>
 __global__ __launch_bounds__(TB) void ffdnet_head_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wq,
                                                               const float* __restrict__ sigma, int sigma_stride,
                                                               float* __restrict__ h, int H, int W) {
@@ -361,32 +333,7 @@ __global__ __launch_bounds__(TB) void ffdnet_head_mfma_kernel(const float* __res
             for (int cg = 0; cg < 4; ++cg) acc[cg] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cg][ks], pv[ks], acc[cg], 0, 0, 0);
         const int r = r0 + lr, c = c0 + lc0 + pn;
         if (r < H && c < W) {
-            if (OUT_SP16) {
-                // D: column = position pn, rows = couts 16 cg + 4 kq .. + 3.  An sp16 block is 8 couts: rows kq = 2 kb and 2 kb + 1 of one cout
-                // group hold its halves.  v_permlane16_swap on the registers of cout groups (A, B) = (0, 1) and (2, 3) swaps the odd rows of A's
-                // with the even rows of B's: lanes of even kq then hold the whole block (chunk A, kb = kq >> 1), lanes of odd kq (chunk B, kb).
-                // (the partner lane 16 away has the same position, hence the same predicate: no lane waits for an inactive one)
-                char* ysp = reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256;
-                const int64_t HW = (int64_t)H * W, pos = (int64_t)r * W + c;
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    unsigned ha[2], la[2], hb[2], lb[2];
-                    sp16_split2(fmaxf(acc[2 * pr][0], 0.0f), fmaxf(acc[2 * pr][1], 0.0f), ha[0], la[0]);
-                    sp16_split2(fmaxf(acc[2 * pr][2], 0.0f), fmaxf(acc[2 * pr][3], 0.0f), ha[1], la[1]);
-                    sp16_split2(fmaxf(acc[2 * pr + 1][0], 0.0f), fmaxf(acc[2 * pr + 1][1], 0.0f), hb[0], lb[0]);
-                    sp16_split2(fmaxf(acc[2 * pr + 1][2], 0.0f), fmaxf(acc[2 * pr + 1][3], 0.0f), hb[1], lb[1]);
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        auto sh = __builtin_amdgcn_permlane16_swap(ha[e], hb[e], false, false);
-                        ha[e] = sh[0]; hb[e] = sh[1];
-                        auto sl = __builtin_amdgcn_permlane16_swap(la[e], lb[e], false, false);
-                        la[e] = sl[0]; lb[e] = sl[1];
-                    }
-                    const int chunk = 2 * pr + (kq & 1), kb = kq >> 1;
-                    *reinterpret_cast<eu4*>(ysp + ((int64_t)(chunk * 4 + 0 + kb) * HW + pos) * 16) = (eu4){ha[0], ha[1], hb[0], hb[1]};
-                    *reinterpret_cast<eu4*>(ysp + ((int64_t)(chunk * 4 + 2 + kb) * HW + pos) * 16) = (eu4){la[0], la[1], lb[0], lb[1]};
-                }
-            } else {
+            {
                 float* o = hn + ((int64_t)r * W + c) * 64 + 4 * kq;    // D: column = position pn, rows 4 kq .. 4 kq + 3 of the cout group
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg)
@@ -400,8 +347,8 @@ __global__ __launch_bounds__(TB) void ffdnet_head_mfma_kernel(const float* __res
 
 using namespace deqsci;
 
-static int head_impl(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, float* h, int64_t n, int64_t H, int64_t W,
-                     int sp16, deqsci_stream_t stream) {
+extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, float* h,
+                                      int64_t n, int64_t H, int64_t W, deqsci_stream_t stream) {
     if (!x || !w_packed || !sigma || !h) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
     if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
@@ -418,76 +365,54 @@ static int head_impl(const float* x, const float* w_packed, const float* sigma, 
         hipLaunchKernelGGL(KERNEL, grid, dim3(TB), 0, st, x, w_packed, sigma, (int)sigma_stride, h, (int)H, (int)W);                    \
     } while (0)
     const bool big = ceil_div(W, 32) * ceil_div(H, 32) * n >= 2 * (int64_t)num_cus();
-    if (!head_vector_only && big) { if (sp16) HEAD_LAUNCH((ffdnet_head_mfma_kernel<1>), 32); else HEAD_LAUNCH((ffdnet_head_mfma_kernel<0>), 32); }
-    else if (big) { if (sp16) HEAD_LAUNCH((ffdnet_head_kernel<32, 1>), 32); else HEAD_LAUNCH((ffdnet_head_kernel<32, 0>), 32); }
-    else { if (sp16) HEAD_LAUNCH((ffdnet_head_kernel<16, 1>), 16); else HEAD_LAUNCH((ffdnet_head_kernel<16, 0>), 16); }
+    if (!head_vector_only && big) HEAD_LAUNCH(ffdnet_head_mfma_kernel, 32);
+    else if (big) HEAD_LAUNCH((ffdnet_head_kernel<32>), 32);
+    else HEAD_LAUNCH((ffdnet_head_kernel<16>), 16);
 #undef HEAD_LAUNCH
     return launch_status();
 }
 
-extern "C" int deqsci_ffdnet_head_f32(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, float* h,
-                                      int64_t n, int64_t H, int64_t W, deqsci_stream_t stream) {
-    return head_impl(x, w_packed, sigma, sigma_stride, h, n, H, W, 0, stream);
-}
-
-extern "C" int deqsci_ffdnet_head_sp16(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
-                                       int64_t n, int64_t H, int64_t W, deqsci_stream_t stream) {
-    return head_impl(x, w_packed, sigma, sigma_stride, static_cast<float*>(h_sp16), n, H, W, 1, stream);
-}
-
 template <int COUT>
-static int tail_impl(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n, int64_t H, int64_t W, int sp16,
-                     deqsci_stream_t stream) {
+static int tail_impl(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n, int64_t H, int64_t W, deqsci_stream_t stream) {
     if (!h || !w_packed || !out) return DEQSCI_ERR_NULL;
     if (in_bias && !aligned16(in_bias)) return DEQSCI_ERR_ALIGN;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
-    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || (sp16 && in_bias)) return DEQSCI_ERR_UNSUPPORTED;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(h) || !aligned16(w_packed) || !aligned16(out)) return DEQSCI_ERR_ALIGN;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(W, TT_W), (unsigned)ceil_div(H, TT_H), (unsigned)n);
-    if (sp16) hipLaunchKernelGGL((edge_tail_kernel<COUT, 1>), grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
-    else hipLaunchKernelGGL((edge_tail_kernel<COUT, 0>), grid, dim3(TB), 0, st, h, w_packed, in_bias, out, (int)H, (int)W);
+    hipLaunchKernelGGL((edge_tail_kernel<COUT>), grid, dim3(TB), 0, static_cast<hipStream_t>(stream), h, w_packed, in_bias, out, (int)H, (int)W);
     return launch_status();
 }
 
 extern "C" int deqsci_ffdnet_tail_f32(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n, int64_t H,
                                       int64_t W, deqsci_stream_t stream) {
-    return tail_impl<4>(h, w_packed, in_bias, out, n, H, W, 0, stream);
-}
-
-extern "C" int deqsci_ffdnet_tail_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
-                                       deqsci_stream_t stream) {
-    return tail_impl<4>(static_cast<const float*>(h_sp16), w_packed, nullptr, out, n, H, W, 1, stream);
+    return tail_impl<4>(h, w_packed, in_bias, out, n, H, W, stream);
 }
 
 extern "C" int deqsci_conv3x3_c64_to_1_f32(const float* h, const float* w_packed, const float* in_bias, float* out, int64_t n,
                                            int64_t H, int64_t W, deqsci_stream_t stream) {
-    return tail_impl<1>(h, w_packed, in_bias, out, n, H, W, 0, stream);
+    return tail_impl<1>(h, w_packed, in_bias, out, n, H, W, stream);
 }
 
-extern "C" int deqsci_conv3x3_c64_to_1_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
-                                            deqsci_stream_t stream) {
-    return tail_impl<1>(static_cast<const float*>(h_sp16), w_packed, nullptr, out, n, H, W, 1, stream);
-}
-
-static int c1_to_64_impl(const float* x, const float* w_packed, float* h, int64_t n, int64_t H, int64_t W, int relu, int sp16, deqsci_stream_t stream) {
+static int c1_to_64_impl(const float* x, const float* w_packed, float* h, int64_t n, int64_t H, int64_t W, int relu, int sp16, const float* out_amax,
+                         int out_exp, float* track_amax, deqsci_stream_t stream) {
     if (!x || !w_packed || !h) return DEQSCI_ERR_NULL;
     if (n <= 0 || H <= 0 || W <= 0) return DEQSCI_ERR_SHAPE;
-    if (n > 65535 || H > (1 << 20) || W > (1 << 20)) return DEQSCI_ERR_UNSUPPORTED;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || out_exp < -SP16_EXP_LIMIT || out_exp > SP16_EXP_LIMIT) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(W, H1_T), (unsigned)ceil_div(H, H1_T), (unsigned)n);
-    if (sp16) hipLaunchKernelGGL(conv_c1_to_64_kernel<1>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu);
-    else hipLaunchKernelGGL(conv_c1_to_64_kernel<0>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu);
+    if (sp16) hipLaunchKernelGGL(conv_c1_to_64_kernel<1>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
+    else hipLaunchKernelGGL(conv_c1_to_64_kernel<0>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
     return launch_status();
 }
 
 extern "C" int deqsci_conv3x3_c1_to_64_f32(const float* x, const float* w_packed, float* h, int64_t n, int64_t H, int64_t W,
                                            int relu, deqsci_stream_t stream) {
-    return c1_to_64_impl(x, w_packed, h, n, H, W, relu, 0, stream);
+    return c1_to_64_impl(x, w_packed, h, n, H, W, relu, 0, nullptr, 0, nullptr, stream);
 }
 
 extern "C" int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W,
-                                            int relu, deqsci_stream_t stream) {
-    return c1_to_64_impl(x, w_packed, static_cast<float*>(h_sp16), n, H, W, relu, 1, stream);
+                                            int relu, const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream) {
+    return c1_to_64_impl(x, w_packed, static_cast<float*>(h_sp16), n, H, W, relu, 1, out_amax, out_exp, track_amax, stream);
 }

@@ -188,17 +188,33 @@ def _tail(path, lines=25):
 def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
     """Run `argv` (a full command line) as n child processes, rank r with RANK=r, LOCAL_RANK=device_ids[r] (default r),
     WORLD_SIZE=n and a fresh 127.0.0.1 rendezvous port.  Children are NEW processes (never an exec of this one); rank 0 inherits
-    stdout; every rank's stderr goes to a scratch file that is echoed when the run ends (the tail of a failing rank first).
-    Returns 0, or the exit code of the first rank that failed (128 + signal number for a rank killed by a signal, 124 on timeout);
-    when a rank fails - or this process is interrupted / terminated - the others are terminated, then killed, and reaped.
+    stdout; every rank's stderr goes to a scratch file - rank 0's is forwarded LIVE (warnings and progress of long runs), the other
+    ranks' when the run ends; when a rank fails, the stderr tail of EVERY rank is printed, the failing one first (the root cause is
+    often on another rank than the first to exit).  Returns 0, or the exit code of the first rank that failed (128 + signal number for
+    a rank killed by a signal, 124 on timeout); when a rank fails - or this process is interrupted / terminated - the others are
+    terminated, then killed, and reaped, and the logs are still echoed and removed (all of it in the finally block).
     A rendezvous that loses the race for its port (EADDRINUSE between free_port() and the bind of rank 0) is retried once on
     a new port; nothing else is ever retried."""
+    import shutil
     import signal
     import sys
     import tempfile
     port = free_port()
     procs, logs = [], []
     scratch = tempfile.mkdtemp(prefix="deqsci_ranks_")
+    forwarded = [0]                                      # bytes of rank 0's stderr already passed through
+
+    def forward_rank0():
+        try:
+            with open(logs[0], "rb") as fh:
+                fh.seek(forwarded[0])
+                chunk = fh.read()
+        except (OSError, IndexError):
+            return
+        if chunk:
+            forwarded[0] += len(chunk)
+            sys.stderr.write(chunk.decode(errors="replace"))
+            sys.stderr.flush()
 
     def on_term(signum, frame):
         raise KeyboardInterrupt(f"signal {signum}")
@@ -207,7 +223,7 @@ def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
         old = signal.signal(signal.SIGTERM, on_term)
     except ValueError:                                   # not the main thread: the try/finally below still reaps on exceptions
         pass
-    first_bad, code = None, 0
+    first_bad, code, retry, finished = None, 0, False, False
     try:
         for r in range(n):
             env = dict(os.environ)
@@ -229,31 +245,34 @@ def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
                     first_bad, code = r, (128 - rc if rc < 0 else rc)
             if deadline is not None and time.time() > deadline and first_bad is None and live:
                 first_bad, code = live[0], 124
+            forward_rank0()
             if live and first_bad is None:
                 time.sleep(0.05)
+        finished = True
     finally:
         _stop(procs)
         if old is not None:
             signal.signal(signal.SIGTERM, old)
-    retry = False
-    if first_bad is not None:
-        text = _tail(logs[first_bad], 60)
-        retry = _attempts > 1 and code != 124 and ("EADDRINUSE" in text or "ddress already in use" in text)
-        if not retry:
-            sys.stderr.write(f"[launch_ranks] rank {first_bad} of {n} {'timed out' if code == 124 else 'failed'} (exit code {code}); "
-                             f"the other ranks were stopped.  Its stderr tail:\n{text}")
-    else:
-        for r in range(n):                                   # a clean run: pass the ranks' stderr through (warnings, progress)
-            sys.stderr.write(_tail(logs[r], 10 ** 6))
-    for f in logs:
         try:
-            os.remove(f)
-        except OSError:
-            pass
-    try:
-        os.rmdir(scratch)
-    except OSError:
-        pass
+            if first_bad is not None:
+                text = _tail(logs[first_bad], 60)
+                retry = _attempts > 1 and code != 124 and ("EADDRINUSE" in text or "ddress already in use" in text)
+                if not retry:
+                    forward_rank0()
+                    sys.stderr.write(f"[launch_ranks] rank {first_bad} of {n} {'timed out' if code == 124 else 'failed'} (exit code {code}); the other "
+                                     "ranks were stopped.  " + ("Its stderr is above.\n" if first_bad == 0 else f"Its stderr tail:\n{text}"))
+                    for r in range(1, len(logs)):            # (rank 0's went through live)
+                        other = _tail(logs[r], 25) if r != first_bad else ""
+                        if other:
+                            sys.stderr.write(f"[launch_ranks] stderr tail of rank {r}:\n{other}")
+            else:
+                forward_rank0()                              # a clean (or interrupted) run: the rest of rank 0, then the other ranks' stderr
+                for r in range(1, len(logs)):
+                    sys.stderr.write(_tail(logs[r], 10 ** 6))
+                if not finished:
+                    sys.stderr.write(f"[launch_ranks] interrupted: {len(procs)} rank(s) stopped\n")
+        finally:
+            shutil.rmtree(scratch, ignore_errors=True)
     if retry:
         return launch_ranks(argv, n, device_ids=device_ids, timeout=timeout, _attempts=_attempts - 1)
     return code

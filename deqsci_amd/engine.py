@@ -31,7 +31,6 @@ backward hook) is skipped unless `extra_call=True`.
 """
 import math
 import numpy as np
-import os
 
 import torch
 import torch.nn.functional as F
@@ -64,7 +63,8 @@ class _Denoiser:
     `run(z1_planar, call) -> (tensor (bsz,B,H,W), is_noise)`; dispatch as at
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
-    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast"):
+    def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
+                 act_range="data", blk32=True):
         from .networks import FFDNet
         self.net = net
         self.fused_edges = fused_edges
@@ -73,7 +73,15 @@ class _Denoiser:
         self.f22_calls = None                                       # f-calls [0, f22_calls) run F(2x2,3x3) whatever the policy (DEQSCIEngine)
         self._native_out = False
         self._policy = conv64
-        self.blk32 = os.environ.get("DEQSCI_BLK32", "1") != "0"     # (A/B knob) blk32 activations between F(4x4,3x3) layers
+        self.blk32 = bool(blk32)                                    # blk32 activations between F(4x4,3x3) layers (False: an A/B of the tools)
+        # The scales of the split-fp16 layers' activations: "data" = every activation's power-of-two scale follows max |activation| as
+        # measured ON THE DEVICE during the first f-call of a reconstruction (run(..., calibrate=True): each layer is run once to measure,
+        # once to write - fp32 is scale-free, fp16 is not; see _hip.act_exp); "fixed" = 2^8 throughout (activations of a few units).
+        if act_range not in ("data", "fixed"):
+            raise ValueError(f"act_range={act_range!r}: expected 'data' or 'fixed'")
+        self.act_range = act_range
+        self.ranges = None                                          # (len(layers) + 1,) fp32 on the device: slot i = max |input of layer i|
+        self._calibrating = False
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
         # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
         # 128x128x64 layers, 11 % slower for SimpleCNN's 256x256x64 ones.
@@ -133,9 +141,12 @@ class _Denoiser:
             self.fast = layers
             # 64->64 layers: Winograd on the fp32 matrix cores with bias+ReLU fused: F(4x4,3x3) (csrc/winograd44.hip) when the
             # launch has more than a wave of block tiles, F(2x2,3x3) (csrc/winograd.hip) below that - _hip.conv3x3_c64 picks
-            self.wino = [(_hip.pack_conv64_weights(w) if (self.winograd and self.channels_last and w.is_cuda
-                                                             and tuple(w.shape) == (64, 64, 3, 3)) else None)
+            # (the split-fp16 pack costs a host sync: made here, never inside a hipGraph capture, whenever the policy can pick that kernel)
+            s16 = self.conv64 in ("fast", "s16")
+            self.wino = [(_hip.pack_conv64_weights(w, s16=s16) if (self.winograd and self.channels_last and w.is_cuda
+                                                                      and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
+            self.ranges = None
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
@@ -190,8 +201,13 @@ class _Denoiser:
                         _hip.conv64_kernel_for(h.shape[0], h.shape[2], h.shape[3], h.device, self._policy))
                 if kind == "s16":
                     if not isinstance(h, _hip.Sp16):
-                        h = _hip.to_split16(h)
-                    h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not (chain or (nxt is None and self._native_out)))
+                        if self._calibrating:
+                            _hip.absmax(h, self._slot(i))
+                        h = _hip.to_split16(h, rng=self._slot(i))
+                    sp_out = chain or (nxt is None and self._native_out)
+                    if sp_out and self._calibrating:               # measure max |output| of this layer, then write it with that range
+                        _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, track=self._slot(i + 1))
+                    h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not sp_out, out_rng=self._slot(i + 1) if sp_out else None)
                 elif kind == "f44":
                     h = _hip.conv3x3_c64_winograd44(h, self.wino[i].f44, b, relu, out_blk=bool(self.blk32 and chain))
                 else:
@@ -205,18 +221,30 @@ class _Denoiser:
                     h = F.relu_(h)
         return h
 
+    def _slot(self, i):
+        """Range slot of the input of layer i (= the output of layer i - 1), or None under act_range="fixed"."""
+        return None if self.ranges is None else self.ranges[i:i + 1]
+
     def prepare(self, n_calls, device):
         self._refresh()
+        if self.fast is not None and self.act_range == "data" and (self.ranges is None or self.ranges.device != torch.device(device)):
+            # kept across calls: a captured hipGraph carries this tensor's address in its conv nodes
+            self.ranges = torch.zeros(len(self.fast) + 1, dtype=torch.float32, device=device)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
                 # kept across calls: a captured hipGraph carries this tensor's address in its FFDNet-head nodes
                 self.sigma_table = torch.from_numpy(sigma_schedule(n_calls)).to(device)
 
-    def run(self, z1, call):
+    def run(self, z1, call, calibrate=False):
+        """calibrate: measure the ranges of the split-fp16 activations on this input (the engine: at the first f-call of a reconstruction)
+        instead of using the ones measured last."""
         bsz, B, H, W = z1.shape
         x = z1.view(bsz * B, 1, H, W)
         self._policy = "f22" if (self.f22_calls is not None and call < self.f22_calls) else self.conv64
+        self._calibrating = cal = bool(calibrate) and self.ranges is not None and x.is_cuda
+        if cal:
+            self.ranges.zero_()
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
@@ -225,7 +253,14 @@ class _Denoiser:
                       and _hip.conv64_kernel_for(bsz * B, H // 2, W // 2, x.device, self._policy) == "s16")
                 if self.head_w is not None and x.is_cuda:
                     sg = self.sigma_table[call:call + 1]
-                    h, first_done = (_hip.ffdnet_head_split16(x, self.head_w16, sg) if sp else _hip.ffdnet_head(x, self.head_w, sg)), True
+                    if sp:
+                        if cal:                                # max |image| (the head adds sigma itself), then max |its own output|
+                            _hip.absmax(x, self._slot(0))
+                            _hip.ffdnet_head_split16(x, self.head_w16, sg, in_rng=self._slot(0), out_exp=0, track=self._slot(1))
+                        h = _hip.ffdnet_head_split16(x, self.head_w16, sg, in_rng=self._slot(0), out_rng=self._slot(1))
+                    else:
+                        h = _hip.ffdnet_head(x, self.head_w, sg)
+                    first_done = True
                 else:
                     h = torch.cat((sig.view(-1, 1, 1, 1).expand(bsz * B, 1, H // 2, W // 2), F.pixel_unshuffle(x, 2)), 1)
                     first_done = False
@@ -247,7 +282,9 @@ class _Denoiser:
                     first = self.plain_head_w is not None
                     sp = (first and self.plain_tail_w is not None and all(u is not None for u in self.wino[1:-1])
                           and _hip.conv64_kernel_for(bsz * B, H, W, x.device, self._policy) == "s16")
-                    h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp) if first else x
+                    if first and sp and cal:
+                        _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=True, out_exp=0, track=self._slot(1))
+                    h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp, out_rng=self._slot(1) if sp else None) if first else x
                     if self.plain_tail_w is not None:
                         h = self._run_stack(h, skip_first=first, skip_last=True, native_out=sp)
                         out = (_hip.tail_split16(h, self.plain_tail_w16) if isinstance(h, _hip.Sp16) else
@@ -268,7 +305,7 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
@@ -278,7 +315,7 @@ class DEQSCIEngine:
         # F(2x2,3x3)); "f22" / "f44" / "s16" one kernel always.  `conv64_f22_calls=K` additionally runs the first K f-calls on F(2x2,3x3).
         # What the choice does to the result was measured where it can matter - FFDNet under Anderson beyond ~30 iterations is chaotic
         #  - as 25-start ensembles over the six traffic measurements (tools/config2_ensemble.py,
-        # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.008 (as it is 21.439 +- 0.005); F(2x2,3x3)
+        # profiles/r03_config2_ensembles.json; mean PSNR, standard error 0.004): reference 21.434 +- 0.004 (as it is 21.439 +- 0.005); F(2x2,3x3)
         # 21.420; split-fp16 21.428; F(2x2,3x3) for 40 f-calls then F(4x4,3x3) 21.417; MIOpen's direct fp32 convolution 21.410;
         # F(4x4,3x3) throughout 21.395.  Single measurements move by up to 0.09 dB under ANY change of arithmetic (the reference's own two
         # Gram variants: RMS 0.065 dB), so only the pooled mean separates kernels; it puts split-fp16 and F(2x2,3x3) together, nearest
@@ -287,8 +324,11 @@ class DEQSCIEngine:
         self.conv64 = conv64
         self.conv64_policy = "fast" if conv64 == "auto" else conv64
         self.conv64_f22_calls = None if conv64_f22_calls is None else int(conv64_f22_calls)
+        # act_range: "data" (default) = the power-of-two scales of the split-fp16 activations follow the data, measured on the device at
+        # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
+        # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
@@ -318,7 +358,7 @@ class DEQSCIEngine:
 
     # ------------------------------------------------------------------ one f-call = GAP -> denoise -> store -> solve
     def _store_solve(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
-        out, is_noise = self.den.run(ws.z1, call)
+        out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
         out = _hip.f32c(out)
         if is_noise:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
@@ -341,13 +381,21 @@ class DEQSCIEngine:
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
         with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
             rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
-            if self.conv64 == "auto" and self.conv64_policy == "fast" and not math.isfinite(self.last_info["res"]):
+            self.last_info["conv64_fallback"] = None
+            if self.conv64 == "auto" and not math.isfinite(self.last_info["res"]) and bool(torch.isfinite(y).all()):
                 # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
-                # about) is redone once on the fp32 MFMA kernels, and this engine stays on them.  A run that diverges by itself comes
-                # back non-finite again and is returned as it is.
+                # about) is redone on the fp32 MFMA kernels - THIS call only (eagerly; a captured hipGraph and the policy of later,
+                # unrelated inputs are left alone; every rank of a sharded job decides for its own call) - and last_info says so.  A run
+                # that diverges by itself comes back non-finite again and is returned as it is.
+                saved = (self.conv64_policy, self.den.conv64, self.use_graph)
                 self.conv64_policy = self.den.conv64 = self.den._policy = "fast32"
-                self._graph = None
-                rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+                self.use_graph = False
+                try:
+                    rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+                finally:
+                    self.conv64_policy, self.den.conv64, self.use_graph = saved
+                    self.den._policy = saved[1]
+                self.last_info["conv64_fallback"] = "fast32"
             return rec
 
     def _reconstruct(self, y, Phi, Phi_sum, initial_point):
@@ -383,11 +431,12 @@ class DEQSCIEngine:
         it inf / NaN all the way to the output on purpose) looks like from here - as does a genuinely diverging run.  Say so, loudly."""
         import warnings
         if not math.isfinite(self.last_info["res"]) and self.conv64_policy in ("fast", "s16"):
-            what = ("redoing it with conv64='fast32' (fp32 MFMA kernels, no such limit), which this engine now keeps" if self.conv64 == "auto"
+            what = ("redoing this call with conv64='fast32' (fp32 MFMA kernels, no such limit; last_info['conv64_fallback'])" if self.conv64 == "auto"
                     else "rerun with conv64='fast32' (fp32 MFMA kernels, no such limit)")
+            how = ("16 x the largest activation of the first f-call, which set the scales" if self.den.act_range == "data" and self.den.ranges is not None
+                   else "|x| >= 255.9 under act_range='fixed'; inputs are expected in [0, 1]")
             warnings.warn("DEQSCIEngine: the reconstruction's residual is not finite.  If the iteration itself is not diverging, an activation of "
-                          "the denoiser has left fp16's range inside the split-fp16 64->64 layers (|x| >= 255.9; inputs are expected in [0, 1]): "
-                          + what + ".", RuntimeWarning, stacklevel=4)
+                          f"the denoiser has left fp16's range inside the split-fp16 64->64 layers ({how}): " + what + ".", RuntimeWarning, stacklevel=4)
 
     def _enqueue(self, ws, y, Phi4, Phi_sum, initial_point, poll):
         """Every launch of one reconstruction on the current stream.  poll: True = lagged residual read-back with early stop,
@@ -496,6 +545,8 @@ class DEQSCIEngine:
         _hip.gap_update(xb[0], phi, y, ps, LAYOUT_BHW, out=ws.z1)
         self._store_solve(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-7, 0)           # f0 = f(x0)
         if self.max_iter <= 0:
+            if poll is not None:
+                ws.host_res[0].copy_(ws.res[0], non_blocking=True)
             return xb[1], 1, 0
         last, prev_ev = None, None
         for k in range(self.max_iter):

@@ -187,38 +187,48 @@ int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_pack
 /* ---- the same layer as a DIRECT convolution on the f16 matrix cores with fp32-class accuracy (csrc/conv_s16.hip): every operand
  *     is two fp16 pieces (x = hi + lo, 22 significant bits), three f16 MFMAs per product (w_hi x_hi + w_lo x_hi + w_hi x_lo), fp32
  *     accumulation.  x_sp16: the activation as [n][4 cin chunks][2 pieces: hi, lo][2 blocks of 8 channels][H][W][8 halfs] holding
- *     2^8 x (deqsci_f32_to_split16 writes it from fp32 channels_last; the kernel itself writes it with out_f32 = 0).  w_packed:
- *     2^sw w as [4 chunks][9 taps][2 pieces][2 cout groups of 32][64 lanes][8 halfs] (cout = 32 g + lane % 32, cin = 16 c +
- *     8 (lane / 32) + j).  Output = relu?(acc * out_scale + bias * bias_scale): out_f32 = 0 -> sp16 of 2^8 y (pass out_scale = 2^-sw,
- *     bias_scale = 2^8), out_f32 = 1 -> fp32 channels_last (n,H,W,64) (pass out_scale = 2^-(8+sw), bias_scale = 1).  An activation beyond
- *     fp16's range (|y| >= 255.9) becomes inf, never a silently wrong finite number.  Images up to 2^31 / 256 - 33 pixels.
- *     start_event / stop_event: both NULL, or both raw hipEvent_t handles (measurement). */
+ *     2^e x.  w_packed: 2^w_exp w as [4 chunks][9 taps][2 pieces][2 cout groups of 32][64 lanes][8 halfs] (cout = 32 g + lane % 32,
+ *     cin = 16 c + 8 (lane / 32) + j), w_exp the power of two that puts max |w| into [2^13, 2^14).
+ *
+ *     RANGES.  fp32 (the reference's arithmetic, solvers/equilibrium_solvers_yaping.py:397-420) is scale-free, fp16 is not, so the
+ *     exponent e of an sp16 activation follows the data.  Every sp16 activation is described by a pair (amax, exp): `amax` a DEVICE
+ *     pointer to max |x| of that activation - then e = DEQSCI_SP16_TARGET_EXP - floor(log2(*amax)), i.e. 2^e max|x| in [2^11, 2^12),
+ *     derived identically by the kernel that writes the activation and the kernel that reads it - or NULL: the fixed exponent `exp`
+ *     (DEQSCI_SP16_DEFAULT_EXP = 8 suits activations of a few units).  `track_amax` (may be NULL): a MEASURING launch - the same arithmetic,
+ *     but max |y| of the output is folded into *track_amax (zero it first) and, for the 64->64 layer, y itself is not written: run a
+ *     layer once with track_amax = the slot of its output, then again with out_amax = that slot.  Nothing crosses to the host: a captured hipGraph follows
+ *     its inputs.  An activation that outgrows fp16 (16 x the measured maximum) becomes inf, never a silently wrong finite number.
+ *
+ *     Output = relu?(conv + bias): out_f32 = 0 -> sp16 with the range (out_amax, out_exp); out_f32 = 1 -> fp32 channels_last
+ *     (n,H,W,64).  Images up to 2^31 / 256 - 33 pixels.  start_event / stop_event: both NULL, or both raw hipEvent_t handles. */
+#define DEQSCI_SP16_DEFAULT_EXP 8
+#define DEQSCI_SP16_TARGET_EXP 11
 int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const float* bias, void* y,
-                               int64_t n, int64_t H, int64_t W, int relu, float out_scale, float bias_scale, int out_f32,
+                               int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
+                               const float* out_amax, int out_exp, float* track_amax, int out_f32,
                                deqsci_stream_t stream, void* start_event, void* stop_event);
-int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, float scale, deqsci_stream_t stream);
-/* The edge layers of the denoisers with the sp16 layout on their 64-channel side (same kernels, other stores / loads): the heads
- *     write relu(conv) as sp16 (2^8 x as hi + lo), the tails read sp16 - no conversion pass on either side of a run of split16 layers. */
-int deqsci_ffdnet_head_sp16(const float* x, const float* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
-                            int64_t n, int64_t H, int64_t W, deqsci_stream_t stream);
-int deqsci_ffdnet_tail_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
-                            deqsci_stream_t stream);
+/* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and max |x| over `count` floats folded into *amax (zero it first):
+ *     the range of an activation no sp16-writing kernel produced (the denoiser's input image; a converted fp32 activation). */
+int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, const float* amax, int exp,
+                          deqsci_stream_t stream);
+int deqsci_absmax_f32(const float* x, int64_t count, float* amax, deqsci_stream_t stream);
+/* SimpleCNN's first layer (conv3x3 1 -> 64 [+ ReLU], deqsci_conv3x3_c1_to_64_f32) writing sp16 with the range (out_amax, out_exp)
+ *     instead of fp32 channels_last - no conversion pass in front of a run of split16 layers. */
 int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W, int relu,
-                                 deqsci_stream_t stream);
-int deqsci_conv3x3_c64_to_1_sp16(const void* h_sp16, const float* w_packed, float* out, int64_t n, int64_t H, int64_t W,
-                                 deqsci_stream_t stream);
-/* The same last layers (conv3x3 64 -> 4 + pixel shuffle / 64 -> 1, no bias) on the f16 matrix cores with the split-fp16 arithmetic of
+                                 const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);
+/* The denoisers' last layers (conv3x3 64 -> 4 + pixel shuffle / 64 -> 1, no bias) on the f16 matrix cores with the split-fp16 arithmetic of
  *     deqsci_conv3x3_c64_split16: the 9 taps ride in the matrix N dimension (column = COUT tap + cout), the per-tap products are summed from
- *     LDS.  w_packed: 2^sw w as [4 chunks][2 pieces][N tiles][64 lanes][8 halfs]; out_scale = 2^-(8+sw). */
-int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
-                               deqsci_stream_t stream);
+ *     LDS.  w_packed: 2^w_exp w as [4 chunks][2 pieces][N tiles][64 lanes][8 halfs]; the input's range is (in_amax, in_exp); fp32 out. */
+int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                               int w_exp, const float* in_amax, int in_exp, deqsci_stream_t stream);
+int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                                    int w_exp, const float* in_amax, int in_exp, deqsci_stream_t stream);
 /* FFDNet's first layer (sigma map + pixel-unshuffle + conv3x3 5 -> 64 + ReLU) likewise, writing sp16: K = 45 taps padded to 48, the
- *     activation operand gathered from the image and split on the fly.  w_packed: 2^sw w as [3 k steps][2 pieces][2 cout groups][64 lanes]
- *     [8 halfs], k = 9 ch + tap; out_scale = 2^-sw (the 2^8 of the input split carries over to the sp16 output). */
+ *     activation operand gathered from the image and split on the fly at 2^e_in, e_in from max(*in_amax, sigma) (in_amax = max |x| of
+ *     the image; NULL: in_exp).  w_packed: 2^w_exp w as [3 k steps][2 pieces][2 cout groups][64 lanes][8 halfs], k = 9 ch + tap. */
 int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
-                               int64_t n, int64_t H, int64_t W, float out_scale, deqsci_stream_t stream);
-int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, float out_scale,
-                                    deqsci_stream_t stream);
+                               int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp,
+                               const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);
 
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,

@@ -58,24 +58,31 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 1, 8192, 1025, 1, None) == -4   # 1025 columns pad to 1056
     assert _hip.conv64_kernel_for(64, 2900, 2900, policy="fast") == "f22"                           # the front end falls back by itself
     assert _hip.W44_MAX_PIXELS * 256 + 4096 + 2048 + 16 <= 2 ** 31 < (_hip.W44_MAX_PIXELS + 1) * 256 + 4096 + 2048 + 16
-    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4    # in place
-    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
-    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
-    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 0, 16, 16, 1, None) == -2
-    assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 2, 0, None, None, None) == -4   # unknown layout
-    assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 1, 1, None, p16, None) == -1   # one event only
-    # the split-fp16 convolution and its edge layers: the same contract
-    assert lib.deqsci_conv3x3_c64_split16(None, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -1
-    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, p16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -4      # in place
-    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 2, None, None, None) == -4      # unknown output form
-    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 2900, 2900, 1, 1.0, 1.0, 0, None, None, None) == -4  # 32-bit offsets / OOB sentinel
-    assert lib.deqsci_conv3x3_c64_split16(p16 + 4, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -3
-    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 0, 16, 16, 1, 1.0, 1.0, 0, None, None, None) == -2
-    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, 16, 16, 1, 1.0, 1.0, 0, None, p16, None) == -1       # one event only
-    assert lib.deqsci_f32_to_split16(None, q16, 1, 4, 4, 256.0, None) == -1 and lib.deqsci_f32_to_split16(p16, q16, 1, 0, 4, 256.0, None) == -2
-    assert lib.deqsci_ffdnet_tail_split16(None, p16, q16, 1, 4, 4, 1.0, None) == -1 and lib.deqsci_ffdnet_tail_split16(p16, p16, q16, 1, 4, -4, 1.0, None) == -2
-    assert lib.deqsci_conv3x3_c64_to_1_split16(p16 + 4, p16, q16, 1, 4, 4, 1.0, None) == -3
-    assert lib.deqsci_ffdnet_head_sp16(None, p16, p16, 0, q16, 1, 4, 4, None) == -1 and lib.deqsci_ffdnet_tail_sp16(None, p16, q16, 1, 4, 4, None) == -1
+    # the split-fp16 launcher's margin is the stricter one: an image between the two limits is routed to F(2x2,3x3), not to a launcher that refuses
+    assert _hip.S16_MAX_PIXELS * 256 + 4096 + 4096 + 16 <= 2 ** 31 < (_hip.S16_MAX_PIXELS + 1) * 256 + 4096 + 4096 + 16 and _hip.S16_MAX_PIXELS < _hip.W44_MAX_PIXELS
+    hh_h, hh_w = 511, 32 * 513                                                                      # 8388576 pixels (the advisor's example), 32-column aligned
+    assert _hip.S16_MAX_PIXELS < hh_h * hh_w <= _hip.W44_MAX_PIXELS
+    assert _hip.conv64_kernel_for(64, hh_h, hh_w, policy="fast") == "f22"
+    assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, hh_h, hh_w, 1, 0, None, 8, None, 8, None, 0, None, None, None) == -4
+
+
+def test_act_exp_mirror_matches_the_rule():
+    """_hip.act_exp is the host mirror of csrc/common.hpp: sp16_act_exp (the kernels derive it on the device): 2^e amax in [2^11, 2^12),
+    zero / subnormal / non-finite -> the default 8, clamped to +-64."""
+    import math
+    from deqsci_amd import _hip
+    for amax in (1.0, 0.999, 10.0, 15.99, 16.0, 255.9, 1e-6, 3.3e-11, 2047.0, 2048.0, 5e4, 1e30, 1e-30):
+        e = _hip.act_exp(amax)
+        if abs(e) < 64:
+            assert 2048 <= amax * 2.0 ** e < 4096, (amax, e)
+    assert _hip.act_exp(10.0) == 8 == _hip.SP16_DEFAULT_EXP                     # FFDNet's activations: the fixed scale of round 3
+    assert _hip.act_exp(0.0) == 8 and _hip.act_exp(float("inf")) == 8 and _hip.act_exp(float("nan")) == 8 and _hip.act_exp(1e-45) == 8
+    assert _hip.act_exp(1e30) == -64 and _hip.act_exp(1e-30) == 64
+    src = open(os.path.join(ROOT, "deqsci_amd", "csrc", "common.hpp")).read()
+    hdr = open(os.path.join(ROOT, "include", "deqsci_hip.h")).read()
+    assert "SP16_DEFAULT_EXP = 8, SP16_TARGET_EXP = 11, SP16_EXP_LIMIT = 64" in src
+    assert "#define DEQSCI_SP16_DEFAULT_EXP 8" in hdr and "#define DEQSCI_SP16_TARGET_EXP 11" in hdr
+    assert math.isclose(_hip.SP16_ACT_SCALE, 256.0)
 
 
 def test_shipped_library_reads_no_environment():
@@ -153,7 +160,7 @@ def test_split16_kernels_have_no_spills(tmp_path):
     moving the tile bookkeeping into the MFMA stream: 2-8 spilled registers, tile_done reloading in the middle of the last stage)."""
     report, text = _compile_with_resource_report("conv_s16.hip", tmp_path)
     kernels = re.findall(_RESOURCES % "(?:conv_s16_kernel|tail_s16_kernel|head_s16_kernel)", report, flags=re.S)
-    assert len(kernels) == 5, report[-2000:]                           # conv <0>, <1>; tail <4>, <1>; head
+    assert len(kernels) == 6, report[-2000:]                           # conv <0,0>, <1,0>, <0,1> (the measuring launch); tail <4>, <1>; head
     for name, vgprs, scratch, sspill, vspill in kernels:
         assert int(vgprs) <= 256 and (int(scratch), int(sspill), int(vspill)) == (0, 0, 0), (name, vgprs, scratch, sspill, vspill)
     assert text.count("v_mfma_f32_32x32x16_f16") > 800

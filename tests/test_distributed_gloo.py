@@ -137,6 +137,12 @@ def test_bench_launches_its_own_ranks():
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 6 and rec["steps"] == 2 and rec["data"] == "selftest"
     assert rec["scaling"] == "weak" and rec["config"]["batch_per_gpu"] == 3
     assert rec["allgather_ms_per_step"] > 0 and rec["allgather_bytes_per_step"] == 6 * 16 * 12 * 8 * 4
+    # the N > 1 line proves what the collective library saw: backend, world size as the process group reports it,
+    # one record per rank with its device, its own slice and its own time
+    d = rec["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert [r["measurements"] for r in d["ranks"]] == [[0, 3], [3, 6]] and all(r["ms_per_step"] > 0 for r in d["ranks"])
+    assert max(r["ms_per_step"] for r in d["ranks"]) <= rec["ms_per_step"] * 1.0001 and d["distinct_devices"] >= 1
 
 
 def test_bench_strong_scaling_mode_two_ranks():

@@ -361,6 +361,6 @@ def test_split16_weight_pack_layout():
         cout, cin = 32 * gq + m, 16 * c + 8 * kb + j
         want = float(ws[cout, cin, tap // 3, tap % 3])
         assert abs(float(rec[c, tap, gq, kb, m, j]) - want) <= 2.0 ** -21 * abs(want) + 1e-30
-    assert W.out_scale_sp16 == 2.0 ** -W.sw and W.out_scale_f32 == 2.0 ** -(W.sw + 8)
+    assert W.sw == _hip._weight_exp(w) and _hip._weight_exp(torch.zeros(2)) == 0
     rel = float(((rec.permute(2, 4, 0, 3, 5, 1).reshape(64, 64, 9) - ws.reshape(64, 64, 9)).norm()) / ws.norm())
     assert rel < 2e-7

@@ -16,9 +16,9 @@ hs = _hip.to_split16(h)
 hw, tw, tw16 = _hip.pack_head_weights(wh), _hip.pack_tail_weights(wt), _hip.TailSplit16Weights(wt)
 hw16 = _hip.HeadSplit16Weights(wh)
 oh = torch.empty_like(h); ohs = _hip.Sp16.empty(n, H, W, "cuda"); ot = torch.empty(n, 1, 2 * H, 2 * W, device="cuda")
-fns = {"head fp32 out": lambda: _hip.ffdnet_head(x, hw, sig, out=oh), "head sp16 out": lambda: _hip.ffdnet_head(x, hw, sig, out=ohs, sp16=True),
+fns = {"head fp32 out": lambda: _hip.ffdnet_head(x, hw, sig, out=oh),
        "head sp16 out (f16 MFMA)": lambda: _hip.ffdnet_head_split16(x, hw16, sig, out=ohs),
-       "tail fp32 in (VALU)": lambda: _hip.ffdnet_tail(h, tw, out=ot), "tail sp16 in (VALU)": lambda: _hip.ffdnet_tail(hs, tw, out=ot),
+       "tail fp32 in (VALU)": lambda: _hip.ffdnet_tail(h, tw, out=ot),
        "tail sp16 in (MFMA)": lambda: _hip.tail_split16(hs, tw16, out=ot)}
 res = {k: [] for k in fns}
 for rnd in range(7):
