@@ -24,8 +24,9 @@
 // B operand of v_mfma_f32_32x32x16_f16 (channels 16 c + 8 kb .. + 8), a staged tile row is 544 contiguous bytes per plane, and a
 // tap (dy, dx) is a constant offset into the staged plane: conflict-free ds_read_b128 for every tap, no per-tap address arithmetic.
 //
-// Block tile = 16 x 32 output pixels x 64 couts, one persistent 8-wave workgroup per CU (as csrc/winograd44.hip); wave w owns pixel
-// rows 2 w, 2 w + 1 (two N tiles of 32 pixels) x both cout groups of 32 (two M tiles): four accumulators of 16 registers.  Input
+// Block tile = 16 x 32 output pixels x 64 couts, one persistent 8-wave workgroup per CU (as csrc/winograd44.hip); wave w owns cout
+// group w & 1 (one M tile of 32) x pixel rows 4 (w >> 1) .. + 3 (four N tiles of 32 pixels): four accumulators of 16 registers, twice
+// (two accumulation chains).  Input
 // channels in chunks of 16 (= K of one MFMA): per chunk the 18 x 34 pixel halo tile (4 planes, 39 KB) and the chunk's weights
 // (9 taps x 2 pieces x 2 cout groups x 1 KB = 36 KB, host-packed in LDS order) are double-buffered and fetched by the LDS-DMA path
 // one stage ahead; out-of-image pixels are zeros the buffer hardware writes for out-of-range lanes.  One barrier per stage.
@@ -66,12 +67,20 @@
 #define S16_TAIL_XCD 1      // 0: the last layer's tiles dealt round-robin over the XCDs (A/B)
 #endif
 #ifndef S16_ROWS4
-#define S16_ROWS4 0   // wave geometry inside the 8-wave workgroup: 0 = two pixel rows x both cout groups (60 operand reads from LDS per stage and
-                      // wave: 36 weight + 24 activation fragments); 1 = FOUR pixel rows x ONE cout group (54: 18 + 36) - same accumulators, same MFMAs
+#define S16_ROWS4 1   // wave geometry inside the 8-wave workgroup: 1 (shipped since round 4) = FOUR pixel rows x ONE cout group per wave (54 operand
+                      // reads from LDS per stage and wave: 18 weight + 36 activation fragments; 242 registers); 0 = two pixel rows x both cout
+                      // groups (60: 36 + 24; 256 registers - the round-3 form, kept for the A/B: tools/s16_variants.sh "rows2:-DS16_ROWS4=0")
+#endif
+#ifndef S16_ZEROC
+#define S16_ZEROC S16_ROWS4   // 1: a tile's first MFMA into each accumulator takes the constant 0 as its C operand instead of 128 v_mov_b32 per tile and wave
+#endif
+#ifndef S16_TILE_VOFF
+#define S16_TILE_VOFF S16_ROWS4   // 1: the per-lane offsets of the halo-tile DMA are formed once per TILE (5 registers) instead of once per DMA instruction
 #endif
 #ifndef S16_ABL
 #define S16_ABL 0     // timing ablations only (results wrong; tools/s16_variants.sh): 1 = no DMA inside the stages, 2 = no wait + barrier at the end
-                      // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused)
+                      // of a stage, 4 = no epilogue, 8 = no LDS operand reads (registers reused), 16 = one EXTRA operand read per MFMA group
+                      // (S16_ROWS4: + 9 on 54 per stage; what a read costs with the MFMA operands unchanged)
 #endif
 
 namespace deqsci {
@@ -105,18 +114,27 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // TRACK = 1: the range MEASUREMENT - the same arithmetic, but instead of storing y the launch folds max |y| (true units, pixels of the
 // image only) into *track with one atomic per workgroup
 // The ranges (common.hpp): the input holds 2^e_in x, e_in from *in_amax (or in_exp); the sp16 output 2^e_out y, e_out from *out_amax (or out_exp)
-template <int OUT_F32, int TRACK>
+// STACK = 1: a RUN of n_layers 64->64 layers in ONE launch (the denoisers' 13 / 2 middle layers): the persistent workgroups walk the
+// same tiles layer after layer with a grid-wide barrier in between (release: L2 write-back, one atomic per workgroup, acquire: cache
+// invalidate - what the end of a kernel and the start of the next do, without the dispatch in between).  Layer l reads x (l = 0) or the
+// ping-pong buffer it wrote last, writes y (l even) / y2 (l odd); its parameters come from `layers`, its ranges from in_amax[l], in_amax[l + 1]
+// (in_amax = the slot of the run's input; NULL: in_exp / out_exp throughout).  gbar: two zeroed words (arrival counter, time-out flag).
+struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
+constexpr unsigned STACK_SPIN_LIMIT = 1u << 22;              // (~ seconds) a barrier that never completes sets gbar[1] instead of hanging the GPU
+template <int OUT_F32, int TRACK, int STACK>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
                                                           char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
                                                           const float* __restrict__ out_amax, int out_exp, float* __restrict__ track, int tiles_x, int tiles_y,
-                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx,
+                                                          char* __restrict__ y2, const StackLayer* __restrict__ layers, int n_layers, unsigned* __restrict__ gbar) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     __shared__ uint32_t trk_s[WAVES];
     // acc = 2^(e_in + w_exp) sum w x  ->  2^e_out y; the bias likewise
-    const int e_out = OUT_F32 ? 0 : sp16_resolve_exp(out_amax, out_exp);
-    const float oscale = sp16_pow2(e_out - sp16_resolve_exp(in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
+    int e_out = OUT_F32 ? 0 : sp16_resolve_exp(STACK ? nullptr : out_amax, out_exp);
+    float oscale = sp16_pow2(e_out - sp16_resolve_exp(STACK ? nullptr : in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
+    char* const y_even = y;
     uint32_t trk_max = 0;                                      // (TRACK) the wave's running max |stored output| as float bits, wave-uniform
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
@@ -130,7 +148,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
         } else { t_first = b; t_step = nb; t_end = n_tiles; }
     }
-    if (t_first >= t_end) return;
+    if (!STACK && t_first >= t_end) return;                     // (a workgroup of a STACK launch without tiles still keeps the barriers)
     const int64_t HW = (int64_t)H * W;
 
     // ---- halo tile by LDS-DMA: slot s = 64 (5 wave + j) + lane of the chunk tile is plane p = s / 612 (p = 2 hl + kb), pixel
@@ -170,13 +188,18 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         asm volatile("" : "+v"(off));                          // (a select, not a branch around the arithmetic)
         return ok ? off : RAW_OOB;
     };
+    uint32_t voff[RAW_INSTR];                                  // (S16_TILE_VOFF) the lane offsets of the tile whose chunks are being fetched
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
     auto raw_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
         int w_ = wave;
         asm volatile("" : "+s"(w_));                           // (recomputed at every use: hoisted out of the tile loop, these scalars fill the SGPR file)
         const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + RAW_INSTR * w_ * 1024 + (j == 4 ? 4096 : 0)));
+#if S16_TILE_VOFF
+        const uint32_t voj = voff[j];
+#else
         const uint32_t voj = fetch_lane_offset(j);             // (a dozen vector instructions, in the shadow of the group's MFMAs)
+#endif
         if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
         else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
         else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
@@ -356,14 +379,21 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         S16_MARK(4);
         loads(0);
         __builtin_amdgcn_sched_barrier(0);
+        const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        h8 extra[2];                                           // (S16_ABL & 16)
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
             const int dx = i / 3, dy = i % 3;
+            const bool z1st = S16_ZEROC && c == 0 && i == 0;   // a tile's first MFMA into an accumulator: C = 0 (an inline constant)
 #define S16_SLOT(r) ((6 * dx + dy + (r)) & 7)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[CH1][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i & 1], Bh[S16_SLOT(r)], acc[CH1][r >> 1][r & 1], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) acc[CH1][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i & 1], Bh[S16_SLOT(r)], z1st ? zero16 : acc[CH1][r >> 1][r & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             loads(i + 1);
+            if (S16_ABL & 16) {
+                extra[i & 1] = *reinterpret_cast<const lds_h8*>(bb + PLANE_B + i * 16);
+                if (i > 0) asm volatile("" ::"v"(extra[(i - 1) & 1]));
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[CH1][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bl[S16_SLOT(r)], acc[CH1][r >> 1][r & 1], 0, 0, 0);
@@ -372,16 +402,17 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             shadow(2 * i);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], acc[0][r >> 1][r & 1], 0, 0, 0);
+            for (int r = 0; r < 2; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], (z1st && CH1) ? zero16 : acc[0][r >> 1][r & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             dma(2 * i + 1);
             shadow(2 * i + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 2; r < 4; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], acc[0][r >> 1][r & 1], 0, 0, 0);
+            for (int r = 2; r < 4; ++r) acc[0][r >> 1][r & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i & 1], Bh[S16_SLOT(r)], (z1st && CH1) ? zero16 : acc[0][r >> 1][r & 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #undef S16_SLOT
         }
+        if (S16_ABL & 16) asm volatile("" ::"v"(extra[0]));
 #else
         // 18 groups (dx, dy, g) of 6 MFMAs: the two pixel rows x three products of one tap and cout group.  Operands are read from LDS
         // TWO groups ahead (software pipeline pinned by sched_barriers: left to itself hipcc reads each fragment one MFMA before its use
@@ -452,6 +483,20 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #ifdef S16_PRIO
     if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
 #endif
+    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0};
+#pragma unroll 1
+    for (int L = 0; L < (STACK ? n_layers : 1); ++L) {
+    if (STACK) {
+        const StackLayer ly = layers[L];                       // (wave-uniform: scalar loads)
+        Wp = ly.w; bias = ly.bias; w_exp = ly.w_exp; relu = ly.relu;
+        if (L > 0) x = y;                                      // what the layer before wrote
+        y = (L & 1) ? y2 : y_even;
+        const int e_in = in_amax ? sp16_act_exp(in_amax[L]) : in_exp;
+        e_out = in_amax ? sp16_act_exp(in_amax[L + 1]) : out_exp;
+        oscale = sp16_pow2(e_out - e_in - w_exp);
+        bscale = sp16_pow2(e_out);
+    }
+    if (!STACK || t_first < t_end) {
     // ---- prologue: bias, chunk 0 of the first tile
 #ifdef S16_STAMP
     if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
@@ -459,6 +504,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
 #endif
     fetch_tile_uniform(t_first);
+#if S16_TILE_VOFF
+#pragma unroll
+    for (int j = 0; j < RAW_INSTR; ++j) voff[j] = fetch_lane_offset(j);
+#endif
 #pragma unroll
     for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -472,16 +521,17 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // (all-zero operands: 142 us), where time follows the energy of the launch, not its idle cycles: the out-of-step epilogue, the
     // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
     // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
-    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0};
     S16_MARK(4);
 #pragma unroll 1
     for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+#if !(S16_ZEROC && S16_ROWS4)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[CH1][g][r][i] = 0.0f;
+#endif
         stage(0, true, nothing, no_shadow);
         stage(1, true, nothing, no_shadow);
         const bool next = t_cur + t_step < t_end;
@@ -490,6 +540,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         // tiles this arithmetic cost every wave 1.5 us with the matrix pipe idle
         stage(2, true, nothing, [&](int i) __attribute__((always_inline)) {
             if (i == 10) fetch_tile_uniform(t_cur + t_step);
+#if S16_TILE_VOFF
+            if (i >= 11 && i < 11 + RAW_INSTR) voff[i - 11] = fetch_lane_offset(i - 11);     // (this tile's last raw pieces went out in groups 0..4)
+#endif
         });
         // The epilogue, out of step between the two waves of a SIMD.  Waves 0-3 (one per SIMD, dispatched first: the issue arbiter favours
         // them, they finish a stage's MFMAs in 55 % of its time and idle at the barrier) run their epilogue BEFORE the last stage's barrier,
@@ -531,6 +584,25 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         S16_MARK(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }                                                          // (has tiles)
+    if (STACK && L + 1 < n_layers) {
+        // ---- grid-wide barrier between two layers.  Every wave has waited for its stores (vmcnt(0) above); one lane writes the L2 back
+        // (release at agent scope), arrives, and waits for all workgroups of the launch; then every wave drops its caches (acquire).
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = gridDim.x * (unsigned)(L + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > STACK_SPIN_LIMIT) { __hip_atomic_fetch_or(gbar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    }                                                          // (layers)
     if (TRACK) {
         if (lane == 0) trk_s[wave] = trk_max;
         __syncthreads();
@@ -871,11 +943,43 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
 #define S16_LAUNCH(KERNEL)                                                                                                                  \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
                           bias, static_cast<char*>(y), (int)H, (int)W, relu, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, (int)tiles_x,       \
-                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx)
-    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0>));
-    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1>));
-    else S16_LAUNCH((s16::conv_s16_kernel<0, 0>));
+                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(nullptr),                                        \
+                          static_cast<const s16::StackLayer*>(nullptr), 1, static_cast<unsigned*>(nullptr))
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0, 0>));
+    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1, 0>));
+    else S16_LAUNCH((s16::conv_s16_kernel<0, 0, 0>));
 #undef S16_LAUNCH
+    return launch_status();
+}
+
+static_assert(sizeof(s16::StackLayer) == 24, "the layer table of deqsci_conv3x3_c64_split16_stack is three 8-byte words per layer");
+
+extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
+                                                int64_t n, int64_t H, int64_t W, const float* ranges, int in_exp, int out_exp, void* sync2,
+                                                deqsci_stream_t stream, void* start_event, void* stop_event) {
+    if (!x_sp16 || !y_even || !layers || !sync2 || (n_layers > 1 && !y_odd)) return DEQSCI_ERR_NULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || n_layers <= 0) return DEQSCI_ERR_SHAPE;
+    if (x_sp16 == y_even || x_sp16 == y_odd || y_even == y_odd || n_layers > 64 || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(y_even) || !aligned16(y_odd) || (reinterpret_cast<uintptr_t>(layers) & 7u) || (reinterpret_cast<uintptr_t>(sync2) & 3u))
+        return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // every workgroup of the launch has to be RESIDENT (they wait for one another between the layers): one per CU - the kernel's 152 KB of
+    // LDS admit no second one - and never more workgroups than CUs
+    const int64_t resident = (int64_t)num_cus();
+    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
+    hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
+    hipExtLaunchKernelGGL((s16::conv_s16_kernel<0, 0, 1>), grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16),
+                          static_cast<const char*>(nullptr), static_cast<const float*>(nullptr), static_cast<char*>(y_even), (int)H, (int)W, 0, 0, ranges,
+                          in_exp, static_cast<const float*>(nullptr), out_exp, static_cast<float*>(nullptr), (int)tiles_x, (int)tiles_y, (int)n_tiles,
+                          mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(y_odd), static_cast<const s16::StackLayer*>(layers), n_layers,
+                          static_cast<unsigned*>(sync2));
     return launch_status();
 }
 

@@ -64,7 +64,7 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True):
+                 act_range="data", blk32=True, stack=True):
         from .networks import FFDNet
         self.net = net
         self.fused_edges = fused_edges
@@ -80,8 +80,14 @@ class _Denoiser:
         if act_range not in ("data", "fixed"):
             raise ValueError(f"act_range={act_range!r}: expected 'data' or 'fixed'")
         self.act_range = act_range
+        # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch with grid-wide barriers between the layers
+        # (_hip.conv3x3_c64_split16_stack) instead of one launch per layer; the measuring f-call keeps the per-layer launches
+        self.stack = bool(stack)
+        self._stacks = {}                                           # first layer index of a run -> _hip.Split16Stack
         self.ranges = None                                          # (len(layers) + 1,) fp32 on the device: slot i = max |input of layer i|
         self._calibrating = False
+        self._stale = True                                          # the ranges have not been measured on the current input yet
+        self._stack_used = None                                     # the Split16Stack launched last (its time-out flag is read after the run)
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
         # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
         # 128x128x64 layers, 11 % slower for SimpleCNN's 256x256x64 ones.
@@ -147,6 +153,7 @@ class _Denoiser:
                                                                       and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
             self.ranges = None
+            self._stacks = {}
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
@@ -188,7 +195,21 @@ class _Denoiser:
             return F.conv2d(self._run_layers(h, idx[:-1], fused), w, None, padding=1), b
         return self._run_layers(h, idx, fused)
 
+    def _stack_for(self, idx, device):
+        """The Split16Stack of the run of layers idx (built outside any hipGraph capture: prepare() does it for the shipped denoisers)."""
+        st = self._stacks.get(idx[0])
+        if st is None or st.n_layers != len(idx) or st.table.device != torch.device(device):
+            st = self._stacks[idx[0]] = _hip.Split16Stack([(self.wino[i].s16, self.fast[i][1], self.fast[i][2]) for i in idx], device)
+        return st
+
     def _run_layers(self, h, idx, fused):
+        if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= 2 and self._native_out and not self._calibrating
+                and all(self.wino[i] is not None for i in idx) and (h.rng is None) == (self.ranges is None)):
+            # the whole run in one launch: sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
+            st = self._stack_for(idx, h.t.device)
+            bufs = (_hip.Sp16.empty(h.n, h.H, h.W, h.t.device), _hip.Sp16.empty(h.n, h.H, h.W, h.t.device))
+            self._stack_used = st
+            return _hip.conv3x3_c64_split16_stack(h, st, bufs, None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2])
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
             nxt = idx[pos + 1] if pos + 1 < len(idx) else None
@@ -203,10 +224,12 @@ class _Denoiser:
                     if not isinstance(h, _hip.Sp16):
                         if self._calibrating:
                             _hip.absmax(h, self._slot(i))
+                            self._measured = True
                         h = _hip.to_split16(h, rng=self._slot(i))
                     sp_out = chain or (nxt is None and self._native_out)
                     if sp_out and self._calibrating:               # measure max |output| of this layer, then write it with that range
                         _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, track=self._slot(i + 1))
+                        self._measured = True
                     h = _hip.conv3x3_c64_split16(h, self.wino[i].s16, b, relu, out_f32=not sp_out, out_rng=self._slot(i + 1) if sp_out else None)
                 elif kind == "f44":
                     h = _hip.conv3x3_c64_winograd44(h, self.wino[i].f44, b, relu, out_blk=bool(self.blk32 and chain))
@@ -230,6 +253,9 @@ class _Denoiser:
         if self.fast is not None and self.act_range == "data" and (self.ranges is None or self.ranges.device != torch.device(device)):
             # kept across calls: a captured hipGraph carries this tensor's address in its conv nodes
             self.ranges = torch.zeros(len(self.fast) + 1, dtype=torch.float32, device=device)
+        if (self.fast is not None and self.stack and self.conv64 in ("fast", "s16") and len(self.fast) >= 4
+                and all(u is not None for u in self.wino[1:-1]) and self.wino[1] is not None and self.wino[1].s16.packed.is_cuda):
+            self._stack_for(list(range(1, len(self.fast) - 1)), device)      # (an H2D copy: here, never inside a capture)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
@@ -237,14 +263,27 @@ class _Denoiser:
                 self.sigma_table = torch.from_numpy(sigma_schedule(n_calls)).to(device)
 
     def run(self, z1, call, calibrate=False):
-        """calibrate: measure the ranges of the split-fp16 activations on this input (the engine: at the first f-call of a reconstruction)
-        instead of using the ones measured last."""
+        """calibrate: a new input (the engine: the first f-call of a reconstruction) - the ranges of the split-fp16 activations measured
+        last are stale.  They are measured by the next call that takes the split-fp16 path (this one, unless the policy runs its first
+        f-calls on another kernel) and kept from then on."""
         bsz, B, H, W = z1.shape
         x = z1.view(bsz * B, 1, H, W)
         self._policy = "f22" if (self.f22_calls is not None and call < self.f22_calls) else self.conv64
-        self._calibrating = cal = bool(calibrate) and self.ranges is not None and x.is_cuda
+        if calibrate:
+            self._stale = True
+        self._calibrating = cal = self._stale and self.ranges is not None and x.is_cuda
+        self._measured = False                                      # set by the first measuring launch of this call
         if cal:
             self.ranges.zero_()
+        try:
+            return self._run(z1, x, call, cal)
+        finally:
+            if self._measured:
+                self._stale = False
+            self._calibrating = False
+
+    def _run(self, z1, x, call, cal):
+        bsz, B, H, W = z1.shape
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
             if self.fast is not None:
@@ -255,6 +294,7 @@ class _Denoiser:
                     sg = self.sigma_table[call:call + 1]
                     if sp:
                         if cal:                                # max |image| (the head adds sigma itself), then max |its own output|
+                            self._measured = True
                             _hip.absmax(x, self._slot(0))
                             _hip.ffdnet_head_split16(x, self.head_w16, sg, in_rng=self._slot(0), out_exp=0, track=self._slot(1))
                         h = _hip.ffdnet_head_split16(x, self.head_w16, sg, in_rng=self._slot(0), out_rng=self._slot(1))
@@ -283,6 +323,7 @@ class _Denoiser:
                     sp = (first and self.plain_tail_w is not None and all(u is not None for u in self.wino[1:-1])
                           and _hip.conv64_kernel_for(bsz * B, H, W, x.device, self._policy) == "s16")
                     if first and sp and cal:
+                        self._measured = True
                         _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=True, out_exp=0, track=self._slot(1))
                     h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp, out_rng=self._slot(1) if sp else None) if first else x
                     if self.plain_tail_w is not None:
@@ -305,7 +346,7 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, stack=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
@@ -328,7 +369,7 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
@@ -381,7 +422,7 @@ class DEQSCIEngine:
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
         with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
             rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
-            self.last_info["conv64_fallback"] = None
+            fallback = None
             if self.conv64 == "auto" and not math.isfinite(self.last_info["res"]) and bool(torch.isfinite(y).all()):
                 # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
                 # about) is redone on the fp32 MFMA kernels - THIS call only (eagerly; a captured hipGraph and the policy of later,
@@ -395,7 +436,14 @@ class DEQSCIEngine:
                 finally:
                     self.conv64_policy, self.den.conv64, self.use_graph = saved
                     self.den._policy = saved[1]
-                self.last_info["conv64_fallback"] = "fast32"
+                fallback = "fast32"
+            if self.den._stack_used is not None:               # a grid barrier of a stack launch that timed out invalidates the run: loud
+                st, self.den._stack_used = self.den._stack_used, None
+                _hip.check_stack_sync(st)
+            self.last_info["conv64_fallback"] = fallback
+            # what the first f-call measured: max |activation| in front of every layer of the denoiser's stack (0 where no split-fp16
+            # layer ran); the exponents the kernels derived from them are _hip.act_exp of these
+            self.last_info["act_ranges"] = None if (self.den.ranges is None or fallback) else self.den.ranges.tolist()
             return rec
 
     def _reconstruct(self, y, Phi, Phi_sum, initial_point):

@@ -37,7 +37,7 @@ def test_scratch_size_queries_and_error_strings():
     # argument validation happens before any launch, so it is testable without a GPU
     assert lib.deqsci_sci_forward_f32(None, None, None, 1, 4, 4, 8, 0, 0, None) == -1
     assert lib.deqsci_residual_store_f32(None, None, None, None, None, None, None, 1, 64, 5, 0, 1, None) == -1
-    buf = (ctypes.c_float * 64)()
+    buf = (ctypes.c_float * 96)()
     p = ctypes.addressof(buf)
     p16 = (p + 15) // 16 * 16
     assert lib.deqsci_sci_forward_f32(p16, p16, p16, 1, 2, 2, -8, 0, 0, None) == -2
@@ -64,6 +64,42 @@ def test_scratch_size_queries_and_error_strings():
     assert _hip.S16_MAX_PIXELS < hh_h * hh_w <= _hip.W44_MAX_PIXELS
     assert _hip.conv64_kernel_for(64, hh_h, hh_w, policy="fast") == "f22"
     assert lib.deqsci_conv3x3_c64_split16(p16, p16, None, q16, 1, hh_h, hh_w, 1, 0, None, 8, None, 8, None, 0, None, None, None) == -4
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, p16, 1, 16, 16, 1, None) == -4    # in place
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, None, None, q16, 1, 16, 16, 1, None) == -1
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16 + 4, p16, None, q16, 1, 16, 16, 1, None) == -3
+    assert lib.deqsci_conv3x3_c64_winograd44_f32(p16, p16, None, q16, 0, 16, 16, 1, None) == -2
+    assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 2, 0, None, None, None) == -4   # unknown layout
+    assert lib.deqsci_conv3x3_c64_winograd44_layout_f32(p16, p16, None, q16, 1, 16, 16, 1, 1, 1, None, p16, None) == -1   # one event only
+    # the split-fp16 convolution and its edge layers: the same contract
+
+    def s16(x, w, y, n=1, H=16, W=16, w_exp=0, in_exp=8, out_exp=8, track=None, out_f32=0, ev0=None, ev1=None):
+        return lib.deqsci_conv3x3_c64_split16(x, w, None, y, n, H, W, 1, w_exp, None, in_exp, None, out_exp, track, out_f32, None, ev0, ev1)
+    assert s16(None, p16, q16) == -1
+    assert s16(p16, p16, None) == -1 and s16(p16, p16, None, out_f32=1, track=p16) == -4      # y may be NULL only in a measuring launch, which has no fp32 form
+    assert s16(p16, p16, p16) == -4                                                            # in place
+    assert s16(p16, p16, q16, out_f32=2) == -4                                                 # unknown output form
+    assert s16(p16, p16, q16, H=2900, W=2900) == -4                                            # 32-bit offsets / OOB sentinel
+    assert s16(p16, p16, q16, in_exp=65) == -4 and s16(p16, p16, q16, out_exp=-65) == -4 and s16(p16, p16, q16, w_exp=100) == -4   # exponents beyond +-64
+    assert s16(p16 + 4, p16, q16) == -3
+    assert s16(p16, p16, q16, n=0) == -2
+    assert s16(p16, p16, q16, ev1=p16) == -1                                                   # one event only
+    # the run of layers in one launch: the same contract, plus its own arguments
+    r16 = q16 + 64
+
+    def stk(x, ya, yb, tab, nl=3, n=1, H=16, W=16, sync=q16, in_exp=8, ev0=None, ev1=None):
+        return lib.deqsci_conv3x3_c64_split16_stack(x, ya, yb, tab, nl, n, H, W, None, in_exp, 8, sync, None, ev0, ev1)
+    assert stk(None, q16, r16, p16) == -1 and stk(p16, q16, None, p16) == -1 and stk(p16, q16, r16, p16, sync=None) == -1
+    assert stk(p16, p16, r16, p16) == -4 and stk(p16, q16, q16, p16) == -4 and stk(p16, q16, r16, p16, nl=65) == -4
+    assert stk(p16, q16, r16, p16, nl=0) == -2 and stk(p16, q16, r16, p16, in_exp=65) == -4 and stk(p16, q16, r16, p16 + 4) == -3
+    assert stk(p16, q16, r16, p16, H=2900, W=2900) == -4 and stk(p16, q16, r16, p16, ev0=p16) == -1
+    assert lib.deqsci_f32_to_split16(None, q16, 1, 4, 4, None, 8, None) == -1 and lib.deqsci_f32_to_split16(p16, q16, 1, 0, 4, None, 8, None) == -2
+    assert lib.deqsci_f32_to_split16(p16, q16, 1, 4, 4, None, 99, None) == -4
+    assert lib.deqsci_absmax_f32(None, 4, p16, None) == -1 and lib.deqsci_absmax_f32(p16, 0, p16, None) == -2 and lib.deqsci_absmax_f32(p16 + 4, 4, p16, None) == -3
+    assert lib.deqsci_ffdnet_tail_split16(None, p16, q16, 1, 4, 4, 0, None, 8, None) == -1 and lib.deqsci_ffdnet_tail_split16(p16, p16, q16, 1, 4, -4, 0, None, 8, None) == -2
+    assert lib.deqsci_conv3x3_c64_to_1_split16(p16 + 4, p16, q16, 1, 4, 4, 0, None, 8, None) == -3
+    assert lib.deqsci_ffdnet_head_split16(None, p16, p16, 0, q16, 1, 4, 4, 0, None, 8, None, 8, None, None) == -1
+    assert lib.deqsci_ffdnet_head_split16(p16, p16, p16, 0, q16, 1, 4, 4, 0, None, 8, None, 70, None, None) == -4
+    assert lib.deqsci_conv3x3_c1_to_64_sp16(None, p16, q16, 1, 4, 4, 1, None, 8, None, None) == -1
 
 
 def test_act_exp_mirror_matches_the_rule():
@@ -160,7 +196,7 @@ def test_split16_kernels_have_no_spills(tmp_path):
     moving the tile bookkeeping into the MFMA stream: 2-8 spilled registers, tile_done reloading in the middle of the last stage)."""
     report, text = _compile_with_resource_report("conv_s16.hip", tmp_path)
     kernels = re.findall(_RESOURCES % "(?:conv_s16_kernel|tail_s16_kernel|head_s16_kernel)", report, flags=re.S)
-    assert len(kernels) == 6, report[-2000:]                           # conv <0,0>, <1,0>, <0,1> (the measuring launch); tail <4>, <1>; head
+    assert len(kernels) == 7, report[-2000:]                           # conv <0,0,0>, <1,0,0>, <0,1,0> (the measuring launch), <0,0,1> (the stack); tail <4>, <1>; head
     for name, vgprs, scratch, sspill, vspill in kernels:
         assert int(vgprs) <= 256 and (int(scratch), int(sspill), int(vspill)) == (0, 0, 0), (name, vgprs, scratch, sspill, vspill)
     assert text.count("v_mfma_f32_32x32x16_f16") > 800

@@ -123,6 +123,9 @@ def main():
             eng = DEQSCIEngine(net, **kw)
         elif v == "fixed":                                     # the round-3 arithmetic: activation scales pinned at 2^8
             eng = DEQSCIEngine(net, act_range="fixed", **kw)
+        elif "+" in v:                                         # "fast+3": the first 3 f-calls on F(2x2,3x3), then the policy - a family of
+            pol, k = v.split("+")                              # equivalent arithmetics (the scatter of the pooled mean between implementations)
+            eng = DEQSCIEngine(net, conv64=pol, conv64_f22_calls=int(k), **kw)
         else:
             eng = DEQSCIEngine(net, conv64=v, **kw)            # fast32 / f22 / f44 / s16
         runs[v] = ensemble(eng, n_seeds, v)
@@ -144,11 +147,17 @@ def main():
                 d = summary[v]["pooled_mean_psnr"] - summary[u]["pooled_mean_psnr"]
                 se = float(np.hypot(summary[v]["se"], summary[u]["se"]))
                 diffs[f"{v} - {u}"] = {"dB": round(d, 4), "se_of_difference": round(se, 4), "in_se": round(d / se, 2)}
-    print("SUMMARY", json.dumps({k: (v["pooled_mean_psnr"], v["se"]) for k, v in summary.items()}))
+    fam = [summary[v]["pooled_mean_psnr"] for v in runs if "+" in v]
+    if len(fam) >= 3:                                          # the between-implementation scatter of the pooled statistic, measured
+        summary["family of equivalent arithmetics (policy+K)"] = {"members": len(fam), "mean_of_pooled_means": round(float(np.mean(fam)), 4),
+                                                                    "sd_of_pooled_means": round(float(np.std(fam, ddof=1)), 4),
+                                                                    "min": round(min(fam), 4), "max": round(max(fam), 4)}
+        print("FAMILY", json.dumps(summary["family of equivalent arithmetics (policy+K)"]))
+    print("SUMMARY", json.dumps({k: (v["pooled_mean_psnr"], v["se"]) for k, v in summary.items() if "pooled_mean_psnr" in v}))
     print("DIFFS", json.dumps(diffs))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump({"what": __doc__.split("\n\n")[0], "seeds": n_seeds, "summary": summary, "differences": diffs, "runs": runs},
-              open(os.path.join(ROOT, "gpurun_out", "config2_fp64_denoiser.json"), "w"), indent=1)
+              open(os.path.join(ROOT, "gpurun_out", args.get("out", "config2_fp64_denoiser.json")), "w"), indent=1)
 
 
 if __name__ == "__main__":

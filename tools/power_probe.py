@@ -65,15 +65,16 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(5)
     w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
     b = torch.randn(64, device="cuda", generator=g)
-    x = torch.randn(64, 64, 128, 128, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+    NI = int(os.environ.get("PROBE_IMAGES", "64"))             # 64 = the bench shape (16 block tiles per CU); 8 = one measurement per call (ONE tile per CU)
+    x = torch.randn(NI, 64, 128, 128, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
     if zero:
         x.zero_(); w.zero_()
     kind = os.environ.get("PROBE_KERNEL", "s16")               # s16 | f44 (Winograd F(4x4,3x3), blk32 -> blk32) | f22 (Winograd F(2x2,3x3))
     if kind == "s16":
-        xs = _hip.to_split16(x); out = _hip.Sp16.empty(64, 128, 128, "cuda"); Wsp = _hip.Split16Weights(w)
+        xs = _hip.to_split16(x); out = _hip.Sp16.empty(NI, 128, 128, "cuda"); Wsp = _hip.Split16Weights(w)
         launch = lambda: _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=out)  # noqa: E731
     elif kind == "f44":
-        xb = _hip.Blk32.from_nchw(x); ob = _hip.Blk32.empty(64, 128, 128, "cuda"); U = _hip.pack_winograd44_weights(w)
+        xb = _hip.Blk32.from_nchw(x); ob = _hip.Blk32.empty(NI, 128, 128, "cuda"); U = _hip.pack_winograd44_weights(w)
         launch = lambda: _hip.conv3x3_c64_winograd44(xb, U, b, True, out=ob, out_blk=True)  # noqa: E731
     else:
         o2 = torch.empty_like(x); U2 = _hip.pack_winograd_weights(w)
@@ -85,7 +86,7 @@ def main():
     idle = {k: int(open(f).read().strip()) for k, f in files.items() if k != "power1_cap"} if files else {}
     s = Sampler({k: f for k, f in files.items() if k != "power1_cap"})
     s.start()
-    n = 12000 if kind == "s16" else 8000
+    n = (12000 if kind == "s16" else 8000) * max(1, 64 // NI) // (1 if NI == 64 else 2)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
@@ -95,7 +96,7 @@ def main():
     s.stop = True
     us = e0.elapsed_time(e1) / n * 1e3
     rows = s.rows[len(s.rows) // 4:]                     # steady part
-    res = {"kernel": kind, "lib": os.environ.get("DEQSCI_HIP_LIB", "product"), "zero_operands": zero, "launch_us": round(us, 1), "samples": len(rows), "idle": idle, "pci": pci}
+    res = {"kernel": kind, "images": NI, "lib": os.environ.get("DEQSCI_HIP_LIB", "product"), "zero_operands": zero, "launch_us": round(us, 1), "samples": len(rows), "idle": idle, "pci": pci}
     for k in ("power1_average", "power1_input", "freq1_input"):
         v = [r[k] for r in rows if k in r]
         if v:
