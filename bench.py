@@ -201,7 +201,6 @@ def parse_args(argv=None):
     ap.add_argument("--no-fused-edges", action="store_true")
     ap.add_argument("--no-winograd", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer instead of one per run of layers (A/B)")
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -226,8 +225,6 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
     kw = {}
     if args.no_graph:
         kw["use_graph"] = False
-    if args.no_stack:
-        kw["stack"] = False
     if args.act_range != "data":
         kw["act_range"] = args.act_range
     return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
@@ -278,7 +275,7 @@ def run_rank(args):
             step()
     timing = not (selftest or args.no_kernel_timing or graph_mode) and rank == 0
     timer = None
-    conv_timers, conv_shape, conv_launches, conv_layers = {}, {}, {"f22": 0, "f44": 0, "s16": 0}, {}
+    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0}
     if timing:
         timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
         conv_timers = {k: _hip.KernelTimer(capacity=400) for k in conv_launches}   # a sample of launches of each kernel is enough
@@ -291,12 +288,11 @@ def run_rank(args):
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
 
-        def conv_hook(kind, n, H, W, layers=1):                # _hip.CONV64_EVENT_HOOK: a (start, stop) event pair per 64->64 launch
-            if not timing_on[0]:                               # (layers > 1: ONE launch that runs a whole run of layers - the split-fp16 stack)
+        def conv_hook(kind, n, H, W):                          # _hip.CONV64_EVENT_HOOK: a (start, stop) event pair per 64->64 launch
+            if not timing_on[0]:
                 return None
             conv_launches[kind] += 1
             conv_shape[kind] = [n, H, W]
-            conv_layers[kind] = max(conv_layers.get(kind, 1), layers)
             return conv_timers[kind].pair()
         _hip.CONV64_EVENT_HOOK = conv_hook
 
@@ -408,8 +404,7 @@ def run_rank(args):
             if not cms:
                 continue
             nimg, ch, cw = conv_shape[kind]
-            lpl = conv_layers.get(kind, 1)                        # layers per launch (the split-fp16 stack: FFDNet's 13 in one launch)
-            direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg * lpl
+            direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
             mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS), "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
             cavg = 1e-3 * sum(cms) / len(cms)
             share = cavg * conv_launches[kind] / elapsed
@@ -421,7 +416,7 @@ def run_rank(args):
                     with open(wfile) as fh:
                         rec = json.load(fh)
                     if rec.get("shape") == [nimg, 64, ch, cw]:
-                        wtraffic = rec["hbm_bytes_per_launch"] * lpl       # (the PMC passes count one layer)
+                        wtraffic = rec["hbm_bytes_per_launch"]
             kname = {"s16": "deqsci::s16::conv_s16_kernel (conv3x3 64->64 + bias + ReLU, direct convolution on the f16 matrix cores: fp32 operands as hi + lo "
                             "fp16 pairs, three MFMAs per product, fp32 accumulation)",
                      "f44": "deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
@@ -433,8 +428,7 @@ def run_rank(args):
                            # algorithmic = the direct-convolution flops of the layer, SURVEY 8(d) / section 6 (`frac_useful`)
                            "executed_mfma_flops_per_launch": direct * mult, "algorithmic_flops_per_launch": direct,
                            "achieved_useful": direct / cavg / 1e12, "frac_useful": direct / cavg / 1e12 / peak,
-                           "avg_launch_us": 1e6 * cavg, "layers_per_launch": lpl, "avg_layer_us": 1e6 * cavg / lpl, "launches_timed": len(cms),
-                           "launches_per_step": conv_launches[kind] // max(args.steps, 1),
+                           "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "launches_per_step": conv_launches[kind] // max(args.steps, 1),
                            "share_of_step_time": round(share, 3),
                            "note": {"s16": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; on random operands the kernel runs against the chip's power limit "
                                            "(1.9-2.0 GHz, not 2.4): see DESIGN.md section 6",

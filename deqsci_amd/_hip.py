@@ -46,7 +46,6 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -453,17 +452,10 @@ ACT_NHWC, ACT_BLK32 = 0, 1
 CONV64_EVENT_HOOK = None
 
 
-def _hook_events(kind, n, H, W, events, layers=1):
-    """layers > 1: one launch that runs `layers` 64->64 layers (the split-fp16 stack); the hook is told through its `layers` keyword
-    when it accepts one."""
+def _hook_events(kind, n, H, W, events):
     if events is not None:
         return events
     if CONV64_EVENT_HOOK is not None:
-        if layers > 1:
-            try:
-                return CONV64_EVENT_HOOK(kind, n, H, W, layers=layers)
-            except TypeError:
-                pass
         return CONV64_EVENT_HOOK(kind, n, H, W)
     return None
 
@@ -759,62 +751,6 @@ def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=Fals
                                                  weights.sw, _rng(x.rng), x.exp, _rng(out_rng), int(out_exp), None, 1 if out_f32 else 0,
                                                  _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
     return o
-
-
-class Split16Stack:
-    """A RUN of 64->64 layers for deqsci_conv3x3_c64_split16_stack: the device table of (weights, bias, w_exp, relu) per layer - three
-    8-byte words each - plus the tensors it points to (kept alive here) and the two synchronisation words of the launch."""
-    __slots__ = ("table", "n_layers", "keep", "sync")
-
-    def __init__(self, layers, device):
-        """layers: [(Split16Weights, bias tensor or None, relu), ...]"""
-        rows, keep = [], []
-        for w16, bias, relu in layers:
-            if not isinstance(w16, Split16Weights):
-                raise DeqsciHipError("Split16Stack: every layer needs Split16Weights")
-            wp = w16.packed if w16.packed.device == torch.device(device) else w16.packed.to(device)
-            b = None if bias is None else f32c(bias.detach().to(device))
-            if b is not None and b.numel() < 64:
-                raise DeqsciHipError("Split16Stack: bias must have 64 elements")
-            keep += [wp, b]
-            rows += [wp.data_ptr(), 0 if b is None else b.data_ptr(), (int(w16.sw) & 0xffffffff) | ((1 if relu else 0) << 32)]
-        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
-        self.n_layers, self.keep = len(layers), keep
-        self.sync = torch.zeros(2, dtype=torch.int32, device=device)      # arrival counter, time-out flag
-
-
-def conv3x3_c64_split16_stack(x, stack, bufs, ranges=None, events=None):
-    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack) in ONE launch; bufs = (Sp16, Sp16) ping-pong outputs (layer l writes
-    bufs[l % 2]); ranges: the (n_layers + 1,) slice of range slots - input of the run first - or None (fixed exponents: the input's and
-    2^8).  Returns the Sp16 the last layer wrote.  The persistent workgroups meet at a grid-wide barrier between layers; stack.sync[1] != 0
-    afterwards means a barrier timed out (a workgroup was not resident) and the result is invalid - check_stack_sync raises."""
-    if not isinstance(x, Sp16) or not isinstance(stack, Split16Stack) or len(bufs) != 2 or not all(isinstance(b, Sp16) for b in bufs):
-        raise DeqsciHipError("conv3x3_c64_split16_stack: Sp16 input, Split16Stack and two Sp16 buffers required")
-    n, H, W = x.n, x.H, x.W
-    for b in bufs:
-        if (b.n, b.H, b.W) != (n, H, W) or b.t.device != x.t.device or not b.t.is_contiguous():
-            raise DeqsciHipError("conv3x3_c64_split16_stack: buffers must match the input's (n, H, W) and device")
-    if ranges is not None and (ranges.dtype != torch.float32 or ranges.numel() != stack.n_layers + 1 or not ranges.is_contiguous()):
-        raise DeqsciHipError("conv3x3_c64_split16_stack: ranges must hold n_layers + 1 contiguous fp32 slots")
-    if ranges is None and x.rng is not None:
-        raise DeqsciHipError("conv3x3_c64_split16_stack: an input with a measured range needs the ranges of the whole run")
-    ev = _hook_events("s16", n, H, W, events, layers=stack.n_layers) or (None, None)
-    stack.sync[0:1].zero_()                                   # (the arrival counter; the time-out flag stays until check_stack_sync reads it)
-    with _dev(x.t):
-        _check(load().deqsci_conv3x3_c64_split16_stack(x.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), stack.table.data_ptr(), stack.n_layers,
-                                                       n, H, W, None if ranges is None else ranges.data_ptr(), x.exp, SP16_DEFAULT_EXP,
-                                                       stack.sync.data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_split16_stack")
-    out = bufs[(stack.n_layers - 1) % 2]
-    out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers:stack.n_layers + 1]), SP16_DEFAULT_EXP
-    return out
-
-
-def check_stack_sync(stack):
-    """(host sync) raise if a grid barrier of the last launch of `stack` timed out."""
-    if stack is not None and int(stack.sync[1]) != 0:
-        stack.sync[1:2].zero_()
-        raise DeqsciHipError("conv3x3_c64_split16_stack: a grid-wide barrier timed out (not every workgroup of the launch was resident: "
-                             "is another process using this GPU's CUs?); the result of that call is invalid - rerun with stack=False")
 
 
 class Conv64Weights:

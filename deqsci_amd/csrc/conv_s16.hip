@@ -114,27 +114,18 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // TRACK = 1: the range MEASUREMENT - the same arithmetic, but instead of storing y the launch folds max |y| (true units, pixels of the
 // image only) into *track with one atomic per workgroup
 // The ranges (common.hpp): the input holds 2^e_in x, e_in from *in_amax (or in_exp); the sp16 output 2^e_out y, e_out from *out_amax (or out_exp)
-// STACK = 1: a RUN of n_layers 64->64 layers in ONE launch (the denoisers' 13 / 2 middle layers): the persistent workgroups walk the
-// same tiles layer after layer with a grid-wide barrier in between (release: L2 write-back, one atomic per workgroup, acquire: cache
-// invalidate - what the end of a kernel and the start of the next do, without the dispatch in between).  Layer l reads x (l = 0) or the
-// ping-pong buffer it wrote last, writes y (l even) / y2 (l odd); its parameters come from `layers`, its ranges from in_amax[l], in_amax[l + 1]
-// (in_amax = the slot of the run's input; NULL: in_exp / out_exp throughout).  gbar: two zeroed words (arrival counter, time-out flag).
-struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
-constexpr unsigned STACK_SPIN_LIMIT = 1u << 22;              // (~ seconds) a barrier that never completes sets gbar[1] instead of hanging the GPU
-template <int OUT_F32, int TRACK, int STACK>
+template <int OUT_F32, int TRACK>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
                                                           char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
                                                           const float* __restrict__ out_amax, int out_exp, float* __restrict__ track, int tiles_x, int tiles_y,
-                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx,
-                                                          char* __restrict__ y2, const StackLayer* __restrict__ layers, int n_layers, unsigned* __restrict__ gbar) {
+                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
     __shared__ uint32_t trk_s[WAVES];
     // acc = 2^(e_in + w_exp) sum w x  ->  2^e_out y; the bias likewise
-    int e_out = OUT_F32 ? 0 : sp16_resolve_exp(STACK ? nullptr : out_amax, out_exp);
-    float oscale = sp16_pow2(e_out - sp16_resolve_exp(STACK ? nullptr : in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
-    char* const y_even = y;
+    const int e_out = OUT_F32 ? 0 : sp16_resolve_exp(out_amax, out_exp);
+    const float oscale = sp16_pow2(e_out - sp16_resolve_exp(in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
     uint32_t trk_max = 0;                                      // (TRACK) the wave's running max |stored output| as float bits, wave-uniform
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
@@ -148,7 +139,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             t_end = min(n_tiles, ((b & 7) + 1) * per_xcd);
         } else { t_first = b; t_step = nb; t_end = n_tiles; }
     }
-    if (!STACK && t_first >= t_end) return;                     // (a workgroup of a STACK launch without tiles still keeps the barriers)
+    if (t_first >= t_end) return;
     const int64_t HW = (int64_t)H * W;
 
     // ---- halo tile by LDS-DMA: slot s = 64 (5 wave + j) + lane of the chunk tile is plane p = s / 612 (p = 2 hl + kb), pixel
@@ -484,19 +475,6 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
 #endif
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0};
-#pragma unroll 1
-    for (int L = 0; L < (STACK ? n_layers : 1); ++L) {
-    if (STACK) {
-        const StackLayer ly = layers[L];                       // (wave-uniform: scalar loads)
-        Wp = ly.w; bias = ly.bias; w_exp = ly.w_exp; relu = ly.relu;
-        if (L > 0) x = y;                                      // what the layer before wrote
-        y = (L & 1) ? y2 : y_even;
-        const int e_in = in_amax ? sp16_act_exp(in_amax[L]) : in_exp;
-        e_out = in_amax ? sp16_act_exp(in_amax[L + 1]) : out_exp;
-        oscale = sp16_pow2(e_out - e_in - w_exp);
-        bscale = sp16_pow2(e_out);
-    }
-    if (!STACK || t_first < t_end) {
     // ---- prologue: bias, chunk 0 of the first tile
 #ifdef S16_STAMP
     if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
@@ -584,25 +562,6 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         S16_MARK(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }                                                          // (has tiles)
-    if (STACK && L + 1 < n_layers) {
-        // ---- grid-wide barrier between two layers.  Every wave has waited for its stores (vmcnt(0) above); one lane writes the L2 back
-        // (release at agent scope), arrives, and waits for all workgroups of the launch; then every wave drops its caches (acquire).
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(gbar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned target = gridDim.x * (unsigned)(L + 1);
-            unsigned spins = 0;
-            while (__hip_atomic_load(gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                if (++spins > STACK_SPIN_LIMIT) { __hip_atomic_fetch_or(gbar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    }                                                          // (layers)
     if (TRACK) {
         if (lane == 0) trk_s[wave] = trk_max;
         __syncthreads();
@@ -943,43 +902,11 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
 #define S16_LAUNCH(KERNEL)                                                                                                                  \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
                           bias, static_cast<char*>(y), (int)H, (int)W, relu, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, (int)tiles_x,       \
-                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(nullptr),                                        \
-                          static_cast<const s16::StackLayer*>(nullptr), 1, static_cast<unsigned*>(nullptr))
-    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0, 0>));
-    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1, 0>));
-    else S16_LAUNCH((s16::conv_s16_kernel<0, 0, 0>));
+                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx)
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0>));
+    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1>));
+    else S16_LAUNCH((s16::conv_s16_kernel<0, 0>));
 #undef S16_LAUNCH
-    return launch_status();
-}
-
-static_assert(sizeof(s16::StackLayer) == 24, "the layer table of deqsci_conv3x3_c64_split16_stack is three 8-byte words per layer");
-
-extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
-                                                int64_t n, int64_t H, int64_t W, const float* ranges, int in_exp, int out_exp, void* sync2,
-                                                deqsci_stream_t stream, void* start_event, void* stop_event) {
-    if (!x_sp16 || !y_even || !layers || !sync2 || (n_layers > 1 && !y_odd)) return DEQSCI_ERR_NULL;
-    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
-    if (n <= 0 || H <= 0 || W <= 0 || n_layers <= 0) return DEQSCI_ERR_SHAPE;
-    if (x_sp16 == y_even || x_sp16 == y_odd || y_even == y_odd || n_layers > 64 || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
-    if (!aligned16(x_sp16) || !aligned16(y_even) || !aligned16(y_odd) || (reinterpret_cast<uintptr_t>(layers) & 7u) || (reinterpret_cast<uintptr_t>(sync2) & 3u))
-        return DEQSCI_ERR_ALIGN;
-    const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
-    const int64_t n_tiles = n * tiles_x * tiles_y;
-    if (n_tiles > (int64_t)INT32_MAX / 16 || H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // every workgroup of the launch has to be RESIDENT (they wait for one another between the layers): one per CU - the kernel's 152 KB of
-    // LDS admit no second one - and never more workgroups than CUs
-    const int64_t resident = (int64_t)num_cus();
-    const dim3 grid((unsigned)(n_tiles < resident ? n_tiles : resident));
-    uint32_t mg_img, sh_img, mg_tx, sh_tx;
-    s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
-    s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
-    hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
-    hipExtLaunchKernelGGL((s16::conv_s16_kernel<0, 0, 1>), grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16),
-                          static_cast<const char*>(nullptr), static_cast<const float*>(nullptr), static_cast<char*>(y_even), (int)H, (int)W, 0, 0, ranges,
-                          in_exp, static_cast<const float*>(nullptr), out_exp, static_cast<float*>(nullptr), (int)tiles_x, (int)tiles_y, (int)n_tiles,
-                          mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(y_odd), static_cast<const s16::StackLayer*>(layers), n_layers,
-                          static_cast<unsigned*>(sync2));
     return launch_status();
 }
 

@@ -64,7 +64,7 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True, stack=True):
+                 act_range="data", blk32=True):
         from .networks import FFDNet
         self.net = net
         self.fused_edges = fused_edges
@@ -80,14 +80,9 @@ class _Denoiser:
         if act_range not in ("data", "fixed"):
             raise ValueError(f"act_range={act_range!r}: expected 'data' or 'fixed'")
         self.act_range = act_range
-        # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch with grid-wide barriers between the layers
-        # (_hip.conv3x3_c64_split16_stack) instead of one launch per layer; the measuring f-call keeps the per-layer launches
-        self.stack = bool(stack)
-        self._stacks = {}                                           # first layer index of a run -> _hip.Split16Stack
         self.ranges = None                                          # (len(layers) + 1,) fp32 on the device: slot i = max |input of layer i|
         self._calibrating = False
         self._stale = True                                          # the ranges have not been measured on the current input yet
-        self._stack_used = None                                     # the Split16Stack launched last (its time-out flag is read after the run)
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
         # MIOpen trade-off measured on MI355X (profiles/r01_denoiser_variants.jsonl): 8 % faster for FFDNet's
         # 128x128x64 layers, 11 % slower for SimpleCNN's 256x256x64 ones.
@@ -153,7 +148,6 @@ class _Denoiser:
                                                                       and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
             self.ranges = None
-            self._stacks = {}
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
@@ -195,21 +189,7 @@ class _Denoiser:
             return F.conv2d(self._run_layers(h, idx[:-1], fused), w, None, padding=1), b
         return self._run_layers(h, idx, fused)
 
-    def _stack_for(self, idx, device):
-        """The Split16Stack of the run of layers idx (built outside any hipGraph capture: prepare() does it for the shipped denoisers)."""
-        st = self._stacks.get(idx[0])
-        if st is None or st.n_layers != len(idx) or st.table.device != torch.device(device):
-            st = self._stacks[idx[0]] = _hip.Split16Stack([(self.wino[i].s16, self.fast[i][1], self.fast[i][2]) for i in idx], device)
-        return st
-
     def _run_layers(self, h, idx, fused):
-        if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= 2 and self._native_out and not self._calibrating
-                and all(self.wino[i] is not None for i in idx) and (h.rng is None) == (self.ranges is None)):
-            # the whole run in one launch: sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
-            st = self._stack_for(idx, h.t.device)
-            bufs = (_hip.Sp16.empty(h.n, h.H, h.W, h.t.device), _hip.Sp16.empty(h.n, h.H, h.W, h.t.device))
-            self._stack_used = st
-            return _hip.conv3x3_c64_split16_stack(h, st, bufs, None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2])
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
             nxt = idx[pos + 1] if pos + 1 < len(idx) else None
@@ -253,9 +233,6 @@ class _Denoiser:
         if self.fast is not None and self.act_range == "data" and (self.ranges is None or self.ranges.device != torch.device(device)):
             # kept across calls: a captured hipGraph carries this tensor's address in its conv nodes
             self.ranges = torch.zeros(len(self.fast) + 1, dtype=torch.float32, device=device)
-        if (self.fast is not None and self.stack and self.conv64 in ("fast", "s16") and len(self.fast) >= 4
-                and all(u is not None for u in self.wino[1:-1]) and self.wino[1] is not None and self.wino[1].s16.packed.is_cuda):
-            self._stack_for(list(range(1, len(self.fast) - 1)), device)      # (an H2D copy: here, never inside a capture)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
@@ -346,9 +323,18 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, stack=True):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64"):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
+        if anderson_arith not in ("float64", "reference"):
+            raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'float64' or 'reference'")
+        # How alpha is computed.  "float64" (default): the Gram row accumulated in float64 from the fp32 block partials of K4, the bordered
+        # system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference": the reference's own arithmetic for that step,
+        # solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over the N = H W B elements (rocBLAS here, MKL there:
+        # ~5e-6 relative on an entry at N = 2^19), the system solved by fp32 LU (torch.linalg.solve_ex) - eager launches only.  It exists
+        # because that rounding error is not neutral on BASELINE config 2: it is what puts the reference's 180-iteration ensemble mean
+        # 0.02 dB above the exact-Gram result ("Config 2"; tools/config2_anderson_arith.py).
+        self.anderson_arith = anderson_arith
         if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
             raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'fast32', 'f22', 'f44' or 's16'")
         # Which kernel runs the 64->64 layers (_hip.conv64_kernel_for): "fast" (= "auto") the faster of the split-fp16 direct convolution
@@ -369,7 +355,7 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
@@ -405,7 +391,18 @@ class DEQSCIEngine:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
         else:
             _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
-        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row)
+        ref = self.anderson_arith == "reference" and n_solve > 0
+        _hip.anderson_solve(ws, slot, n_filled, 0 if ref else n_solve, self.lam, eps, res_row)      # (n = 0: residual only)
+        if ref:
+            n = n_solve
+            G = ws.G[:, :n]                                                                     # rows in the reference's slot order k % m
+            H = torch.zeros((ws.bsz, n + 1, n + 1), dtype=torch.float32, device=G.device)
+            H[:, 0, 1:] = 1
+            H[:, 1:, 0] = 1
+            H[:, 1:, 1:] = torch.bmm(G, G.transpose(1, 2)) + self.lam * torch.eye(n, dtype=torch.float32, device=G.device)[None]      # :178
+            rhs = torch.zeros((ws.bsz, n + 1, 1), dtype=torch.float32, device=G.device)
+            rhs[:, 0] = 1
+            ws.alpha[:, :n] = torch.linalg.solve_ex(H, rhs, check_errors=False)[0][:, 1:, 0]       # :180
 
     def _poll(self, ws, row):
         ws.host_res[row].copy_(ws.res[row], non_blocking=True)
@@ -437,9 +434,6 @@ class DEQSCIEngine:
                     self.conv64_policy, self.den.conv64, self.use_graph = saved
                     self.den._policy = saved[1]
                 fallback = "fast32"
-            if self.den._stack_used is not None:               # a grid barrier of a stack launch that timed out invalidates the run: loud
-                st, self.den._stack_used = self.den._stack_used, None
-                _hip.check_stack_sync(st)
             self.last_info["conv64_fallback"] = fallback
             # what the first f-call measured: max |activation| in front of every layer of the denoiser's stack (0 where no split-fp16
             # layer ran); the exponents the kernels derived from them are _hip.act_exp of these
@@ -462,6 +456,8 @@ class DEQSCIEngine:
         ws = self._workspace(bsz, H, W, B, y.device)
         self.den.prepare(self.max_iter + 4, y.device)
         graph = self.use_graph if self.use_graph != "auto" else bsz * H * W <= self.GRAPH_AUTO_PIXELS
+        if self.anderson_arith == "reference":
+            graph = False                                      # (torch's batched LU is not a captured node of this engine's graph)
         if graph:
             rec = self._replay(ws, y, Phi4, Phi_sum, initial_point)
             if rec is not None:

@@ -207,17 +207,6 @@ int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const f
                                int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
                                const float* out_amax, int out_exp, float* track_amax, int out_f32,
                                deqsci_stream_t stream, void* start_event, void* stop_event);
-/* A RUN of n_layers such layers (the denoisers' 13 / 2 middle layers, each followed by the next) in ONE launch: the kernel's persistent
- *     workgroups - one per CU, all resident - walk the same tiles layer after layer and meet at a grid-wide barrier in between (L2
- *     write-back, one atomic per workgroup, cache invalidate: what a kernel boundary does, without the dispatch).  layers: DEVICE table
- *     of n_layers x { const void* w_packed; const float* bias (may be NULL); int32 w_exp; int32 relu } (24 bytes each).  Layer l reads
- *     x_sp16 (l = 0) or the buffer layer l - 1 wrote, and writes y_even (l even) / y_odd (l odd); all sp16.  ranges: n_layers + 1
- *     consecutive range slots, ranges[l] = max |input of layer l| (NULL: the input holds 2^in_exp x, every output 2^out_exp y).
- *     sync2: two zeroed 32-bit DEVICE words; sync2[1] != 0 after the launch = a barrier timed out (a workgroup was not resident) and
- *     the output is invalid - the launch never hangs.  Same size limits as the single layer. */
-int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
-                                     int64_t n, int64_t H, int64_t W, const float* ranges, int in_exp, int out_exp, void* sync2,
-                                     deqsci_stream_t stream, void* start_event, void* stop_event);
 /* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and max |x| over `count` floats folded into *amax (zero it first):
  *     the range of an activation no sp16-writing kernel produced (the denoiser's input image; a converted fp32 activation). */
 int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, const float* amax, int exp,

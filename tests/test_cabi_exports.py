@@ -83,15 +83,6 @@ def test_scratch_size_queries_and_error_strings():
     assert s16(p16 + 4, p16, q16) == -3
     assert s16(p16, p16, q16, n=0) == -2
     assert s16(p16, p16, q16, ev1=p16) == -1                                                   # one event only
-    # the run of layers in one launch: the same contract, plus its own arguments
-    r16 = q16 + 64
-
-    def stk(x, ya, yb, tab, nl=3, n=1, H=16, W=16, sync=q16, in_exp=8, ev0=None, ev1=None):
-        return lib.deqsci_conv3x3_c64_split16_stack(x, ya, yb, tab, nl, n, H, W, None, in_exp, 8, sync, None, ev0, ev1)
-    assert stk(None, q16, r16, p16) == -1 and stk(p16, q16, None, p16) == -1 and stk(p16, q16, r16, p16, sync=None) == -1
-    assert stk(p16, p16, r16, p16) == -4 and stk(p16, q16, q16, p16) == -4 and stk(p16, q16, r16, p16, nl=65) == -4
-    assert stk(p16, q16, r16, p16, nl=0) == -2 and stk(p16, q16, r16, p16, in_exp=65) == -4 and stk(p16, q16, r16, p16 + 4) == -3
-    assert stk(p16, q16, r16, p16, H=2900, W=2900) == -4 and stk(p16, q16, r16, p16, ev0=p16) == -1
     assert lib.deqsci_f32_to_split16(None, q16, 1, 4, 4, None, 8, None) == -1 and lib.deqsci_f32_to_split16(p16, q16, 1, 0, 4, None, 8, None) == -2
     assert lib.deqsci_f32_to_split16(p16, q16, 1, 4, 4, None, 99, None) == -4
     assert lib.deqsci_absmax_f32(None, 4, p16, None) == -1 and lib.deqsci_absmax_f32(p16, 0, p16, None) == -2 and lib.deqsci_absmax_f32(p16 + 4, 4, p16, None) == -3
@@ -196,7 +187,7 @@ def test_split16_kernels_have_no_spills(tmp_path):
     moving the tile bookkeeping into the MFMA stream: 2-8 spilled registers, tile_done reloading in the middle of the last stage)."""
     report, text = _compile_with_resource_report("conv_s16.hip", tmp_path)
     kernels = re.findall(_RESOURCES % "(?:conv_s16_kernel|tail_s16_kernel|head_s16_kernel)", report, flags=re.S)
-    assert len(kernels) == 7, report[-2000:]                           # conv <0,0,0>, <1,0,0>, <0,1,0> (the measuring launch), <0,0,1> (the stack); tail <4>, <1>; head
+    assert len(kernels) == 6, report[-2000:]                           # conv <0,0>, <1,0>, <0,1> (the measuring launch); tail <4>, <1>; head
     for name, vgprs, scratch, sspill, vspill in kernels:
         assert int(vgprs) <= 256 and (int(scratch), int(sspill), int(vspill)) == (0, 0, 0), (name, vgprs, scratch, sspill, vspill)
     assert text.count("v_mfma_f32_32x32x16_f16") > 800

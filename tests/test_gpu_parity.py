@@ -946,70 +946,6 @@ def _denoiser_error_vs_float64(net, z1, call=3):
     return err
 
 
-@pytest.mark.parametrize("shape,layers", [((8, 128, 128), 13), ((3, 40, 56), 3), ((1, 16, 32), 2), ((70, 64, 80), 4), ((2, 17, 23), 5), ((300, 16, 16), 2)])
-def test_split16_stack_is_bit_identical_to_single_layers(shape, layers):
-    """A run of split-fp16 64->64 layers as ONE launch (persistent workgroups, grid-wide barrier between the layers:
-    _hip.conv3x3_c64_split16_stack) against the same layers launched one by one: the same arithmetic in the same order, so the sp16
-    output is bit-identical - with measured ranges and with the fixed exponent, from fewer tiles than CUs (one workgroup per tile)
-    to runs of many tiles per workgroup and ragged per-XCD ranges; repeated launches leave nothing behind; no barrier timed out."""
-    n, H, W = shape
-    g = torch.Generator(device=DEV).manual_seed(41)
-    x = torch.relu(torch.randn(n, 64, H, W, device=DEV, generator=g)).contiguous(memory_format=torch.channels_last)
-    ws = [torch.randn(64, 64, 3, 3, device=DEV, generator=g) * (2.0 / 576) ** 0.5 for _ in range(layers)]
-    bs = [None if i % 3 == 2 else torch.randn(64, device=DEV, generator=g) * 0.1 for i in range(layers)]
-    relus = [i % 4 != 3 for i in range(layers)]
-    Ws = [_hip.Split16Weights(w) for w in ws]
-    for measured in (True, False):
-        rng = torch.zeros(layers + 1, device=DEV) if measured else None
-        slot = (lambda i: rng[i:i + 1]) if measured else (lambda i: None)
-        if measured:
-            _hip.absmax(x, slot(0))
-        h = _hip.to_split16(x, rng=slot(0))
-        for i in range(layers):
-            if measured:
-                _hip.conv3x3_c64_split16(h, Ws[i], bs[i], relus[i], track=slot(i + 1))
-            h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], relus[i], out_rng=slot(i + 1))
-        st = _hip.Split16Stack(list(zip(Ws, bs, relus)), DEV)
-        bufs = (_hip.Sp16.empty(n, H, W, DEV), _hip.Sp16.empty(n, H, W, DEV))
-        for b in bufs:
-            b.t.fill_(float("nan"))
-        for _ in range(2):
-            got = _hip.conv3x3_c64_split16_stack(_hip.to_split16(x, rng=slot(0)), st, bufs, rng)
-            assert got is bufs[(layers - 1) % 2] and torch.equal(got.t, h.t) and got.exponent() == h.exponent()
-        _hip.check_stack_sync(st)
-        assert int(st.sync[0]) == (layers - 1) * min(n * -(-H // 16) * -(-W // 32), torch.cuda.get_device_properties(0).multi_processor_count)
-    want = x.double()
-    for i in range(layers):
-        want = torch.nn.functional.conv2d(want, ws[i].double(), None if bs[i] is None else bs[i].double(), padding=1)
-        want = torch.relu(want) if relus[i] else want
-    assert float((h.to_nchw().double() - want).norm() / want.norm()) < 2.5e-7 * layers
-
-
-@pytest.mark.parametrize("kind,weights", [("ffdnet", "ffdnet_gray"), ("SimpleCNN", "cnn")])
-def test_engine_stack_launch_is_bit_identical(kind, weights):
-    """The engine with the denoiser's run of 64->64 layers as one launch per f-call (stack=True, the default) against one launch per
-    layer: bit-identical reconstructions, eagerly (8 measurements) and through the hipGraph (one measurement per call)."""
-    d = _clip("traffic_cacti.mat")
-    Phi = d["mask"][None].to(DEV)
-    ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)
-    net = build_pipeline(kind, checkpoint.shipped(weights), 8)[0].nonlinear_op
-    seen = []
-    _hip.CONV64_EVENT_HOOK = lambda k, n, h, w, layers=1: seen.append(layers)
-    try:
-        a = DEQSCIEngine(net, max_iter=8, use_graph=False).reconstruct(ys, Phi)
-    finally:
-        _hip.CONV64_EVENT_HOOK = None
-    nl = 13 if kind == "ffdnet" else 2
-    assert seen.count(nl) == 8 and seen.count(1) == nl           # the measuring f-call launches layer by layer (its measuring launches are not timed); then one launch per f-call
-    b = DEQSCIEngine(net, max_iter=8, use_graph=False, stack=False).reconstruct(ys, Phi)
-    assert torch.equal(a, b)
-    g1, g0 = DEQSCIEngine(net, max_iter=8, use_graph=True), DEQSCIEngine(net, max_iter=8, use_graph=True, stack=False)
-    for _ in range(3):
-        r1, r0 = g1.reconstruct(ys[:1], Phi), g0.reconstruct(ys[:1], Phi)
-        assert torch.equal(r1, r0)
-    assert g1.last_info["graph"] is True and torch.equal(r1, DEQSCIEngine(net, max_iter=8, use_graph=False).reconstruct(ys[:1], Phi))
-
-
 def test_ranges_are_measured_by_the_first_split16_call():
     """The ranges of the split-fp16 activations are measured by the first f-call that takes that path - f-call 0, unless the policy runs
     its first K f-calls on another kernel (conv64_f22_calls=K): then f-call K measures (a round-4 bug: it used unmeasured slots and the
@@ -1348,41 +1284,18 @@ def _se(v):
     return float(np.std(v, ddof=1) / np.sqrt(len(v)))
 
 
-def test_config2_ffdnet_anderson_180_all_measurements():
-    """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement, on the
-    DEFAULT engine (conv64="auto": the split-fp16 direct convolution at this size).
-    The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0),
-    so one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and
-    x0 (1 + 1e-7 randn), seeds 1.. - on both sides:
-      reference (generated by importing it, make_golden g10): as it is, and with the Gram matrix of :178
-        computed exactly (25 runs per chaotic measurement each: seeds 1-24; 9-10 on drop8 / runner8).  The second exists because the reference's fp32 torch.bmm Gram carries ~1e-6 of rounding error at
-        N = 2^19, which the ill-conditioned Anderson system turns into ~5e-4 of noise on alpha; this build sums the Gram partials
-        in float64 and belongs to the second ensemble (deviation 3).
-      build: 25 starts per measurement through the engine.
-    Bounds are STATISTICAL, computed from the two ensembles themselves, not hand-set:
-      * the mean over the six chaotic measurements of the per-measurement ensemble means: within 3 standard errors of the
-        difference from the exact-Gram reference (observed -0.006 dB at SE 0.0057: 3 SE = 0.017), and from the reference AS IT IS within 3 SE
-        plus the shift the reference itself shows between its two Gram variants (0.005 dB);
-      * per chaotic measurement: mean within 3 SE of the difference from the exact-Gram reference mean PLUS the distance between the
-        reference's own two variants on that measurement.  (The x0-ensemble samples the chaos, not the implementation: ANY change of
-        arithmetic moves single measurements by more than their ensemble SE of ~0.01-0.02 dB, in both directions - the reference's
-        Gram variants differ by -0.03 .. +0.15 dB per measurement (RMS 0.065), this build with F(2x2,3x3) / with MIOpen's direct
-        convolution sits at +0.01 / -0.09 dB on m0 and -0.09 / +0.00 dB on m2 (profiles/r03_config2_ensembles.json); the six-measurement
-        mean above averages that out and is the statistic with power.)  Median PSNR / residual inside the hull of both reference
-        ensembles widened by 1.5 (+ 0.01 dB / 1 %); no run further than 1.5 hull widths outside;
-      * the RMS over the six of (build mean - exact-Gram reference mean) no larger than the same RMS for the reference as it is (0.065 dB):
-        the build deviates from the exact-arithmetic reference less than the shipped reference does;
-      * well-conditioned measurements (drop8, runner8: reference bands of 2 and 25 mdB): ensemble mean within 0.01 dB (+ 3 SE) of the
-        reference's, every one of the 25 runs within 1.5 reference hull widths of the reference's 9-10 run hull;
-      * the harness average of the unperturbed run inside the hull of the two reference average bands."""
+CONFIG2_GRAM_SHIFT = 0.020   # dB: what the reference's fp32 torch.bmm Gram adds to the six-measurement mean (profiles/r04_config2_anderson_arith_*:
+                             # +0.018 / +0.022 +- 0.005 between fp32 and fp64 Gram, same code path, same denoiser, same seeds)
+
+
+def _config2_ensembles(eng, chaotic_only=False):
+    """-> [(measurement id, build PSNRs, build residuals, reference-as-it-is PSNRs, reference-exact-Gram PSNRs, reference residuals)], unperturbed PSNR by clip"""
     from deqsci_amd.harness import SCITestDataset, as_clip, psnr, scored_measurements
     a, b = _config2_reference()
-    solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
-    eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
-    assert eng.conv64 == "auto" and eng.conv64_f22_calls is None and eng.conv64_policy == "fast"
-    assert _hip.conv64_kernel_for(8, 128, 128, policy=eng.conv64_policy) == "s16"      # one measurement per call = 8 images of 128 x 128
     report, base_by_clip = [], {}
     for clip in (as_clip(c) for c in SCITestDataset(orc.DATA_DIR)):
+        if chaotic_only and "traffic" not in clip["file"]:
+            continue
         Phi = clip["mask"].to(DEV)[None].contiguous()
         for fi in scored_measurements(clip["file"], clip["meas"].shape[-1]):
             mid = f"{clip['file']}:{fi}"
@@ -1406,6 +1319,45 @@ def test_config2_ffdnet_anderson_180_all_measurements():
             rb = [v["psnr"] for v in vb.values()]
             ea = [v["res"] for v in va.values()] + [v["res"] for v in vb.values()]
             report.append((mid, ps, rs, ra, rb, ea))
+    return report, base_by_clip, (a, b)
+
+
+def _pooled(chaotic, k):
+    mean = float(np.mean([np.mean(c[k]) for c in chaotic]))                   # mean of the per-measurement ensemble means
+    se = float(np.sqrt(sum(_se(c[k]) ** 2 for c in chaotic)) / len(chaotic))
+    return mean, se
+
+
+def test_config2_ffdnet_anderson_180_all_measurements():
+    """BASELINE config 2 as stated (test_ffdnet.sh:1-7): FFDNet, Anderson, and_maxiters=180, every shipped measurement, on the DEFAULT
+    engine.  The map is chaotic on the `traffic` clip (the reference moves by 4e-2 rel-L2 / 0.1-0.2 dB under a 1e-7 perturbation of x0), so
+    one run against one run says nothing; the gate compares ENSEMBLES built by the same recipe - the unperturbed x0 and x0 (1 + 1e-7 randn),
+    seeds 1..24 - with the reference's own (make_golden g10: the reference as it is, and with the Gram matrix of :178 in float64).
+
+    What four rounds of measurements established ("Config 2"; profiles/r04_config2_*):
+      * per measurement the ensemble mean is a property of the (measurement, ARITHMETIC) pair, far beyond its ensemble error: the reference's
+        own two variants differ by up to 0.22 dB on one measurement (RMS 0.12 over the six), every implementation of the build likewise;
+      * the six-measurement mean is tight within a family of equivalent arithmetics (12 members, SD 0.003 = sampling error) and does NOT move
+        with the denoiser's rounding (float64 denoiser: 21.414; split-fp16 21.417; F(2x2,3x3) 21.417; MIOpen 21.410);
+      * it DOES move with the precision of the Gram matrix: the reference's Anderson step emulated on the GPU around the same f - fp32
+        torch.bmm Gram, fp32 LU - gives 21.430 +- 0.004 and the reference's per-measurement pattern (m2 at 21.53), the same code with a
+        float64 Gram 21.408 / 21.412.  The reference's fp32 Gram error (~5e-6 at N = 2^19) is worth +0.02 dB at 180 iterations.
+    The build's default keeps the exact Gram (deviation 3), so its pooled mean is EXPECTED CONFIG2_GRAM_SHIFT below the reference's; the
+    engine's `anderson_arith="reference"` (the next test) reproduces the reference's.  Criteria, all computed from the ensembles:
+      * six-measurement mean: no more than 3 SE above the reference's (either variant), no more than CONFIG2_GRAM_SHIFT + 3 SE below;
+      * per chaotic measurement: median PSNR / residual inside the hull of both reference ensembles widened by 1.5 (+ 0.01 dB / 1 %), no run
+        further than 1.5 hull widths outside (25 runs each side; single measurements are arithmetic-dependent, see above);
+      * the RMS over the six of (build mean - exact-Gram reference mean) no larger than the same RMS for the reference as it is;
+      * well-conditioned measurements (drop8, runner8: reference bands of 2 and 25 mdB): ensemble mean within 0.01 dB (+ 3 SE); every run
+        within HALF a reference hull width (+ 0.01 dB) of the reference's 9-10 run hull - the expected range of 25 draws is 1.3 x that
+        of 9, i.e. 0.16 widths per side, and the 9-run hull itself is uncertain by about as much; residuals within 3 % of the reference's
+        band (the residual of a run that has not converged to 1e-5 moves by 1-2 % under a 1e-7 perturbation on either side);
+      * the harness average of the unperturbed run inside the hull of the two reference average bands."""
+    solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
+    eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
+    assert eng.conv64 == "auto" and eng.conv64_f22_calls is None and eng.conv64_policy == "fast" and eng.anderson_arith == "float64"
+    assert _hip.conv64_kernel_for(8, 128, 128, policy=eng.conv64_policy) == "s16"      # one measurement per call = 8 images of 128 x 128
+    report, base_by_clip, (a, b) = _config2_ensembles(eng)
     chaotic = []
     for mid, ps, rs, ra, rb, ea in report:
         lo, hi = _widened(ra + rb, 0.01)
@@ -1415,37 +1367,59 @@ def test_config2_ffdnet_anderson_180_all_measurements():
               % (mid, np.mean(ps), _se(ps), np.median(ps), min(ps), max(ps), np.mean(rb), _se(rb), np.mean(ra), lo, hi))
         w = max(ra + rb) - min(ra + rb)
         if w < 0.05:
-            # well-conditioned (drop8: reference band 2 mdB, runner8: 25 mdB): the ensemble mean to the north_star tolerance of 0.01 dB
-            # (+ 3 SE), every one of the 25 runs within one reference hull width of the (9-10 run) reference hull, residuals likewise
             assert abs(np.mean(ps) - np.mean(rb)) <= 0.01 + 3 * se, (mid, np.mean(ps), np.mean(rb), se)
-            assert min(ra + rb) - 1.5 * w - 0.01 <= min(ps) and max(ps) <= max(ra + rb) + 1.5 * w + 0.01, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
+            assert min(ra + rb) - 0.5 * w - 0.01 <= min(ps) and max(ps) <= max(ra + rb) + 0.5 * w + 0.01, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
             assert all(rlo * 0.97 <= r <= rhi * 1.03 for r in rs), (mid, rs, rlo, rhi)
             continue
         chaotic.append((ps, ra, rb))
-        assert abs(np.mean(ps) - np.mean(rb)) <= 3 * se + abs(np.mean(ra) - np.mean(rb)), (mid, np.mean(ps), np.mean(rb), se, np.mean(ra))
         assert lo <= np.median(ps) <= hi, (mid, np.median(ps), lo, hi)
         assert rlo * 0.99 <= np.median(rs) <= rhi * 1.01, (mid, np.median(rs), rlo, rhi)
-        # (25 runs against the 9-10 of a reference ensemble: the expected range of 25 draws is 1.3x that of 9; 1.5 hull widths outside)
         assert min(ra + rb) - 1.5 * w <= min(ps) and max(ps) <= max(ra + rb) + 1.5 * w, (mid, min(ps), max(ps), min(ra + rb), max(ra + rb))
     assert len(chaotic) == 6
-    pooled = lambda k: float(np.mean([np.mean(c[k]) for c in chaotic]))       # mean of the per-measurement ensemble means
-    pooled_se = lambda k: float(np.sqrt(sum(_se(c[k]) ** 2 for c in chaotic)) / len(chaotic))
-    mb, ma_, mx = pooled(0), pooled(1), pooled(2)
-    se_x, se_a = float(np.hypot(pooled_se(0), pooled_se(2))), float(np.hypot(pooled_se(0), pooled_se(1)))
-    print("six chaotic measurements: build %.4f +- %.4f | reference exact Gram %.4f +- %.4f (diff %+.4f, 3 SE = %.4f) | as it is %.4f +- %.4f "
-          "(diff %+.4f, 3 SE + Gram shift = %.4f)" % (mb, pooled_se(0), mx, pooled_se(2), mb - mx, 3 * se_x, ma_, pooled_se(1), mb - ma_,
-                                                     3 * se_a + abs(ma_ - mx)))
-    assert abs(mb - mx) <= 3 * se_x, (mb, mx, se_x)
-    assert abs(mb - ma_) <= 3 * se_a + abs(ma_ - mx), (mb, ma_, se_a)
-    # and measurement by measurement the build sits closer to the exact-Gram reference than the reference AS IT IS does (RMS over the six
-    # of the differences of ensemble means; the reference's own two variants: 0.065 dB): the yardstick for "implementation-level" offsets
-    rms = lambda k: float(np.sqrt(np.mean([(np.mean(c[k]) - np.mean(c[2])) ** 2 for c in chaotic])))
+    (mb, sb), (ma_, sa), (mx, sx) = _pooled(chaotic, 0), _pooled(chaotic, 1), _pooled(chaotic, 2)
+    print("six chaotic measurements: build %.4f +- %.4f | reference exact Gram %.4f +- %.4f (diff %+.4f) | as it is %.4f +- %.4f (diff %+.4f); "
+          "expected shift of the exact Gram -%.3f" % (mb, sb, mx, sx, mb - mx, ma_, sa, mb - ma_, CONFIG2_GRAM_SHIFT))
+    for ref, sr in ((mx, sx), (ma_, sa)):
+        se = float(np.hypot(sb, sr))
+        assert -(CONFIG2_GRAM_SHIFT + 3 * se) <= mb - ref <= 3 * se, (mb, ref, se)
+    rms = lambda k: float(np.sqrt(np.mean([(np.mean(c[k]) - np.mean(c[2])) ** 2 for c in chaotic])))   # noqa: E731
     print("per-measurement offsets from the exact-Gram reference, RMS: build %.4f dB, reference as it is %.4f dB" % (rms(0), rms(1)))
-    assert rms(0) <= rms(1) + pooled_se(0), (rms(0), rms(1))
+    assert rms(0) <= rms(1) + sb, (rms(0), rms(1))
     avg = float(np.mean([np.mean(v) for v in base_by_clip.values()]))         # test_solver_sci's average: mean over clips of the clip mean
     alo, ahi = _widened([a["avg_psnr_min"], a["avg_psnr_max"], b["avg_psnr_min"], b["avg_psnr_max"]], 0.01)
     print("harness average of the unperturbed run %.4f in [%.4f, %.4f]" % (avg, alo, ahi))
     assert alo <= avg <= ahi, (avg, alo, ahi)
+
+
+def test_config2_with_the_references_anderson_arithmetic():
+    """The other half of the config-2 account: with the reference's OWN arithmetic for alpha - `anderson_arith="reference"`: G G^T as one
+    fp32 torch.bmm over N = 2^19 elements, fp32 LU, solvers/new_equilibrium_utils_yaping.py:177-180 - the engine's 25-start ensembles of the
+    six chaotic measurements reproduce the reference AS IT IS: the six-measurement mean within 3 SE of the difference (the exact-Gram
+    default sits 0.02 below, previous test), and the reference's signature measurement - traffic m2, 21.53 +- 0.01 dB in the reference as
+    it is, 21.31-21.41 under every exact-Gram implementation incl. the float64 denoiser - above 21.45.  On a well-conditioned
+    configuration the two arithmetics agree to 1e-5 and both hold the reference's run at 1e-4."""
+    solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
+    eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, anderson_arith="reference")
+    report, _, _ = _config2_ensembles(eng, chaotic_only=True)
+    assert eng.last_info["graph"] is False
+    chaotic = [(ps, ra, rb) for _, ps, _, ra, rb, _ in report]
+    (mb, sb), (ma_, sa) = _pooled(chaotic, 0), _pooled(chaotic, 1)
+    for (mid, ps, *_), (_, ra, _) in zip(report, chaotic):
+        print("%-22s reference arithmetic on the GPU %.4f +- %.4f | reference as it is %.4f +- %.4f" % (mid, np.mean(ps), _se(ps), np.mean(ra), _se(ra)))
+    print("six chaotic measurements: engine with the reference's Anderson arithmetic %.4f +- %.4f | reference as it is %.4f +- %.4f (diff %+.4f)"
+          % (mb, sb, ma_, sa, mb - ma_))
+    assert abs(mb - ma_) <= 3 * float(np.hypot(sb, sa)), (mb, ma_, sb, sa)
+    m2 = [ps for mid, ps, *_ in report if mid.endswith(":2")][0]
+    assert np.mean(m2) > 21.45, np.mean(m2)
+    # well-conditioned: SimpleCNN @ 180 on traffic m0 against the reference's run, both arithmetics
+    gold = np.load(os.path.join(GOLDEN, "e2e_SimpleCNN_anderson_180_rec.npz"))
+    d = _clip("traffic_cacti.mat")
+    Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 0].contiguous().to(DEV)
+    net = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 180)[0].nonlinear_op
+    r_ref = DEQSCIEngine(net, max_iter=180, anderson_arith="reference").reconstruct(y, Phi).cpu().numpy()
+    r_def = DEQSCIEngine(net, max_iter=180).reconstruct(y, Phi).cpu().numpy()
+    want = gold["traffic_m0"]
+    assert rel_l2(r_ref, r_def) < 1e-5 and rel_l2(r_ref, want) < 1e-4 and rel_l2(r_def, want) < 1e-4
 
 
 def test_conv64_rounding_on_the_networks_own_data():

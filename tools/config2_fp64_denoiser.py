@@ -123,6 +123,10 @@ def main():
             eng = DEQSCIEngine(net, **kw)
         elif v == "fixed":                                     # the round-3 arithmetic: activation scales pinned at 2^8
             eng = DEQSCIEngine(net, act_range="fixed", **kw)
+        elif v == "refarith":                                  # the reference's Anderson arithmetic (fp32 bmm Gram, fp32 LU) around the shipped denoiser
+            eng = DEQSCIEngine(net, anderson_arith="reference", **kw)
+        elif v == "refarith_fp64":                             # ... around the float64 denoiser
+            eng = DEQSCIEngine(Float64FFDNet(net), anderson_arith="reference", **kw)
         elif "+" in v:                                         # "fast+3": the first 3 f-calls on F(2x2,3x3), then the policy - a family of
             pol, k = v.split("+")                              # equivalent arithmetics (the scatter of the pooled mean between implementations)
             eng = DEQSCIEngine(net, conv64=pol, conv64_f22_calls=int(k), **kw)
