@@ -60,6 +60,10 @@ def parser():
     p.add_argument('--conv64', default='auto', choices=['auto', 'fast', 'fast32', 'f22', 'f44', 's16'],
                    help="(this build) kernel of the denoiser's 64->64 layers: auto = split-fp16 direct convolution on the f16 matrix cores / "
                         "Winograd F(2x2,3x3), the faster per launch; fast32 = fp32 MFMA arithmetic only")
+    p.add_argument('--anderson_arith', default='float64', choices=['float64', 'reference'],
+                   help="(this build) how alpha is computed: float64 = Gram and solve in float64 (default, exact); reference = the reference's "
+                        "own arithmetic (one fp32 torch.bmm Gram + fp32 LU, new_equilibrium_utils_yaping.py:177-180) - reproduces the reference's "
+                        "ensemble statistics on the chaotic FFDNet + Anderson @180 configuration (DESIGN.md section 5)")
     p.add_argument('--batch_measurements', action='store_true',
                    help="(this build) a clip's measurements as ONE engine batch instead of the reference's one-by-one schedule; "
                         "implied by more than one --gpu_ids entry, which shards them")
@@ -82,8 +86,13 @@ def run(args):
     rank, world, _, dev = distributed.init_from_env("nccl")
     loadpath = args.loadpath or checkpoint.shipped(SHIPPED[args.denoiser])
     _, deq = build_pipeline(args.denoiser, loadpath, args.and_maxiters, args.and_m, args.and_beta, device=dev)
+    opts = {}
     if args.conv64 != 'auto':
-        deq.engine_options = {"conv64": args.conv64}
+        opts["conv64"] = args.conv64
+    if args.anderson_arith != 'float64':
+        opts["anderson_arith"] = args.anderson_arith
+    if opts:
+        deq.engine_options = opts
     if rank == 0:
         print('loaded dict!')
         os.makedirs(args.savepath, exist_ok=True)

@@ -737,6 +737,8 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
 // the sigma plane in LDS, multiplies by 2^8 and splits them into hi + lo fp16 on the fly; the weight operands (12 fragments) stay in
 // registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
 constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
+template <int TRACK>   // 1: additionally folds max |output| into *track (the measuring launch of the first f-call; the per-value maximum costs the
+                       // gather-bound kernel a quarter of its time, so the other 180 calls run without it)
 __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
                                                        int sigma_stride, char* __restrict__ y, int H, int W, int w_exp, const float* __restrict__ in_amax,
                                                        int in_exp, const float* __restrict__ out_amax, int out_exp, float* __restrict__ track) {
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                     f32x2 t = (f32x2){acc[g][i], acc[g][i + 1]} * (f32x2){oscale, oscale};
                     t.x = __builtin_elementwise_maximum(t.x, 0.0f);
                     t.y = __builtin_elementwise_maximum(t.y, 0.0f);
-                    if (pix != RAW_OOB) tmax = fmaxf(tmax, fmaxf(t.x, t.y));                        // (positions of the image only)
+                    if (TRACK && pix != RAW_OOB) tmax = fmaxf(tmax, fmaxf(t.x, t.y));               // (positions of the image only)
                     const h2 hh = __builtin_convertvector(t, h2);
                     hi[e] = __builtin_bit_cast(unsigned, hh);
                     lo[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(t - __builtin_convertvector(hh, f32x2), h2));
@@ -862,7 +864,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                 asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
             }
     }
-    if (track) sp16_track_block_max(tmax, sp16_pow2(-e_out), track, trk_s);      // (uniform: the range measurement of the first f-call)
+    if (TRACK) sp16_track_block_max(tmax, sp16_pow2(-e_out), track, trk_s);
 }
 
 }  // namespace s16
@@ -966,7 +968,11 @@ extern "C" int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, 
     if (bad_exp(w_exp) || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(w_packed) || !aligned16(h_sp16)) return DEQSCI_ERR_ALIGN;
     const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
-    hipLaunchKernelGGL(s16::head_s16_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
-                       (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
+    if (track_amax)
+        hipLaunchKernelGGL(s16::head_s16_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                           (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
+    else
+        hipLaunchKernelGGL(s16::head_s16_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                           (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
     return launch_status();
 }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
         if (r < H && c < W) {
             if (relu) { acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f); }
             if (OUT_SP16) {
-                tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+                if (track) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));   // (uniform branch)
                 sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, acc, oscale, true);
             } else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
         }

@@ -946,6 +946,34 @@ def _denoiser_error_vs_float64(net, z1, call=3):
     return err
 
 
+def test_config3_synthetic_batch_vs_oracle():
+    """BASELINE config 3 - what bench.py times: the synthetic batch of SURVEY 8(d) C3 (Bernoulli(0.5) masks, x ~ U[0,1), y = Phi x, one mask
+    per measurement, seed (1234, i)), 256 x 256 x 8, FFDNet - checked directly: measurements 0..2 as ONE engine batch (24 images of 128 x 128:
+    the split-fp16 kernel with its ranges measured over the batch), and_maxiters=10 (the chaos-free horizon), against the CPU
+    oracle run measurement by measurement; and the batch result equals the one-by-one results to rounding (the batch shares its activation
+    ranges, so not bit for bit)."""
+    import bench
+    y, Phi, _ = bench.make_batch(0, 3, 256, 256, 8, 1234, torch.device(DEV))
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 10)[0].nonlinear_op
+    seen = set()
+    _hip.CONV64_EVENT_HOOK = lambda k, n, h, w: seen.add((k, n))
+    try:
+        eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
+        rec = eng.reconstruct(y, Phi)
+    finally:
+        _hip.CONV64_EVENT_HOOK = None
+    assert seen == {("s16", 24)} and eng.last_info["f_calls"] == 11 and 0 < eng.last_info["res"] < 1
+    yc, Pc = y.cpu(), Phi.cpu()
+    for i in range(3):
+        Ps = orc.phi_sum(Pc[i:i + 1])
+        want, wres = orc.deq_forward(orc.ProxGradSCI("ffdnet"), orc.andersonexp, yc[i:i + 1], Pc[i:i + 1], Ps, orc.initial_point(yc[i:i + 1], Pc[i:i + 1]),
+                                     m=5, beta=1.0, lam=1e-2, max_iter=10, tol=1e-5)
+        assert rel_l2(rec[i:i + 1].cpu().numpy(), want.numpy()) < 1e-4
+        assert abs(eng.last_info["res_per_sample"][i] / wres - 1) < 1e-3
+        one = DEQSCIEngine(net, max_iter=10, use_graph=False).reconstruct(y[i:i + 1], Phi[i:i + 1])
+        assert rel_l2(one.cpu().numpy(), rec[i:i + 1].cpu().numpy()) < 1e-5
+
+
 def test_ranges_are_measured_by_the_first_split16_call():
     """The ranges of the split-fp16 activations are measured by the first f-call that takes that path - f-call 0, unless the policy runs
     its first K f-calls on another kernel (conv64_f22_calls=K): then f-call K measures (a round-4 bug: it used unmeasured slots and the
