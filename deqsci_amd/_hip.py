@@ -47,7 +47,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
-    "deqsci_absmax_f32": [_ptr, _i64, _ptr, _ptr],
+    "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
     "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -361,7 +361,7 @@ def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False, out_rng=None,
         o.rng, o.exp = out_rng, SP16_DEFAULT_EXP if out_exp is None else int(out_exp)
         with _dev(x):
             _check(load().deqsci_conv3x3_c1_to_64_sp16(_p(x, "x"), _p(w_packed, "w_packed"), o.t.data_ptr(), n, H, W, 1 if relu else 0,
-                                                       _rng(o.rng), o.exp, _rng(track), _stream()), "conv3x3_c1_to_64_sp16")
+                                                       _rng(o.rng, n), o.exp, _rng(track, n), _stream()), "conv3x3_c1_to_64_sp16")
         return o
     o = out if out is not None else torch.empty((n, 64, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     with _dev(x):
@@ -537,10 +537,11 @@ def conv3x3_c64_winograd44(x, u_packed, bias=None, relu=True, out=None, out_blk=
 
 
 # ----------------------------------------------------------------------------- split-fp16 direct convolution (csrc/conv_s16.hip)
-# An sp16 activation holds the fp16 pieces hi + lo of 2^e x.  fp32 is scale-free, fp16 is not, so e follows the data: the RANGE of an
-# activation is (rng, exp) - `rng` a 1-element fp32 GPU tensor holding max |x| of that activation as a kernel measured it (every kernel
-# that writes or reads the activation derives e = act_exp(max |x|) from that device word: nothing crosses to the host, a captured
-# hipGraph follows its inputs), or None: the fixed exponent `exp`.  The mirror of csrc/common.hpp: sp16_act_exp.
+# An sp16 activation holds the fp16 pieces hi + lo of 2^e x.  fp32 is scale-free, fp16 is not, so e follows the data, PER IMAGE of the
+# batch (a measurement's result never depends on what else is in the batch): the RANGE of an activation is (rng, exp) - `rng` a fp32 GPU
+# tensor of n elements, rng[i] = max |x| of image i of that activation as a kernel measured it (every kernel that writes or reads the
+# activation derives e(i) = act_exp(rng[i]) from those device words: nothing crosses to the host, a captured hipGraph follows its
+# inputs), or None: the fixed exponent `exp` for every image.  The mirror of csrc/common.hpp: sp16_act_exp.
 SP16_DEFAULT_EXP, SP16_TARGET_EXP, SP16_EXP_LIMIT = 8, 11, 64
 SP16_ACT_SCALE = 2.0 ** SP16_DEFAULT_EXP     # the fixed default: 2^8 x suits activations of a few units (|x| < 255.9)
 
@@ -557,24 +558,27 @@ def act_exp(amax):
     return max(-SP16_EXP_LIMIT, min(SP16_EXP_LIMIT, SP16_TARGET_EXP - (e - 127)))
 
 
-def _rng(t):
-    """Device pointer of a range slot (1-element fp32 GPU tensor), or None."""
+def _rng(t, n):
+    """Device pointer of the range slots of an n-image activation (a contiguous fp32 GPU tensor of n elements), or None."""
     if t is None:
         return None
-    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.numel() != 1:
-        raise DeqsciHipError("a range slot must be a 1-element fp32 GPU tensor")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.numel() != n or not t.is_contiguous():
+        raise DeqsciHipError(f"range slots must be a contiguous fp32 GPU tensor with one element per image ({n}), got "
+                             f"{tuple(getattr(t, 'shape', ()))}")
     return t.data_ptr()
 
 
-def absmax(x, slot):
-    """slot = max(slot, max |x|) on the device (zero the slot first): the range of an activation no sp16-writing kernel produced."""
+def absmax(x, slots):
+    """slots[i] = max(slots[i], max |x[i]|) on the device (zero them first), x (n, ...): the ranges of an activation no sp16-writing
+    kernel produced."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == torch.float32):
         raise DeqsciHipError("absmax: fp32 GPU tensor required")
-    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):    # any dense order does
+    if not (x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))):    # any dense order per image does
         x = x.contiguous()
+    n = x.shape[0]
     with _dev(x):
-        _check(load().deqsci_absmax_f32(x.data_ptr(), x.numel(), _rng(slot), _stream()), "absmax")
-    return slot
+        _check(load().deqsci_absmax_f32(x.data_ptr(), n, x.numel() // n, _rng(slots, n), _stream()), "absmax")
+    return slots
 
 
 class Sp16:
@@ -594,13 +598,14 @@ class Sp16:
     def empty(n, H, W, device):
         return Sp16(torch.empty((n, 4, 2, 2, H, W, 8), dtype=torch.float16, device=device), n, H, W)
 
-    def exponent(self):
-        """(host sync when the range is a device slot: tests / tools)"""
-        return self.exp if self.rng is None else act_exp(float(self.rng))
+    def exponents(self):
+        """The exponent of every image (host sync when the ranges are device slots: tests / tools)."""
+        return [self.exp] * self.n if self.rng is None else [act_exp(v) for v in self.rng.tolist()]
 
     def to_nchw(self):
-        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: (hi + lo) / 2^e, exactly."""
-        v = (self.t[:, :, 0].float() + self.t[:, :, 1].float()) * 2.0 ** (-self.exponent())       # (n, 4, 2, H, W, 8)
+        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: (hi + lo) / 2^e(image), exactly."""
+        sc = torch.tensor([2.0 ** (-e) for e in self.exponents()], dtype=torch.float32, device=self.t.device).view(-1, 1, 1, 1, 1, 1)
+        v = (self.t[:, :, 0].float() + self.t[:, :, 1].float()) * sc                               # (n, 4, 2, H, W, 8)
         return v.permute(0, 1, 2, 5, 3, 4).reshape(self.n, 64, self.H, self.W).contiguous(memory_format=torch.channels_last)
 
 
@@ -612,7 +617,7 @@ def to_split16(x, out=None, rng=None, exp=SP16_DEFAULT_EXP):
     o = out if out is not None else Sp16.empty(n, H, W, x.device)
     o.rng, o.exp = rng, int(exp)
     with _dev(x):
-        _check(load().deqsci_f32_to_split16(x.data_ptr(), o.t.data_ptr(), n, H, W, _rng(rng), o.exp, _stream()), "f32_to_split16")
+        _check(load().deqsci_f32_to_split16(x.data_ptr(), o.t.data_ptr(), n, H, W, _rng(rng, n), o.exp, _stream()), "f32_to_split16")
     return o
 
 
@@ -699,8 +704,8 @@ def ffdnet_head_split16(x, weights, sigma, out=None, in_rng=None, in_exp=SP16_DE
     wp = weights.packed if weights.packed.device == x.device else weights.packed.to(x.device)
     with _dev(x):
         _check(load().deqsci_ffdnet_head_split16(_p(x, "x"), wp.data_ptr(), sigma.data_ptr(), 0 if sigma.numel() == 1 else sigma.stride(0),
-                                                 o.t.data_ptr(), n, H, W, weights.sw, _rng(in_rng), int(in_exp), _rng(out_rng), o.exp,
-                                                 _rng(track), _stream()), "ffdnet_head_split16")
+                                                 o.t.data_ptr(), n, H, W, weights.sw, _rng(in_rng, n), int(in_exp), _rng(out_rng, n), o.exp,
+                                                 _rng(track, n), _stream()), "ffdnet_head_split16")
     return o
 
 
@@ -714,7 +719,7 @@ def tail_split16(h, weights, out=None):
     wp = weights.packed if weights.packed.device == h.t.device else weights.packed.to(h.t.device)
     fn = load().deqsci_ffdnet_tail_split16 if weights.cout == 4 else load().deqsci_conv3x3_c64_to_1_split16
     with _dev(h.t):
-        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng), h.exp, _stream()), "tail_split16")
+        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng, h.n), h.exp, _stream()), "tail_split16")
     return o
 
 
@@ -735,7 +740,7 @@ def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=Fals
             raise DeqsciHipError("conv3x3_c64_split16: a measuring launch (track=) serves the sp16 output")
         with _dev(x.t):
             _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), None, n, H, W, 1 if relu else 0,
-                                                     weights.sw, _rng(x.rng), x.exp, None, 0, _rng(track), 0, _stream(), None, None),
+                                                     weights.sw, _rng(x.rng, n), x.exp, None, 0, _rng(track, n), 0, _stream(), None, None),
                    "conv3x3_c64_split16 (measuring)")
         return None
     if out_f32:
@@ -748,7 +753,7 @@ def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=Fals
     ev = _hook_events("s16", n, H, W, events) or (None, None)
     with _dev(x.t):
         _check(load().deqsci_conv3x3_c64_split16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), ot.data_ptr(), n, H, W, 1 if relu else 0,
-                                                 weights.sw, _rng(x.rng), x.exp, _rng(out_rng), int(out_exp), None, 1 if out_f32 else 0,
+                                                 weights.sw, _rng(x.rng, n), x.exp, _rng(out_rng, n), int(out_exp), None, 1 if out_f32 else 0,
                                                  _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
     return o
 

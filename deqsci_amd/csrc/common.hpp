@@ -91,9 +91,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---- power-of-two scales of the "sp16" activations (csrc/conv_s16.hip: a tensor stored as the fp16 pieces hi + lo of 2^e x).
-// fp32 is scale-free, fp16 is not, so the exponent e FOLLOWS THE DATA: an activation's range is the pair (amax, exp) - `amax` a device
-// pointer to max |x| of that activation as measured by the kernel that produced it (NULL: the fixed exponent `exp`), from which every
-// kernel that writes or reads the activation derives the same e = SP16_TARGET_EXP - floor(log2(amax)): 2^e max|x| lies in [2^11, 2^12),
+// fp32 is scale-free, fp16 is not, so the exponent e FOLLOWS THE DATA, per image of the batch: an activation's range is the pair (amax, exp)
+// - `amax` a device pointer to one word per image, max |x| of that image of the activation as measured by the kernel that produced it
+// (NULL: the fixed exponent `exp`), from which every kernel that writes or reads the image derives the same
+// e = SP16_TARGET_EXP - floor(log2(amax[image])): 2^e max|x| lies in [2^11, 2^12),
 // a factor 16 below fp16's overflow, and an element keeps all 22 bits of its split down to 2^-14 of the maximum (below that the lo
 // piece goes subnormal: the ABSOLUTE error stays 2^-36 of the maximum).  Powers of two: every scaling is exact.
 constexpr int SP16_DEFAULT_EXP = 8, SP16_TARGET_EXP = 11, SP16_EXP_LIMIT = 64;

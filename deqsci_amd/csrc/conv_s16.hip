@@ -112,8 +112,10 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 
 // OUT_F32 = 0: sp16 output (the next 64->64 layer's input); 1: fp32 channels_last (n, H, W, 64) output (the consumer is not this kernel)
 // TRACK = 1: the range MEASUREMENT - the same arithmetic, but instead of storing y the launch folds max |y| (true units, pixels of the
-// image only) into *track with one atomic per workgroup
-// The ranges (common.hpp): the input holds 2^e_in x, e_in from *in_amax (or in_exp); the sp16 output 2^e_out y, e_out from *out_amax (or out_exp)
+// image only) into track[image] (one atomic per wave and tile)
+// The ranges (common.hpp) are PER IMAGE - in_amax, out_amax, track point to n words, one per image of the batch, so that a measurement's
+// result does not depend on what else is in the batch: image i of the input holds 2^e_in x, e_in from in_amax[i] (or in_exp), of the sp16
+// output 2^e_out y, e_out from out_amax[i] (or out_exp); a tile's scales are formed where its output descriptor is (tile_done)
 template <int OUT_F32, int TRACK>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
                                                           char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
@@ -122,11 +124,6 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
-    __shared__ uint32_t trk_s[WAVES];
-    // acc = 2^(e_in + w_exp) sum w x  ->  2^e_out y; the bias likewise
-    const int e_out = OUT_F32 ? 0 : sp16_resolve_exp(out_amax, out_exp);
-    const float oscale = sp16_pow2(e_out - sp16_resolve_exp(in_amax, in_exp) - w_exp), bscale = sp16_pow2(e_out);
-    uint32_t trk_max = 0;                                      // (TRACK) the wave's running max |stored output| as float bits, wave-uniform
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     int t_first, t_step, t_end;
@@ -228,7 +225,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     f32x16 acc[CH1 + 1][2][2];
     // where the finished tile goes: descriptor of its image, per-lane offsets of rows r (S16_ROWS4: of the lane's COLUMN - the rows of a wave
     // are wave-uniform and go into the stores' scalar offset, an out-of-image row is a uniform branch), first pixel row of the wave
-    struct Done { i32x4 orsrc; uint32_t pix[2]; int oy0; };
+    // ... and the tile's scales: acc = 2^(e_in + w_exp) sum w x  ->  oscale acc + bscale bias = 2^e_out y (e of the tile's image)
+    struct Done { i32x4 orsrc; uint32_t pix[2]; int oy0; float oscale, bscale; int img; };
     const int pl = lane & 31, kb = lane >> 5;
 #if S16_ROWS4
     const int wg = wave & 1, wr4 = 4 * (wave >> 1);             // the wave's cout group and its first pixel row; acc[.][r >> 1][r & 1] is row r
@@ -266,7 +264,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             const f32x2 a0 = {acc[0][ga][ra][i], acc[0][ga][ra][i + 1]}, a1 = TRACK ? (f32x2){0.0f, 0.0f} : (f32x2){acc[CH1][ga][ra][i], acc[CH1][ga][ra][i + 1]};
             const f32x4 b4 = bz4[gb][2 * gp + (e >> 1)];
             const f32x2 bz = (e & 1) ? (f32x2){b4.z, b4.w} : (f32x2){b4.x, b4.y};
-            f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){oscale, oscale}, bz);
+            f32x2 t = __builtin_elementwise_fma(a0 + a1, (f32x2){d.oscale, d.oscale}, bz);
             t.x = __builtin_elementwise_maximum(t.x, floor_);
             t.y = __builtin_elementwise_maximum(t.y, floor_);
             if (TRACK && row_ok && pixv != RAW_OOB) tmax = fmaxf(tmax, fmaxf(__builtin_fabsf(t.x), __builtin_fabsf(t.y)));   // (pixels of the image only)
@@ -323,6 +321,13 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         d.orsrc.y = (int)uniform((uint32_t)(ob >> 32));
         d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
         d.orsrc.w = 0x00020000;
+        {
+            const int e_in = in_amax ? sp16_act_exp(in_amax[n]) : in_exp;                         // (wave-uniform: scalar loads)
+            const int e_out = (OUT_F32 || TRACK) ? 0 : out_amax ? sp16_act_exp(out_amax[n]) : out_exp;   // (the measuring launch: true units)
+            d.oscale = sp16_pow2(e_out - e_in - w_exp);
+            d.bscale = sp16_pow2(e_out);
+            d.img = n;
+        }
 #if S16_ROWS4
         d.oy0 = OUT_ROWS * by + wr4;
         d.pix[0] = d.pix[1] = ox >= W ? RAW_OOB : OUT_F32 ? (uint32_t)(ox * 256 + 16 * kb) : (uint32_t)((kb * (int)HW + ox) * 16);
@@ -474,12 +479,12 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #ifdef S16_PRIO
     if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
 #endif
-    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0};
+    const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0, 0.0f, 0.0f, 0};
     // ---- prologue: bias, chunk 0 of the first tile
 #ifdef S16_STAMP
     if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
 #else
-    if (wave == 0) bias_s[lane] = bias ? bias[lane] * bscale : 0.0f;     // (the sp16 output carries 2^8 y: so does its bias)
+    if (wave == 0) bias_s[lane] = bias ? bias[lane] : 0.0f;     // (scaled per tile: the sp16 output of image i carries 2^e_out(i) y, so does its bias)
 #endif
     fetch_tile_uniform(t_first);
 #if S16_TILE_VOFF
@@ -535,19 +540,19 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 f32x4 bz4[2][4];
 #if S16_ROWS4
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bz4[0][q] = bz4[1][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * wg + 8 * q + 4 * kb);
+                for (int q = 0; q < 4; ++q) bz4[0][q] = bz4[1][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * wg + 8 * q + 4 * kb) * d.bscale;
 #else
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb);
+                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb) * d.bscale;
 #endif
                 float tmax = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) ep_piece(d, k, bz4, tmax);
-                if (TRACK) {                                   // (the measuring launch only: once per tile and wave)
+                if (TRACK) {                                   // (the measuring launch only: one atomic per tile and wave, on the tile's image)
                     const uint32_t tb = sp16_wave_max_bits(tmax);
-                    trk_max = tb > trk_max ? tb : trk_max;
+                    if (lane == 0 && track) atomicMax(reinterpret_cast<unsigned int*>(track) + d.img, tb);
                 }
             }
         };
@@ -562,16 +567,6 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         S16_MARK(3);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (TRACK) {
-        if (lane == 0) trk_s[wave] = trk_max;
-        __syncthreads();
-        if (threadIdx.x == 0 && track) {
-            uint32_t m = trk_s[0];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) m = trk_s[w] > m ? trk_s[w] : m;
-            atomicMax(reinterpret_cast<unsigned int*>(track), __builtin_bit_cast(uint32_t, __builtin_bit_cast(float, m) * sp16_pow2(-e_out)));
-        }
-    }
 #ifdef S16_STAMP
     if (lane == 0)
         for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
@@ -583,9 +578,9 @@ __global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restric
                                                           const float* __restrict__ amax, int exp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // over n * HW * 8
     if (i >= total) return;
-    const float scale = sp16_pow2(sp16_resolve_exp(amax, exp));
     const int blk = (int)(i & 7);
     const int64_t pix = i >> 3, n = pix / HW, p = pix - n * HW;
+    const float scale = sp16_pow2(amax ? sp16_act_exp(amax[n]) : exp);
     const float4 a = ld4s(x + pix * 64 + blk * 8), b = ld4s(x + pix * 64 + blk * 8 + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     h8 hi, lo;
@@ -601,21 +596,24 @@ __global__ __launch_bounds__(256) void f32_to_sp16_kernel(const float* __restric
     *reinterpret_cast<h8*>(base + ((int64_t)(c * 4 + 2 + kb) * HW + p) * 16) = lo;
 }
 
-// max |x| over a tensor folded into *amax (one atomic per workgroup): the range of an activation that no sp16-writing kernel produced
-// (the denoiser's input image; an fp32 activation converted by f32_to_sp16_kernel)
+// max |x| over each image of a batch (n images of `count` contiguous floats; blockIdx.y = image) folded into amax[image] (one atomic per
+// workgroup): the range of an activation that no sp16-writing kernel produced (the denoiser's input image; an fp32 activation converted
+// by f32_to_sp16_kernel)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t count, float* __restrict__ amax) {
     __shared__ uint32_t wmax[4];
     float m = 0.0f;
+    const float* xi = x + (int64_t)blockIdx.y * count;
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    const bool al = ((reinterpret_cast<uintptr_t>(xi) & 15u) == 0);
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += stride) {
-        if (i + 4 <= count) {
-            const float4 v = ld4(x + i);
+        if (al && i + 4 <= count) {
+            const float4 v = ld4(xi + i);
             m = fmaxf(fmaxf(m, fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
         } else {
-            for (int64_t k = i; k < count; ++k) m = fmaxf(m, __builtin_fabsf(x[k]));
+            for (int64_t k = i; k < count && k < i + 4; ++k) m = fmaxf(m, __builtin_fabsf(xi[k]));
         }
     }
-    sp16_track_block_max(m, 1.0f, amax, wmax);
+    sp16_track_block_max(m, 1.0f, amax + blockIdx.y, wmax);
 }
 
 
@@ -633,7 +631,7 @@ template <int COUT>
 __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
                                                        int w_exp, const float* __restrict__ in_amax, int in_exp, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
-    const float oscale = sp16_pow2(-sp16_resolve_exp(in_amax, in_exp) - w_exp);   // acc = 2^(e_in + w_exp) sum w x  ->  true units
+
     __shared__ __attribute__((aligned(16))) float P[TL_PIX * PS + 32 * 36];       // (+ slack: the last pixel block writes 352 rows)
     // Workgroup b runs on XCD b % 8: every XCD takes a contiguous range of tiles (image-major, then rows), so that the two halo rows a
     // tile shares with the tile above and below it are re-read from THAT XCD's L2 while they are hot - with tiles dealt round-robin
@@ -646,6 +644,7 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
     if (t >= n_tiles) return;
     const int n = t / (tiles_x * tiles_y), rt = t - n * (tiles_x * tiles_y), by = rt / tiles_x;
     const int r0 = by * TL_H, c0 = (rt - by * tiles_x) * TL_W;
+    const float oscale = sp16_pow2(-(in_amax ? sp16_act_exp(in_amax[n]) : in_exp) - w_exp);   // acc = 2^(e_in + w_exp) sum w x  ->  true units (the tile's image)
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
     const int64_t HW = (int64_t)H * W;
     const char* xn = x + (int64_t)n * HW * 256;
@@ -757,7 +756,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
     }
     const float sig = sigma[(int64_t)n * sigma_stride];
     // the operand gathered below holds 2^e_in (image | sigma): *in_amax is max |image| (the sigma plane is this kernel's own business)
-    const int e_in = in_amax ? sp16_act_exp(fmaxf(*in_amax, __builtin_fabsf(sig))) : in_exp, e_out = sp16_resolve_exp(out_amax, out_exp);
+    const int e_in = in_amax ? sp16_act_exp(fmaxf(in_amax[n], __builtin_fabsf(sig))) : in_exp, e_out = out_amax ? sp16_act_exp(out_amax[n]) : out_exp;
     const float in_scale = sp16_pow2(e_in), oscale = sp16_pow2(e_out - e_in - w_exp);
     float tmax = 0.0f;
     for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
@@ -864,7 +863,7 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                 asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(ol), "v"(pix), "s"(orsrc), "s"(so_l) : "memory");
             }
     }
-    if (TRACK) sp16_track_block_max(tmax, sp16_pow2(-e_out), track, trk_s);
+    if (TRACK) sp16_track_block_max(tmax, sp16_pow2(-e_out), track + n, trk_s);
 }
 
 }  // namespace s16
@@ -924,13 +923,15 @@ extern "C" int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t 
     return launch_status();
 }
 
-extern "C" int deqsci_absmax_f32(const float* x, int64_t count, float* amax, deqsci_stream_t stream) {
+extern "C" int deqsci_absmax_f32(const float* x, int64_t n, int64_t count, float* amax, deqsci_stream_t stream) {
     if (!x || !amax) return DEQSCI_ERR_NULL;
-    if (count <= 0) return DEQSCI_ERR_SHAPE;
+    if (count <= 0 || n <= 0) return DEQSCI_ERR_SHAPE;
+    if (n > 65535) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x)) return DEQSCI_ERR_ALIGN;
-    const int64_t blocks = ceil_div(count, 256 * 4 * 8);             // eight float4 per lane
-    const int64_t cap = 8 * (int64_t)num_cus();
-    hipLaunchKernelGGL(s16::absmax_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(256), 0, static_cast<hipStream_t>(stream), x, count, amax);
+    int64_t blocks = ceil_div(count, 256 * 4 * 8);                   // eight float4 per lane
+    const int64_t cap = ceil_div(8 * (int64_t)num_cus(), n);
+    blocks = blocks < cap ? blocks : cap;
+    hipLaunchKernelGGL(s16::absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : blocks), (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), x, count, amax);
     return launch_status();
 }
 

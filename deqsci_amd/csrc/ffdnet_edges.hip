@@ -145,10 +145,10 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
                                                            int out_exp, float* __restrict__ track) {
     __shared__ float patch[H1_P * H1_PS];
     __shared__ uint32_t trk_s[TB / WAVE];
-    const float oscale = OUT_SP16 ? sp16_pow2(sp16_resolve_exp(out_amax, out_exp)) : 1.0f;
     float tmax = 0.0f;
     const int n = blockIdx.z;
     const int r0 = blockIdx.y * H1_T, c0 = blockIdx.x * H1_T;
+    const float oscale = OUT_SP16 ? sp16_pow2(out_amax ? sp16_act_exp(out_amax[n]) : out_exp) : 1.0f;     // (the ranges are per image)
     const float* xn = x + (int64_t)n * H * W;
     for (int e = threadIdx.x; e < H1_P * H1_P; e += TB) {
         const int pr = e / H1_P, pc = e % H1_P;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
             } else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
         }
     }
-    if (OUT_SP16 && track) sp16_track_block_max(tmax, 1.0f, track, trk_s);
+    if (OUT_SP16 && track) sp16_track_block_max(tmax, 1.0f, track + n, trk_s);
 }
 
 // ------------------------------------------------------------------------------------------------

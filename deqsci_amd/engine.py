@@ -80,7 +80,7 @@ class _Denoiser:
         if act_range not in ("data", "fixed"):
             raise ValueError(f"act_range={act_range!r}: expected 'data' or 'fixed'")
         self.act_range = act_range
-        self.ranges = None                                          # (len(layers) + 1,) fp32 on the device: slot i = max |input of layer i|
+        self.ranges = None                                          # (len(layers) + 1, images) fp32 on the device: [i, j] = max |input of layer i, image j|
         self._calibrating = False
         self._stale = True                                          # the ranges have not been measured on the current input yet
         # channels_last is what the HIP Winograd / edge kernels consume.  Without them (winograd=False) it is a
@@ -225,14 +225,21 @@ class _Denoiser:
         return h
 
     def _slot(self, i):
-        """Range slot of the input of layer i (= the output of layer i - 1), or None under act_range="fixed"."""
-        return None if self.ranges is None else self.ranges[i:i + 1]
+        """Range slots (one per image) of the input of layer i (= the output of layer i - 1), or None under act_range="fixed"."""
+        return None if self.ranges is None else self.ranges[i]
 
-    def prepare(self, n_calls, device):
+    def _alloc_ranges(self, n_img, device):
+        if self.fast is not None and self.act_range == "data" and (self.ranges is None or self.ranges.device != torch.device(device)
+                                                                    or self.ranges.shape[1] != n_img):
+            # kept across calls of a shape: a captured hipGraph carries this tensor's address in its conv nodes (a new batch size is a
+            # new graph, captured after an eager call)
+            self.ranges = torch.zeros((len(self.fast) + 1, n_img), dtype=torch.float32, device=device)
+            self._stale = True
+
+    def prepare(self, n_calls, device, n_img=None):
         self._refresh()
-        if self.fast is not None and self.act_range == "data" and (self.ranges is None or self.ranges.device != torch.device(device)):
-            # kept across calls: a captured hipGraph carries this tensor's address in its conv nodes
-            self.ranges = torch.zeros(len(self.fast) + 1, dtype=torch.float32, device=device)
+        if n_img is not None:
+            self._alloc_ranges(n_img, device)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
@@ -246,6 +253,8 @@ class _Denoiser:
         bsz, B, H, W = z1.shape
         x = z1.view(bsz * B, 1, H, W)
         self._policy = "f22" if (self.f22_calls is not None and call < self.f22_calls) else self.conv64
+        if x.is_cuda:
+            self._alloc_ranges(bsz * B, x.device)
         if calibrate:
             self._stale = True
         self._calibrating = cal = self._stale and self.ranges is not None and x.is_cuda
@@ -435,9 +444,9 @@ class DEQSCIEngine:
                     self.den._policy = saved[1]
                 fallback = "fast32"
             self.last_info["conv64_fallback"] = fallback
-            # what the first f-call measured: max |activation| in front of every layer of the denoiser's stack (0 where no split-fp16
-            # layer ran); the exponents the kernels derived from them are _hip.act_exp of these
-            self.last_info["act_ranges"] = None if (self.den.ranges is None or fallback) else self.den.ranges.tolist()
+            # what the first f-call measured: max |activation| in front of every layer of the denoiser's stack, here the maximum over the
+            # batch's images (the kernels use one range per image: den.ranges; 0 where no split-fp16 layer ran)
+            self.last_info["act_ranges"] = None if (self.den.ranges is None or fallback) else self.den.ranges.max(dim=1).values.tolist()
             return rec
 
     def _reconstruct(self, y, Phi, Phi_sum, initial_point):
@@ -454,7 +463,7 @@ class DEQSCIEngine:
         if initial_point is not None:
             initial_point = _hip.f32c(initial_point)
         ws = self._workspace(bsz, H, W, B, y.device)
-        self.den.prepare(self.max_iter + 4, y.device)
+        self.den.prepare(self.max_iter + 4, y.device, n_img=bsz * B)
         graph = self.use_graph if self.use_graph != "auto" else bsz * H * W <= self.GRAPH_AUTO_PIXELS
         if self.anderson_arith == "reference":
             graph = False                                      # (torch's batched LU is not a captured node of this engine's graph)

@@ -191,12 +191,13 @@ int deqsci_conv3x3_c64_winograd44_layout_f32(const float* x, const float* u_pack
  *     cin = 16 c + 8 (lane / 32) + j), w_exp the power of two that puts max |w| into [2^13, 2^14).
  *
  *     RANGES.  fp32 (the reference's arithmetic, solvers/equilibrium_solvers_yaping.py:397-420) is scale-free, fp16 is not, so the
- *     exponent e of an sp16 activation follows the data.  Every sp16 activation is described by a pair (amax, exp): `amax` a DEVICE
- *     pointer to max |x| of that activation - then e = DEQSCI_SP16_TARGET_EXP - floor(log2(*amax)), i.e. 2^e max|x| in [2^11, 2^12),
- *     derived identically by the kernel that writes the activation and the kernel that reads it - or NULL: the fixed exponent `exp`
- *     (DEQSCI_SP16_DEFAULT_EXP = 8 suits activations of a few units).  `track_amax` (may be NULL): a MEASURING launch - the same arithmetic,
- *     but max |y| of the output is folded into *track_amax (zero it first) and, for the 64->64 layer, y itself is not written: run a
- *     layer once with track_amax = the slot of its output, then again with out_amax = that slot.  Nothing crosses to the host: a captured hipGraph follows
+ *     exponent e of an sp16 activation follows the data - PER IMAGE of the batch, so that one measurement's result never depends on what
+ *     else is in the batch.  Every sp16 activation is described by a pair (amax, exp): `amax` a DEVICE pointer to n floats, amax[i] =
+ *     max |x| of image i of that activation - then e(i) = DEQSCI_SP16_TARGET_EXP - floor(log2(amax[i])), i.e. 2^e max|x| in
+ *     [2^11, 2^12), derived identically by the kernel that writes the activation and the kernel that reads it - or NULL: the fixed
+ *     exponent `exp` for every image (DEQSCI_SP16_DEFAULT_EXP = 8 suits activations of a few units).  `track_amax` (may be NULL): a MEASURING launch - the same arithmetic,
+ *     but max |y| of image i of the output is folded into track_amax[i] (n floats; zero them first) and, for the 64->64 layer, y itself
+ *     is not written: run a layer once with track_amax = the slots of its output, then again with out_amax = those slots.  Nothing crosses to the host: a captured hipGraph follows
  *     its inputs.  An activation that outgrows fp16 (16 x the measured maximum) becomes inf, never a silently wrong finite number.
  *
  *     Output = relu?(conv + bias): out_f32 = 0 -> sp16 with the range (out_amax, out_exp); out_f32 = 1 -> fp32 channels_last
@@ -207,11 +208,12 @@ int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const f
                                int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
                                const float* out_amax, int out_exp, float* track_amax, int out_f32,
                                deqsci_stream_t stream, void* start_event, void* stop_event);
-/* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and max |x| over `count` floats folded into *amax (zero it first):
- *     the range of an activation no sp16-writing kernel produced (the denoiser's input image; a converted fp32 activation). */
+/* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and, for x = n images of `count` contiguous floats each, max |x| of
+ *     image i folded into amax[i] (zero them first): the range of an activation no sp16-writing kernel produced (the denoiser's input
+ *     image; a converted fp32 activation). */
 int deqsci_f32_to_split16(const float* x_nhwc, void* y_sp16, int64_t n, int64_t H, int64_t W, const float* amax, int exp,
                           deqsci_stream_t stream);
-int deqsci_absmax_f32(const float* x, int64_t count, float* amax, deqsci_stream_t stream);
+int deqsci_absmax_f32(const float* x, int64_t n, int64_t count, float* amax, deqsci_stream_t stream);
 /* SimpleCNN's first layer (conv3x3 1 -> 64 [+ ReLU], deqsci_conv3x3_c1_to_64_f32) writing sp16 with the range (out_amax, out_exp)
  *     instead of fp32 channels_last - no conversion pass in front of a run of split16 layers. */
 int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W, int relu,
@@ -224,8 +226,8 @@ int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_packed, float* 
 int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W,
                                     int w_exp, const float* in_amax, int in_exp, deqsci_stream_t stream);
 /* FFDNet's first layer (sigma map + pixel-unshuffle + conv3x3 5 -> 64 + ReLU) likewise, writing sp16: K = 45 taps padded to 48, the
- *     activation operand gathered from the image and split on the fly at 2^e_in, e_in from max(*in_amax, sigma) (in_amax = max |x| of
- *     the image; NULL: in_exp).  w_packed: 2^w_exp w as [3 k steps][2 pieces][2 cout groups][64 lanes][8 halfs], k = 9 ch + tap. */
+ *     activation operand gathered from the image and split on the fly at 2^e_in, e_in(i) from max(in_amax[i], sigma(i)) (in_amax[i] =
+ *     max |x| of image i; NULL: in_exp).  w_packed: 2^w_exp w as [3 k steps][2 pieces][2 cout groups][64 lanes][8 halfs], k = 9 ch + tap. */
 int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
                                int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp,
                                const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);

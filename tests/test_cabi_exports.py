@@ -85,7 +85,8 @@ def test_scratch_size_queries_and_error_strings():
     assert s16(p16, p16, q16, ev1=p16) == -1                                                   # one event only
     assert lib.deqsci_f32_to_split16(None, q16, 1, 4, 4, None, 8, None) == -1 and lib.deqsci_f32_to_split16(p16, q16, 1, 0, 4, None, 8, None) == -2
     assert lib.deqsci_f32_to_split16(p16, q16, 1, 4, 4, None, 99, None) == -4
-    assert lib.deqsci_absmax_f32(None, 4, p16, None) == -1 and lib.deqsci_absmax_f32(p16, 0, p16, None) == -2 and lib.deqsci_absmax_f32(p16 + 4, 4, p16, None) == -3
+    assert lib.deqsci_absmax_f32(None, 1, 4, p16, None) == -1 and lib.deqsci_absmax_f32(p16, 1, 0, p16, None) == -2 and lib.deqsci_absmax_f32(p16 + 4, 1, 4, p16, None) == -3
+    assert lib.deqsci_absmax_f32(p16, 0, 4, p16, None) == -2 and lib.deqsci_absmax_f32(p16, 70000, 4, p16, None) == -4
     assert lib.deqsci_ffdnet_tail_split16(None, p16, q16, 1, 4, 4, 0, None, 8, None) == -1 and lib.deqsci_ffdnet_tail_split16(p16, p16, q16, 1, 4, -4, 0, None, 8, None) == -2
     assert lib.deqsci_conv3x3_c64_to_1_split16(p16 + 4, p16, q16, 1, 4, 4, 0, None, 8, None) == -3
     assert lib.deqsci_ffdnet_head_split16(None, p16, p16, 0, q16, 1, 4, 4, 0, None, 8, None, 8, None, None) == -1
