@@ -30,6 +30,7 @@ SIGNATURES = {
     "deqsci_residual_out_f32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr],
     "deqsci_residual_store_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
     "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_anderson_solve_gram_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr, _ptr],
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                     _i64, _i64, _i64, _i64, _int, _int, _ptr],
@@ -264,11 +265,14 @@ def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
                                                 n_filled, _stream()), "residual_store")
 
 
-def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0):
+def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None):
+    """gram32: (bsz, n, n) fp32 - alpha from THAT Gram block with an fp32 LU (the reference's arithmetic, :177-180) instead of the float64 sums."""
+    if gram32 is not None and (tuple(gram32.shape) != (ws.bsz, n, n) or gram32.dtype != torch.float32 or not gram32.is_contiguous() or not gram32.is_cuda):
+        raise DeqsciHipError(f"anderson_solve: gram32 must be a contiguous fp32 GPU tensor of shape {(ws.bsz, n, n)}")
     with _dev(ws.F):
-        _check(load().deqsci_anderson_solve_f32(_p(ws.partials), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
-                                                ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()),
-               "anderson_solve")
+        _check(load().deqsci_anderson_solve_gram_f32(_p(ws.partials), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
+                                                     ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps),
+                                                     None if gram32 is None else gram32.data_ptr(), _stream()), "anderson_solve")
 
 
 def anderson_mix(ws, x_out, beta, n):

@@ -189,7 +189,8 @@ __device__ __forceinline__ void bordered_solve(const double* Gl, double (*M)[MAX
 
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
-                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32
+                                                              int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32,
+                                                              const float* __restrict__ gram32
 #ifdef DEQSCI_DIAG
                                                               , float gram_noise
 #endif
@@ -243,7 +244,15 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
         res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
     }
     if (n > 0) {
-        if (solve_f32) bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
+        if (gram32) {
+            // the REFERENCE's arithmetic for alpha (new_equilibrium_utils_yaping.py:177-180): the n x n Gram block as the caller's fp32
+            // torch.bmm produced it (rows in slot order), the system formed and factorised in fp32 like torch.solve = sgesv.  The residual
+            // above and the persistent float64 Gram keep their own, exact, sums.
+            __syncthreads();
+            for (int i = lane; i < n * n; i += WAVE) Gl[(i / n) * MAXM + (i % n)] = (double)gram32[(int64_t)s * n * n + i];
+            __syncthreads();
+            bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
+        } else if (solve_f32) bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
         else bordered_solve<double>(Gl, M, alpha, s, lane, n, lam);
     }
     if (lane != 0) return;
@@ -445,19 +454,28 @@ int deqsci_residual_store_f32(const float* z1, const float* noise, const float* 
     return launch_status();
 }
 
+int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                                   int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream);
+
 int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
                               int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    return deqsci_anderson_solve_gram_f32(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, nullptr, stream);
+}
+
+int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                                   int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream) {
     if (!partials || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
+    if (gram32 && n <= 0) return DEQSCI_ERR_SHAPE;
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
 #ifdef DEQSCI_DIAG
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
 #else
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0);
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32);
 #endif
     return launch_status();
 }

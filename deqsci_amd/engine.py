@@ -340,7 +340,8 @@ class DEQSCIEngine:
         # How alpha is computed.  "float64" (default): the Gram row accumulated in float64 from the fp32 block partials of K4, the bordered
         # system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference": the reference's own arithmetic for that step,
         # solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over the N = H W B elements (rocBLAS here, MKL there:
-        # ~5e-6 relative on an entry at N = 2^19), the system solved by fp32 LU (torch.linalg.solve_ex) - eager launches only.  It exists
+        # ~5e-6 relative on an entry at N = 2^19), the system formed and factorised in fp32 by K6 as sgesv does (the GEMM is capturable: the hipGraph path stays; it costs rocBLAS's
+        # ~200 us for this 5 x 2^19 x 5 shape per iteration, +50 % at one measurement per call).  It exists
         # because that rounding error is not neutral on BASELINE config 2: it is what puts the reference's 180-iteration ensemble mean
         # 0.02 dB above the exact-Gram result ("Config 2"; tools/config2_anderson_arith.py).
         self.anderson_arith = anderson_arith
@@ -400,18 +401,11 @@ class DEQSCIEngine:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
         else:
             _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
-        ref = self.anderson_arith == "reference" and n_solve > 0
-        _hip.anderson_solve(ws, slot, n_filled, 0 if ref else n_solve, self.lam, eps, res_row)      # (n = 0: residual only)
-        if ref:
-            n = n_solve
-            G = ws.G[:, :n]                                                                     # rows in the reference's slot order k % m
-            H = torch.zeros((ws.bsz, n + 1, n + 1), dtype=torch.float32, device=G.device)
-            H[:, 0, 1:] = 1
-            H[:, 1:, 0] = 1
-            H[:, 1:, 1:] = torch.bmm(G, G.transpose(1, 2)) + self.lam * torch.eye(n, dtype=torch.float32, device=G.device)[None]      # :178
-            rhs = torch.zeros((ws.bsz, n + 1, 1), dtype=torch.float32, device=G.device)
-            rhs[:, 0] = 1
-            ws.alpha[:, :n] = torch.linalg.solve_ex(H, rhs, check_errors=False)[0][:, 1:, 0]       # :180
+        gram32 = None
+        if self.anderson_arith == "reference" and n_solve > 0:
+            G = ws.G[:, :n_solve]                                                               # rows in the reference's slot order k % m
+            gram32 = torch.bmm(G, G.transpose(1, 2))                                            # :178, ONE fp32 GEMM over N elements (rocBLAS)
+        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, gram32=gram32)    # (+ lam I and the fp32 LU of :178-180 in K6)
 
     def _poll(self, ws, row):
         ws.host_res[row].copy_(ws.res[row], non_blocking=True)
@@ -465,8 +459,6 @@ class DEQSCIEngine:
         ws = self._workspace(bsz, H, W, B, y.device)
         self.den.prepare(self.max_iter + 4, y.device, n_img=bsz * B)
         graph = self.use_graph if self.use_graph != "auto" else bsz * H * W <= self.GRAPH_AUTO_PIXELS
-        if self.anderson_arith == "reference":
-            graph = False                                      # (torch's batched LU is not a captured node of this engine's graph)
         if graph:
             rec = self._replay(ws, y, Phi4, Phi_sum, initial_point)
             if rec is not None:

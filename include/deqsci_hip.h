@@ -110,6 +110,15 @@ int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, f
                               int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                               float lam, float eps, deqsci_stream_t stream);
 
+/* The same with the REFERENCE's arithmetic for alpha: gram32 = the n x n block G G^T of the first n history rows as the caller's fp32
+ *     GEMM produced it ((bsz, n, n) row-major, rows in slot order: torch.bmm(G[:, :n], G[:, :n]^T), :178), the bordered system formed
+ *     and factorised in fp32 (torch.solve = sgesv, :180).  The relative residual still comes from the exact sums.  gram32 NULL = the
+ *     entry point above.  Why it exists: DESIGN.md section 5, "Config 2" - the ~5e-6 rounding error of that GEMM at N = 2^19 is worth
+ *     +0.02 dB on the reference's 180-iteration FFDNet ensemble. */
+int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res,
+                                   int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
+                                   float lam, float eps, const float* gram32, deqsci_stream_t stream);
+
 /* K7  x_out = beta * sum_i alpha_i F_i + (1-beta) * sum_i alpha_i X_i,  X_i = F_i - G_i   (:182) */
 int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha,
                             float* x_out, float beta, int n, int64_t bsz, int64_t N, int m,

@@ -1448,7 +1448,6 @@ def test_config2_with_the_references_anderson_arithmetic():
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
     eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, anderson_arith="reference")
     report, _, _ = _config2_ensembles(eng, chaotic_only=True)
-    assert eng.last_info["graph"] is False
     chaotic = [(ps, ra, rb) for _, ps, _, ra, rb, _ in report]
     (mb, sb), (ma_, sa) = _pooled(chaotic, 0), _pooled(chaotic, 1)
     for (mid, ps, *_), (_, ra, _) in zip(report, chaotic):
