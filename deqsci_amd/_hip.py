@@ -47,6 +47,8 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_split16_stack_fits": [_i64, _i64, _i64],
+    "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -760,6 +762,79 @@ def conv3x3_c64_split16(x, weights, bias=None, relu=True, out=None, out_f32=Fals
                                                  weights.sw, _rng(x.rng, n), x.exp, _rng(out_rng, n), int(out_exp), None, 1 if out_f32 else 0,
                                                  _stream(), ev[0], ev[1]), "conv3x3_c64_split16")
     return o
+
+
+class Split16Stack:
+    """A RUN of 64->64 layers for deqsci_conv3x3_c64_split16_stack: the device table of (weights, bias, w_exp, relu) per layer - three
+    8-byte words each - the tensors it points to (kept alive here), and per launch shape the progress words of the tiles (zeroed once:
+    they count on from launch to launch) and the two ping-pong buffers (kept: a captured hipGraph carries their addresses)."""
+    __slots__ = ("table", "n_layers", "keep", "_state")
+
+    def __init__(self, layers, device):
+        """layers: [(Split16Weights, bias tensor or None, relu), ...]"""
+        rows, keep = [], []
+        for w16, bias, relu in layers:
+            if not isinstance(w16, Split16Weights):
+                raise DeqsciHipError("Split16Stack: every layer needs Split16Weights")
+            wp = w16.packed if w16.packed.device == torch.device(device) else w16.packed.to(device)
+            b = None if bias is None else f32c(bias.detach().to(device))
+            if b is not None and b.numel() < 64:
+                raise DeqsciHipError("Split16Stack: bias must have 64 elements")
+            keep += [wp, b]
+            rows += [wp.data_ptr(), 0 if b is None else b.data_ptr(), (int(w16.sw) & 0xffffffff) | ((1 if relu else 0) << 32)]
+        self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+        self.n_layers, self.keep, self._state = len(layers), keep, {}
+
+    def state(self, n, H, W):
+        """(flags, (Sp16, Sp16)) of the launch shape: 32 (n_tiles + 1) zeroed words (a 128-byte line per tile + the time-out word), two
+        output buffers."""
+        st = self._state.get((n, H, W))
+        if st is None:
+            n_tiles = n * (-(-H // 16)) * (-(-W // 32))
+            dev = self.table.device
+            st = self._state[(n, H, W)] = (torch.zeros(32 * (n_tiles + 1), dtype=torch.int32, device=dev), (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev)))
+        return st
+
+    def timed_out(self):
+        """(host sync) True if a wait of any launch since the last call timed out - the outputs since then are invalid; the words are
+        rearmed."""
+        bad = False
+        for flags, _ in self._state.values():
+            if int(flags[-32]) != 0:
+                flags.zero_()
+                bad = True
+        return bad
+
+
+def split16_stack_fits(n, H, W):
+    """Whether a launch of n images of H x W is at most one block tile per CU - what deqsci_conv3x3_c64_split16_stack takes."""
+    return bool(load().deqsci_conv3x3_c64_split16_stack_fits(n, H, W))
+
+
+def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None):
+    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack) in ONE launch (csrc/conv_s16.hip, STACK: workgroup = tile, a layer of a
+    tile waits for the layer before of its eight neighbours); ranges: the (n_layers + 1, n) range slots of the run - its input's first -
+    or None (fixed exponents: the input's, then 2^8).  Returns the Sp16 the last layer wrote (one of the stack's two buffers of this
+    shape).  stack.timed_out() afterwards tells whether a wait gave up (foreign work on the device's CUs): the result is invalid then."""
+    if not isinstance(x, Sp16) or not isinstance(stack, Split16Stack) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
+        raise DeqsciHipError("conv3x3_c64_split16_stack: a contiguous Sp16 GPU activation and a Split16Stack are required")
+    n, H, W = x.n, x.H, x.W
+    if x.t.device != stack.table.device:
+        raise DeqsciHipError("conv3x3_c64_split16_stack: the stack was built for another device")
+    if ranges is not None and (not isinstance(ranges, torch.Tensor) or ranges.dtype != torch.float32 or tuple(ranges.shape) != (stack.n_layers + 1, n)
+                               or not ranges.is_contiguous() or ranges.device != x.t.device):
+        raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, {n}) tensor on the input's device")
+    if (ranges is None) != (x.rng is None):
+        raise DeqsciHipError("conv3x3_c64_split16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
+    flags, bufs = stack.state(n, H, W)
+    ev = events or (None, None)
+    with _dev(x.t):
+        _check(load().deqsci_conv3x3_c64_split16_stack(x.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), stack.table.data_ptr(), stack.n_layers,
+                                                       n, H, W, None if ranges is None else ranges.data_ptr(), x.exp, SP16_DEFAULT_EXP,
+                                                       flags.data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_split16_stack")
+    out = bufs[(stack.n_layers - 1) % 2]
+    out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers]), SP16_DEFAULT_EXP
+    return out
 
 
 class Conv64Weights:

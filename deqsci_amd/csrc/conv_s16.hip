@@ -116,11 +116,31 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // The ranges (common.hpp) are PER IMAGE - in_amax, out_amax, track point to n words, one per image of the batch, so that a measurement's
 // result does not depend on what else is in the batch: image i of the input holds 2^e_in x, e_in from in_amax[i] (or in_exp), of the sp16
 // output 2^e_out y, e_out from out_amax[i] (or out_exp); a tile's scales are formed where its output descriptor is (tile_done)
-template <int OUT_F32, int TRACK>
+//
+// STACK = 1: a RUN of n_layers 64->64 layers in ONE launch, for launches of at most ONE block tile per CU (the reference's usage: one
+// measurement per call, 8 x 128 x 128 = 256 tiles) - where a layer is a single tile per workgroup, nothing overlaps a launch's dispatch,
+// its first fetch and its last stores, and a kernel boundary per layer costs a fifth of the layer.  Workgroup = tile, for all the layers;
+// DATAFLOW synchronisation, no grid-wide barrier: a tile of layer l + 1 needs layer l of its EIGHT NEIGHBOURS and nothing else, so every
+// tile has a progress word (flags[32 tile] = layers finished - a 128-byte line per tile -, counted on from launch to launch: never reset) which its workgroup writes once
+// its stores have been acknowledged and its neighbours poll.  Coherence without cache maintenance: the activations are stored
+// write-through and fetched with agent-scope loads (sc1 - the tiles of one image may sit on different XCDs, whose L2s do not snoop each other),
+// the words are agent-scope atomics.  Layer l reads x (l = 0) or the buffer layer l - 1 wrote and writes y (l even) / y2 (l odd); its
+// weights, bias, w_exp, relu come from `layers`, its ranges from in_amax[l][image] -> in_amax[l + 1][image] (in_amax = the run's slot
+// table, or NULL: in_exp for the run's input, out_exp for every output).  flags[32 n_tiles] != 0: a wait timed out (a workgroup of the
+// launch was not resident) - the launch never hangs, the result is invalid and says so.
+struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
+constexpr unsigned STACK_SPIN_LIMIT = 1u << 21;                // polls, one every ~0.1 us: a wait gives up after a quarter of a second
+#ifndef S16_STACK_POLLS
+#define S16_STACK_POLLS 8
+#endif
+constexpr int STACK_POLLS = S16_STACK_POLLS;                   // polls of the neighbours' words in flight
+constexpr int STACK_FLAG_STRIDE = 32;                          // words between two tiles' progress words: a 128-byte line each (256 pollers would queue on eight lines)
+template <int OUT_F32, int TRACK, int STACK>
 __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ bias,
                                                           char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
                                                           const float* __restrict__ out_amax, int out_exp, float* __restrict__ track, int tiles_x, int tiles_y,
-                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx) {
+                                                          int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx,
+                                                          char* __restrict__ y2, const StackLayer* __restrict__ layers, int n_layers, unsigned* flags) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
@@ -188,19 +208,28 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #else
         const uint32_t voj = fetch_lane_offset(j);             // (a dozen vector instructions, in the shadow of the group's MFMAs)
 #endif
-        if (j == 0 || j == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:1024" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
-        else if (j == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:2048" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
-        else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:3072" S16_NT " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0");
+#define S16_RAW_LOAD(OFFS, MOD) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen" OFFS MOD " lds" ::"s"(m0v), "v"(voj), "s"(rsrc), "s"(soff) : "m0")
+        if (STACK) {                                           // agent-scope loads: what another XCD's workgroup wrote through a moment ago
+            if (j == 0 || j == 4) S16_RAW_LOAD("", " sc1");
+            else if (j == 1) S16_RAW_LOAD(" offset:1024", " sc1");
+            else if (j == 2) S16_RAW_LOAD(" offset:2048", " sc1");
+            else S16_RAW_LOAD(" offset:3072", " sc1");
+        } else {
+            if (j == 0 || j == 4) S16_RAW_LOAD("", S16_NT);
+            else if (j == 1) S16_RAW_LOAD(" offset:1024", S16_NT);
+            else if (j == 2) S16_RAW_LOAD(" offset:2048", S16_NT);
+            else S16_RAW_LOAD(" offset:3072", S16_NT);
+        }
+#undef S16_RAW_LOAD
     };
     // ---- weight chunk: 36 pieces of 1 KiB, host-packed in LDS order; wave w moves the five pieces from 9 w / 2 on
-    auto w_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
+    auto w_piece = [&](const char* Wl, int c, int buf, int j) __attribute__((always_inline)) {
         int w_ = wave;
         asm volatile("" : "+s"(w_));
         const int first = (9 * w_) >> 1;                       // (odd waves own four pieces: their fifth is the next wave's first, fetched twice -
                                                                // the same bytes to the same place - rather than branched around)
         const uint32_t off = (uint32_t)((first + j) * 1024);
-        const uint64_t g = (uint64_t)(Wp + (int64_t)c * W_CHUNK) + off;
+        const uint64_t g = (uint64_t)(Wl + (int64_t)c * W_CHUNK) + off;
         const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_CHUNK) + off);
         const uint64_t gs = ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
         const uint32_t lv = (uint32_t)lane * 16u;
@@ -208,10 +237,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     };
 
 #ifdef S16_STAMP   // profiling build (tools/s16_stamps.py): cycles per phase, summed over the launch, written over the bias array: [workgroup][wave][5]
-    uint32_t st_sum[5] = {0, 0, 0, 0, 0};
+    uint32_t st_sum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};         // (STACK: + store drain, barrier, publish + wait for the neighbours, first fetch of the next layer)
     uint64_t st_t = __builtin_readcyclecounter();
 #define S16_MARK(i) do { const uint64_t now_ = __builtin_readcyclecounter(); st_sum[i] += (uint32_t)(now_ - st_t); st_t = now_; } while (0)
-    uint32_t* st_out = reinterpret_cast<uint32_t*>(const_cast<float*>(bias));
+    uint32_t* st_out = reinterpret_cast<uint32_t*>(const_cast<float*>(STACK ? layers[0].bias : bias));
 #else
 #define S16_MARK(i) do { } while (0)
 #endif
@@ -307,10 +336,16 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             const u32x4 oh = {hi[0], hi[1], hi[2], hi[3]}, ol = {lo[0], lo[1], lo[2], lo[3]};
             const uint32_t so_h = uniform((uint32_t)((2 * g + gp) * 4 + 0) * (uint32_t)HW * 16u + rowoff);
             const uint32_t so_l = uniform((uint32_t)((2 * g + gp) * 4 + 2) * (uint32_t)HW * 16u + rowoff);
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(pixv), "s"(d.orsrc), "s"(so_h) : "memory");
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(pixv), "s"(d.orsrc), "s"(so_l) : "memory");
+            if (STACK) {                                       // write-through (agent scope): the neighbours' next layer reads it from another CU, maybe another XCD
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(oh), "v"(pixv), "s"(d.orsrc), "s"(so_h) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen sc1\n\ts_nop 1" ::"v"(ol), "v"(pixv), "s"(d.orsrc), "s"(so_l) : "memory");
+            } else {
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(oh), "v"(pixv), "s"(d.orsrc), "s"(so_h) : "memory");
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" S16_ST "\n\ts_nop 1" ::"v"(ol), "v"(pixv), "s"(d.orsrc), "s"(so_l) : "memory");
+            }
         }
     };
+    int se_in = 0, se_out = 0;                                 // (STACK) the exponents of the tile's image: input and output of the current layer
     auto tile_done = [&](int t) -> Done {
         Done d;
         const int n = mdiv(t, mg_img, sh_img), rr_ = t - n * (tiles_x * tiles_y);
@@ -322,8 +357,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
         d.orsrc.w = 0x00020000;
         {
-            const int e_in = in_amax ? sp16_act_exp(in_amax[n]) : in_exp;                         // (wave-uniform: scalar loads)
-            const int e_out = (OUT_F32 || TRACK) ? 0 : out_amax ? sp16_act_exp(out_amax[n]) : out_exp;   // (the measuring launch: true units)
+            // (wave-uniform: scalar loads; the measuring launch: true units; STACK: one tile, its exponents are formed between the layers)
+            const int e_in = STACK ? se_in : in_amax ? sp16_act_exp(in_amax[n]) : in_exp;
+            const int e_out = STACK ? se_out : (OUT_F32 || TRACK) ? 0 : out_amax ? sp16_act_exp(out_amax[n]) : out_exp;
             d.oscale = sp16_pow2(e_out - e_in - w_exp);
             d.bscale = sp16_pow2(e_out);
             d.img = n;
@@ -343,6 +379,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         return d;
     };
 
+    const char* Wnx = nullptr;                                 // (STACK) the next layer's weights
     // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
     // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
     // `before_barrier` runs between the stage's last MFMA and its barrier, `shadow(i)` inside group i behind four of its MFMAs.
@@ -369,7 +406,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         };
         auto dma = [&](int j) __attribute__((always_inline)) {    // the next chunk: 10 DMA instructions, two per group in the first five groups
             if (more && j < 2 * RAW_INSTR && !(S16_ABL & 1)) {
-                if (j < RAW_INSTR) raw_piece(cn, nb, j); else w_piece(cn, nb, j - RAW_INSTR);
+                // (STACK, last stage: the next chunk is chunk 0 of the NEXT LAYER - its weights can come now, its activations only once the
+                // neighbours have written them)
+                if (j < RAW_INSTR) { if (!(STACK && c == 3)) raw_piece(cn, nb, j); }
+                else w_piece((STACK && c == 3) ? Wnx : Wp, cn, nb, j - RAW_INSTR);
             }
         };
         S16_MARK(4);
@@ -453,7 +493,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #endif
             if (more && i < 2 * RAW_INSTR && !(S16_ABL & 1)) {   // the next chunk: 10 DMA instructions, one per group in the FIRST half of the
                                                                // stage - the last one needs the second half (an HBM round trip) to land
-                if (i < RAW_INSTR) raw_piece(cn, nb, i); else w_piece(cn, nb, i - RAW_INSTR);
+                if (i < RAW_INSTR) { if (!(STACK && c == 3)) raw_piece(cn, nb, i); }
+                else w_piece((STACK && c == 3) ? Wnx : Wp, cn, nb, i - RAW_INSTR);
             }
             shadow(i);                                         // (tile bookkeeping rides here, behind four of the group's MFMAs)
 #if S16_INTERLEAVE
@@ -480,6 +521,20 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     if (wave >= 4) asm volatile("s_setprio 1");               // (A/B: static priority for the second-dispatched half of the workgroup)
 #endif
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0, 0.0f, 0.0f, 0};
+    char* const y_even = y;
+    const float* const ranges = in_amax;                        // (STACK) the run's slot table [layer][image]
+    int n_img = 0;
+    unsigned fbase = 0, fgiveup = 0;
+    if (STACK) {
+        const StackLayer l0 = layers[0];                       // (wave-uniform: scalar loads)
+        Wp = l0.w; bias = l0.bias; w_exp = l0.w_exp; relu = l0.relu;
+        n_img = mdiv(n_tiles, mg_img, sh_img);
+        const int img0 = mdiv(t_first, mg_img, sh_img);
+        se_in = ranges ? sp16_act_exp(ranges[img0]) : in_exp;
+        se_out = ranges ? sp16_act_exp(ranges[n_img + img0]) : out_exp;
+        fbase = __hip_atomic_load(flags + (int64_t)t_first * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // where the launch before left the tile's word
+        fgiveup = __hip_atomic_load(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // an earlier time-out: no more waiting
+    }
     // ---- prologue: bias, chunk 0 of the first tile
 #ifdef S16_STAMP
     if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
@@ -492,7 +547,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     for (int j = 0; j < RAW_INSTR; ++j) voff[j] = fetch_lane_offset(j);
 #endif
 #pragma unroll
-    for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(0, 0, j); }
+    for (int j = 0; j < RAW_INSTR; ++j) { raw_piece(0, 0, j); w_piece(Wp, 0, 0, j); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // (A "loader + 4" form - four compute waves, one per SIMD, each 4 pixel rows x 64 couts, and a fifth wave issuing all 76 DMA
@@ -505,6 +560,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
     // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
     S16_MARK(4);
+#pragma unroll 1
+    for (int L = 0; L < (STACK ? n_layers : 1); ++L) {
+    const bool more_layers = STACK && L + 1 < n_layers;
+    if (more_layers) Wnx = layers[L + 1].w;
 #pragma unroll 1
     for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
 #if !(S16_ZEROC && S16_ROWS4)
@@ -522,6 +581,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         // that use this tile's - sit in groups 0..9; the per-lane offsets are formed where each DMA instruction is issued).  Between the
         // tiles this arithmetic cost every wave 1.5 us with the matrix pipe idle
         stage(2, true, nothing, [&](int i) __attribute__((always_inline)) {
+            if (STACK) return;                                 // (the same tile again, of another buffer: set up behind the wait for the neighbours)
             if (i == 10) fetch_tile_uniform(t_cur + t_step);
 #if S16_TILE_VOFF
             if (i >= 11 && i < 11 + RAW_INSTR) voff[i - 11] = fetch_lane_offset(i - 11);     // (this tile's last raw pieces went out in groups 0..4)
@@ -557,19 +617,89 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             }
         };
 #if S16_EPI_LOCKSTEP
-        stage(3, next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
+        stage(3, STACK ? more_layers : next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
         epilogue();
 #else
-        stage(3, next, [&]() __attribute__((always_inline)) { if (wave < 4) epilogue(); },
+        stage(3, STACK ? more_layers : next, [&]() __attribute__((always_inline)) { if (wave < 4) epilogue(); },
               [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
         if (wave >= 4) epilogue();
 #endif
         S16_MARK(3);
     }
+    if (more_layers) {
+        // ---- between two layers of a STACK launch.  Every wave waits for its stores (write-through: acknowledged = visible to the device);
+        // behind the barrier one lane publishes the tile's progress and eight lanes wait for the neighbours', while the other waves
+        // switch to the next layer's parameters; then chunk 0 of the same tile of the buffer just written.
+        const StackLayer ln = layers[L + 1];                   // (scalar loads, under the wait for the stores)
+        const float nx_amax = ranges ? ranges[(int64_t)(L + 2) * n_img + mdiv(t_first, mg_img, sh_img)] : 0.0f;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        S16_MARK(5);
+        __syncthreads();
+        S16_MARK(6);
+        const unsigned target = fbase + (unsigned)(L + 1);
+        if (wave == 2 && lane == 0) __hip_atomic_store(flags + (int64_t)t_first * STACK_FLAG_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = y;
+        y = ((L + 1) & 1) ? y2 : y_even;
+        Wp = ln.w; bias = ln.bias; w_exp = ln.w_exp; relu = ln.relu;
+        se_in = se_out;
+        se_out = ranges ? sp16_act_exp(nx_amax) : out_exp;
+#ifndef S16_STAMP
+        if (wave == 1) bias_s[lane] = bias ? bias[lane] : 0.0f;
+#endif
+        fetch_tile_uniform(t_first);
+        if (wave == 0) {
+            const int tpi = tiles_x * tiles_y;
+            const int n = mdiv(t_first, mg_img, sh_img), r = t_first - n * tpi, by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+            const int k = lane < 4 ? lane : lane + 1;          // lanes 0..7: the 3 x 3 neighbourhood without its centre
+            const int ny = by + k / 3 - 1, nx = bx + k % 3 - 1;
+            const bool valid = lane < 8 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x;
+            const unsigned* f = flags + (int64_t)(valid ? n * tpi + ny * tiles_x + nx : t_first) * STACK_FLAG_STRIDE;
+            // The neighbours finish within a fraction of a microsecond of this tile, and a poll is a round trip to memory (~1 us under the
+            // layer's store burst): one poll at a time almost always needs two.  So STACK_POLLS polls are kept in flight, one every ~200
+            // cycles, and the last neighbour's word is seen half a round trip after it lands.  Loads return in order: with STACK_POLLS
+            // outstanding - this wave has no other memory operation in flight; the tile's own word is published by wave 1 - the oldest
+            // has landed once vmcnt <= STACK_POLLS - 1.
+            if (!fgiveup) {
+                unsigned v[STACK_POLLS], spins = 0;
+#pragma unroll
+                for (int q = 0; q < STACK_POLLS; ++q) {
+                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
+                    __builtin_amdgcn_s_sleep(3);
+                }
+                bool waiting = true;
+                while (waiting) {
+#pragma unroll
+                    for (int q = 0; q < STACK_POLLS; ++q) {
+                        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[q]) : "n"(STACK_POLLS - 1) : "memory");
+                        if (__builtin_amdgcn_ballot_w64(valid && (int)(v[q] - target) < 0) == 0) { waiting = false; break; }   // (wrap-safe: the words count on for ever)
+                        if (++spins > STACK_SPIN_LIMIT) {
+                            fgiveup = 1;
+                            if (lane == 0) __hip_atomic_fetch_or(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            waiting = false;
+                            break;
+                        }
+                        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
+                        __builtin_amdgcn_s_sleep(3);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the polls still in flight write registers)
+            }
+        }
+        __syncthreads();
+        S16_MARK(7);
+#pragma unroll
+        for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        S16_MARK(8);
+    }
+    }                                                          // (layers)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (STACK && threadIdx.x == 0)
+        __hip_atomic_store(flags + (int64_t)t_first * STACK_FLAG_STRIDE, fbase + (unsigned)n_layers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef S16_STAMP
     if (lane == 0)
-        for (int i = 0; i < 5; ++i) st_out[((int)blockIdx.x * WAVES + wave) * 5 + i] = st_sum[i];
+        for (int i = 0; i < (STACK ? 9 : 5); ++i) st_out[((int)blockIdx.x * WAVES + wave) * (STACK ? 9 : 5) + i] = st_sum[i];
 #endif
 }
 
@@ -903,11 +1033,47 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
 #define S16_LAUNCH(KERNEL)                                                                                                                  \
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
                           bias, static_cast<char*>(y), (int)H, (int)W, relu, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, (int)tiles_x,       \
-                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx)
-    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0>));
-    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1>));
-    else S16_LAUNCH((s16::conv_s16_kernel<0, 0>));
+                          (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(nullptr),                                        \
+                          static_cast<const s16::StackLayer*>(nullptr), 1, static_cast<unsigned*>(nullptr))
+    if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0, 0>));
+    else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1, 0>));
+    else S16_LAUNCH((s16::conv_s16_kernel<0, 0, 0>));
 #undef S16_LAUNCH
+    return launch_status();
+}
+
+static_assert(sizeof(s16::StackLayer) == 24, "the layer table of deqsci_conv3x3_c64_split16_stack is three 8-byte words per layer");
+
+extern "C" int deqsci_conv3x3_c64_split16_stack_fits(int64_t n, int64_t H, int64_t W) {
+    if (n <= 0 || H <= 0 || W <= 0) return 0;
+    return n * ceil_div(W, s16::OUT_COLS) * ceil_div(H, s16::OUT_ROWS) <= (int64_t)num_cus() ? 1 : 0;
+}
+
+extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
+                                                int64_t n, int64_t H, int64_t W, const float* ranges, int in_exp, int out_exp, void* flags,
+                                                deqsci_stream_t stream, void* start_event, void* stop_event) {
+    if (!x_sp16 || !y_even || !layers || !flags || (n_layers > 1 && !y_odd)) return DEQSCI_ERR_NULL;
+    if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || n_layers <= 0) return DEQSCI_ERR_SHAPE;
+    if (x_sp16 == y_even || x_sp16 == y_odd || y_even == y_odd || n_layers > 64 || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(x_sp16) || !aligned16(y_even) || !aligned16(y_odd) || (reinterpret_cast<uintptr_t>(layers) & 7u) || (reinterpret_cast<uintptr_t>(flags) & 3u))
+        return DEQSCI_ERR_ALIGN;
+    const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
+    const int64_t n_tiles = n * tiles_x * tiles_y;
+    if (H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    // workgroup = tile, and every workgroup of the launch has to be RESIDENT (they wait for one another): one per CU - the kernel's 152 KB
+    // of LDS admit no second one - so never more tiles than CUs.  Larger launches have tiles to overlap and take a launch per layer.
+    if (n_tiles > (int64_t)num_cus()) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t mg_img, sh_img, mg_tx, sh_tx;
+    s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
+    s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
+    hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
+    hipExtLaunchKernelGGL((s16::conv_s16_kernel<0, 0, 1>), dim3((unsigned)n_tiles), dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16),
+                          static_cast<const char*>(nullptr), static_cast<const float*>(nullptr), static_cast<char*>(y_even), (int)H, (int)W, 0, 0, ranges,
+                          in_exp, static_cast<const float*>(nullptr), out_exp, static_cast<float*>(nullptr), (int)tiles_x, (int)tiles_y, (int)n_tiles,
+                          mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(y_odd), static_cast<const s16::StackLayer*>(layers), n_layers,
+                          static_cast<unsigned*>(flags));
     return launch_status();
 }
 

@@ -64,9 +64,16 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True):
+                 act_range="data", blk32=True, stack=True):
         from .networks import FFDNet
         self.net = net
+        # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch (_hip.conv3x3_c64_split16_stack) whenever the
+        # launch is at most one block tile per CU - one measurement of 256 x 256 x 8 per call, the reference's usage - where a kernel
+        # boundary per layer costs a fifth of the layer; bit-identical to the per-layer launches, which larger batches and the measuring
+        # f-call keep
+        self.stack = bool(stack)
+        self._stacks = {}                                           # first layer of a run -> _hip.Split16Stack
+        self.stack_launches = 0
         self.fused_edges = fused_edges
         self.winograd = winograd
         self.conv64 = conv64                                        # _hip.conv64_kernel_for policy: "fast" | "fast32" | "f22" | "f44" | "s16"
@@ -148,6 +155,7 @@ class _Denoiser:
                                                                       and tuple(w.shape) == (64, 64, 3, 3)) else None)
                          for w, _, _ in layers]
             self.ranges = None
+            self._stacks = {}
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
@@ -189,7 +197,31 @@ class _Denoiser:
             return F.conv2d(self._run_layers(h, idx[:-1], fused), w, None, padding=1), b
         return self._run_layers(h, idx, fused)
 
+    def _stack_for(self, idx, device):
+        """The Split16Stack of the run of layers idx (an H2D copy of its table: built by prepare(), never inside a hipGraph capture)."""
+        st = self._stacks.get(idx[0])
+        if st is None or st.n_layers != len(idx) or st.table.device != torch.device(device):
+            st = self._stacks[idx[0]] = _hip.Split16Stack([(self.wino[i].s16, self.fast[i][1], self.fast[i][2]) for i in idx], device)
+        return st
+
+    def _middle_run(self):
+        """Indices of the run of 64->64 layers between the edge layers, when the whole run can take the split-fp16 kernel."""
+        if self.fast is None or self.wino is None or len(self.fast) < 4 or self.conv64 not in ("fast", "s16"):
+            return None
+        idx = list(range(1, len(self.fast) - 1))
+        return idx if all(self.wino[i] is not None for i in idx) else None
+
+    def stack_timed_out(self):
+        """(host sync) whether a wait inside a stack launch gave up since the last call: its results are invalid."""
+        return any(st.timed_out() for st in self._stacks.values())
+
     def _run_layers(self, h, idx, fused):
+        if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= 2 and self._native_out and not self._calibrating
+                and idx[0] in self._stacks and self._stacks[idx[0]].n_layers == len(idx) and (h.rng is None) == (self.ranges is None)
+                and _hip.split16_stack_fits(h.n, h.H, h.W)):
+            # the whole run in one launch: sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
+            self.stack_launches += 1
+            return _hip.conv3x3_c64_split16_stack(h, self._stack_for(idx, h.t.device), None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2])
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
             nxt = idx[pos + 1] if pos + 1 < len(idx) else None
@@ -240,6 +272,9 @@ class _Denoiser:
         self._refresh()
         if n_img is not None:
             self._alloc_ranges(n_img, device)
+        run = self._middle_run() if (self.stack and torch.device(device).type == "cuda") else None
+        if run is not None and self.wino[run[0]].s16.packed.is_cuda:
+            self._stack_for(run, device)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
@@ -332,7 +367,8 @@ class DEQSCIEngine:
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64"):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64",
+                 stack=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if anderson_arith not in ("float64", "reference"):
@@ -365,7 +401,7 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
@@ -422,6 +458,16 @@ class DEQSCIEngine:
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
         with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
             rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+            if self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
+                # a stack launch waits for its own workgroups only - all resident when the device is ours.  A wait that gave up means it is
+                # not (another process holds CUs): that result is invalid; redo it with a launch per layer, and stay there
+                import warnings
+                warnings.warn("deqsci_amd: a wait inside a split-fp16 stack launch timed out (the device's CUs are shared with other work); "
+                              "redoing this call with one launch per layer and keeping that (stack=False) for this engine", RuntimeWarning)
+                self.den.stack = False
+                self._graph = None
+                rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+            self.last_info["stack_launches"], self.den.stack_launches = self.den.stack_launches, 0
             fallback = None
             if self.conv64 == "auto" and not math.isfinite(self.last_info["res"]) and bool(torch.isfinite(y).all()):
                 # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
@@ -527,10 +573,12 @@ class DEQSCIEngine:
             g["x0"] = None if initial_point is None else initial_point.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            c0 = self.den.stack_launches
             with torch.cuda.graph(graph):
                 g["rec"], g["call"], g["last"], g["res_row"] = self._enqueue(ws, g["y"], g["Phi4"], g["ps"], g["x0"], None)
-            g["graph"] = graph
+            g["graph"], g["stack_n"] = graph, self.den.stack_launches - c0
         else:
+            self.den.stack_launches += g["stack_n"]
             g["y"].copy_(y)
             g["Phi4"].copy_(Phi4)
             if Phi_sum is not None:

@@ -920,6 +920,99 @@ def test_split16_conv64_follows_the_data_scale(scale):
         assert not math.isfinite(e_fixed)
 
 
+@pytest.mark.parametrize("n,H,W,n_layers,data_ranges", [(8, 128, 128, 13, True),      # the reference's usage: one measurement, FFDNet's 13 layers, one image per XCD
+                                                        (3, 128, 128, 5, True),       # 96 tiles: every image's tiles straddle XCDs
+                                                        (5, 64, 96, 4, False),        # 60 tiles (not a multiple of 8), fixed exponents
+                                                        (1, 100, 76, 2, True),        # ragged edges, 21 tiles, SimpleCNN's two layers
+                                                        (7, 16, 32, 3, True)])        # one tile per image: no neighbours at all
+def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, data_ranges):
+    """A run of 64->64 layers as ONE launch (deqsci_conv3x3_c64_split16_stack: workgroup = tile, a tile's next layer waits for its eight
+    neighbours' progress words; activations written through and fetched at agent scope) against the same layers as single launches:
+    the same bits, launch after launch (the progress words count on: five launches on the same words), with images that straddle XCDs,
+    ragged edges, no-bias and no-ReLU layers, measured and fixed ranges.  Both ping-pong buffers are poisoned before every launch - a
+    tile that ran ahead of a neighbour would read the poison."""
+    g = torch.Generator(device=DEV).manual_seed(100 * n + n_layers)
+    x = (torch.relu(torch.randn(n, 64, H, W, device=DEV, generator=g)) * torch.logspace(0, -2, n, device=DEV).view(n, 1, 1, 1))
+    x = x.contiguous(memory_format=torch.channels_last)
+    ws = [torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.06 for _ in range(n_layers)]
+    bs = [None if i == 1 else torch.randn(64, device=DEV, generator=g) * 0.1 for i in range(n_layers)]
+    relus = [i != n_layers - 2 for i in range(n_layers)]
+    Ws = [_hip.Split16Weights(w) for w in ws]
+    rng = torch.zeros(n_layers + 1, n, device=DEV) if data_ranges else None
+    if data_ranges:
+        _hip.absmax(x, rng[0])
+    h0 = _hip.to_split16(x, rng=None if rng is None else rng[0])
+    h = h0
+    for i in range(n_layers):                                   # the single launches (measuring first, where the ranges follow the data)
+        if data_ranges:
+            _hip.conv3x3_c64_split16(h, Ws[i], bs[i], relus[i], track=rng[i + 1])
+        h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], relus[i], out_rng=None if rng is None else rng[i + 1])
+    want = h.t.clone()
+    assert bool(torch.isfinite(want).all())
+    assert _hip.split16_stack_fits(n, H, W)
+    stack = _hip.Split16Stack(list(zip(Ws, bs, relus)), DEV)
+    flags, bufs = stack.state(n, H, W)
+    for rep in range(5):
+        for b in bufs:
+            b.t.fill_(float("nan"))
+        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng)
+        assert out is bufs[(n_layers - 1) % 2]
+        assert torch.equal(out.t, want), (rep, float((out.t.float() - want.float()).abs().max()))
+        assert out.exponents() == h.exponents()
+    fl = flags.cpu().view(-1, 32)[:, 0]
+    assert int(fl[-1]) == 0 and bool((fl[:-1] == 5 * n_layers).all())      # every tile: five launches of n_layers layers, no time-out
+    assert not stack.timed_out()
+
+
+def test_split16_stack_limits_and_errors():
+    """More than one tile per CU is refused (a launch per layer there), and so are aliased buffers, a missing odd buffer and ranges of the
+    wrong shape."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert _hip.split16_stack_fits(8, 128, 128) == (cus >= 256) and not _hip.split16_stack_fits(8 * cus, 16, 32 + 1)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    Ws = [_hip.Split16Weights(torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05) for _ in range(2)]
+    stack = _hip.Split16Stack([(w, None, True) for w in Ws], DEV)
+    big = _hip.Sp16.empty(2 * cus, 16, 32, DEV)
+    big.t.zero_()
+    with pytest.raises(_hip.DeqsciHipError, match="unsupported"):
+        _hip.conv3x3_c64_split16_stack(big, stack)
+    small = _hip.Sp16.empty(2, 16, 32, DEV)
+    small.t.zero_()
+    with pytest.raises(_hip.DeqsciHipError, match="ranges"):
+        _hip.conv3x3_c64_split16_stack(small, stack, torch.zeros(2, 2, device=DEV))
+    lib = _hip.load()
+    flags, bufs = stack.state(2, 16, 32)
+    args = lambda x, y0, y1, fl: (x, y0, y1, stack.table.data_ptr(), 2, 2, 16, 32, None, 8, 8, fl, None, None, None)   # noqa: E731
+    assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), small.t.data_ptr(), bufs[1].t.data_ptr(), flags.data_ptr())) == -4
+    assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), None, flags.data_ptr())) == -1
+    assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), None)) == -1
+
+
+@pytest.mark.parametrize("kind", ["ffdnet", "SimpleCNN"])
+def test_engine_stack_launch_matches_per_layer_launches(kind):
+    """One measurement per call - the reference's usage (test_ffdnet.sh: batch 1) - takes the stack launch from the second f-call on (the
+    first measures the ranges layer by layer): the reconstruction is bit-identical to the engine with stack=False, eagerly and as a
+    replayed hipGraph, and last_info says how many stack launches ran."""
+    d = _clip("traffic_cacti.mat")
+    Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 1].contiguous().to(DEV)
+    if kind == "ffdnet":
+        net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 10)[0].nonlinear_op
+    else:
+        net = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 10)[0].nonlinear_op
+    ref = DEQSCIEngine(net, max_iter=10, use_graph=False, stack=False)
+    want = ref.reconstruct(y, Phi)
+    assert ref.last_info["stack_launches"] == 0
+    eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
+    got = eng.reconstruct(y, Phi)
+    fits = _hip.split16_stack_fits(8, 128, 128) if kind == "ffdnet" else _hip.split16_stack_fits(8, 256, 256)
+    assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if fits else 0)
+    assert torch.equal(got, want)
+    gr = DEQSCIEngine(net, max_iter=10, use_graph=True)
+    for _ in range(3):                                          # eager warm-up, capture, replay
+        out = gr.reconstruct(y, Phi)
+    assert gr.last_info["graph"] and torch.equal(out, want)
+
+
 def _denoiser_error_vs_float64(net, z1, call=3):
     """rel-L2 error of one f-call of the engine's denoiser against the SAME folded layers evaluated in float64 (as
     test_denoiser_rounding_along_the_loop does): {"default": the shipped path, measuring its ranges on this input, "f22": the all-fp32

@@ -19,7 +19,7 @@ import csv, collections, glob, json
 n, H, W = 64, 128, 128
 for kern, fname, pos, outs, name in (("winograd_conv64_kernel", "gpurun_out/pmc_winograd.json", 16, 4, "deqsci::winograd_conv64_kernel"),
                                      ("winograd44_conv64_kernel<1, 1>", "gpurun_out/pmc_winograd44.json", 36, 16, "deqsci::w44::winograd44_conv64_kernel<1,1> (blk32 -> blk32)"),
-                                     ("conv_s16_kernel<0, 0>", "gpurun_out/pmc_conv_s16.json", 0, 0, "deqsci::s16::conv_s16_kernel<0, 0> (sp16 -> sp16)")):
+                                     ("conv_s16_kernel<0, 0, 0>", "gpurun_out/pmc_conv_s16.json", 0, 0, "deqsci::s16::conv_s16_kernel<0, 0, 0> (sp16 -> sp16)")):
     agg = collections.defaultdict(list)
     for f in sorted(glob.glob('gpurun_out/pmc_wg/p*/k_counter_collection.csv')):
         for r in csv.DictReader(open(f)):

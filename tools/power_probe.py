@@ -73,6 +73,10 @@ def main():
     if kind == "s16":
         xs = _hip.to_split16(x); out = _hip.Sp16.empty(NI, 128, 128, "cuda"); Wsp = _hip.Split16Weights(w)
         launch = lambda: _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=out)  # noqa: E731
+    elif kind == "stack":                                      # 13 such layers as ONE launch (PROBE_IMAGES=8: the stack launch's shape); per-launch figures = 13 layers
+        xs = _hip.to_split16(x)
+        stack = _hip.Split16Stack([(_hip.Split16Weights(w), b, True)] * 13, "cuda")
+        launch = lambda: _hip.conv3x3_c64_split16_stack(xs, stack)  # noqa: E731
     elif kind == "f44":
         xb = _hip.Blk32.from_nchw(x); ob = _hip.Blk32.empty(NI, 128, 128, "cuda"); U = _hip.pack_winograd44_weights(w)
         launch = lambda: _hip.conv3x3_c64_winograd44(xb, U, b, True, out=ob, out_blk=True)  # noqa: E731
@@ -86,7 +90,7 @@ def main():
     idle = {k: int(open(f).read().strip()) for k, f in files.items() if k != "power1_cap"} if files else {}
     s = Sampler({k: f for k, f in files.items() if k != "power1_cap"})
     s.start()
-    n = (12000 if kind == "s16" else 8000) * max(1, 64 // NI) // (1 if NI == 64 else 2)
+    n = (12000 if kind == "s16" else 8000) * max(1, 64 // NI) // (1 if NI == 64 else 2) // (13 if kind == "stack" else 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
