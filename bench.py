@@ -357,7 +357,10 @@ def run_rank(args):
                    "conv64_policy": None if selftest else (f"{eng.conv64} -> F(2x2,3x3) for f-calls < {eng.conv64_f22_calls}, then {eng.conv64_policy}"
                                                            if eng.conv64_f22_calls else f"{eng.conv64} -> {eng.conv64_policy}"),
                    "parallelism": f"measurements sharded over {world} GPU(s), one all-gather per step" if world > 1 else "single GPU",
-                   "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches"},
+                   "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches",
+                   # f-calls whose run of 64->64 layers went out as ONE launch (csrc/conv_s16.hip, STACK: at most one block tile per CU, i.e. one
+                   # measurement of 256x256x8 per call); 0 = a launch per layer
+                   "stack_launches_per_step": info.get("stack_launches", 0)},
         "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  64->64 conv layers under conv64 policy 'fast' (default): products on the f16 matrix "
                        "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, two fp32 accumulation "
                        "chains; the power-of-two scale of every activation follows max |activation| measured on the device at the first f-call, so "

@@ -465,6 +465,7 @@ class DEQSCIEngine:
                 warnings.warn("deqsci_amd: a wait inside a split-fp16 stack launch timed out (the device's CUs are shared with other work); "
                               "redoing this call with one launch per layer and keeping that (stack=False) for this engine", RuntimeWarning)
                 self.den.stack = False
+                self.den.stack_launches = 0
                 self._graph = None
                 rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
             self.last_info["stack_launches"], self.den.stack_launches = self.den.stack_launches, 0

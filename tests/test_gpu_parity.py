@@ -5,6 +5,7 @@ asks <= 1e-4 relative L2 / 0.01 dB end to end; single kernels are held to ~1 ulp
 import json
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -986,6 +987,32 @@ def test_split16_stack_limits_and_errors():
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), small.t.data_ptr(), bufs[1].t.data_ptr(), flags.data_ptr())) == -4
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), None, flags.data_ptr())) == -1
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), None)) == -1
+
+
+def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
+    """A stack launch waits for its own workgroups only - all resident when the device is ours.  When they are not (another process on the
+    device's CUs) a wait gives up after a quarter of a second instead of hanging: the launch says so in its words, later launches on the
+    same words do not wait at all, and the engine redoes the call with a launch per layer and stays there.  Simulated by setting one
+    tile's progress word back: its neighbours can never see it reach their target."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if cus < 256:
+        pytest.skip("the 8 x 128 x 128 run of FFDNet needs 256 CUs for the stack launch")
+    d = _clip("traffic_cacti.mat")
+    Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 2].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 4)[0].nonlinear_op
+    want = DEQSCIEngine(net, max_iter=4, use_graph=False, stack=False).reconstruct(y, Phi)
+    eng = DEQSCIEngine(net, max_iter=4, use_graph=False)
+    assert torch.equal(eng.reconstruct(y, Phi), want) and eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1 > 0
+    stack = eng.den._stacks[1]
+    flags, _ = stack.state(8, 128, 128)
+    flags[32 * 37] -= 1000                                      # tile 37 of 256
+    t0 = time.time()
+    with pytest.warns(RuntimeWarning, match="stack launch timed out"):
+        got = eng.reconstruct(y, Phi)
+    assert time.time() - t0 < 30.0
+    assert torch.equal(got, want) and eng.den.stack is False and eng.last_info["stack_launches"] == 0
+    assert not stack.timed_out()                                # read and rearmed by the engine
+    assert torch.equal(eng.reconstruct(y, Phi), want)           # ... and stays on per-layer launches
 
 
 @pytest.mark.parametrize("kind", ["ffdnet", "SimpleCNN"])

@@ -13,15 +13,18 @@ timeout 900 python bench.py --steps 3 --warmup 1 --denoiser SimpleCNN --no-cpu-b
 ( timeout 900 python bench.py --steps 1 --warmup 1 --size 512x512x16 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-graph --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
+  timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --batch-per-gpu 32 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --global-batch 64 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 3 --warmup 1 --act-range fixed --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{" ) > $O/r04_bench_other_shapes.jsonl
 timeout 300 python tools/kernel_bench.py 2>&1 | grep "^{" > $O/r04_kernel_bench_bsz64.jsonl
 timeout 300 python tools/conv_bench.py 2>&1 | grep "^{" > $O/r04_conv_bench.jsonl
 timeout 300 python tools/s16_check.py both 2>&1 | grep -v amdgpu > $O/r04_s16_check.txt
-for n in 64 8; do PROBE_IMAGES=$n timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1; done > $O/r04_power_probe.jsonl
+( for n in 64 8; do PROBE_IMAGES=$n timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1; done
+  PROBE_IMAGES=8 PROBE_KERNEL=stack timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1 ) > $O/r04_power_probe.jsonl
 if [ -f build/s16v/lib_stamp.so ]; then
   for n in 64 8; do echo "== $n images of 128 x 128"; S16_IMAGES=$n timeout 200 python tools/s16_stamps.py 2>&1 | grep -v amdgpu; done > $O/r04_s16_stamps.txt
+  timeout 200 python tools/s16_stack_stamps.py 2>&1 | grep -v amdgpu > $O/r04_s16_stack_stamps.txt
 fi
 python - > $O/r04_act_ranges.json <<'PY'
 import json, os, sys, torch
@@ -65,6 +68,6 @@ if ! skip pmc; then
 fi
 ls -la $O; cat $O/r04_gputest_summary.txt; head -c 700 $O/r04_bench_n1.json; echo; python -c "
 import json
-for ln in open('$O/r04_bench_other_shapes.jsonl'): d=json.loads(ln); print(round(d['value'],2), d['config']['workload'][:70], d['config'].get('launch_mode','')[:20])
+for ln in open('$O/r04_bench_other_shapes.jsonl'): d=json.loads(ln); print(round(d['value'],2), d['config']['workload'][:70], d['config'].get('launch_mode','')[:20], d['config'].get('stack_launches_per_step'))
 d=json.load(open('$O/r04_pmc_conv_s16.json')); print({k: d.get(k) for k in ('mfma_busy_fraction','non_mfma_valu_per_mfma','traffic_over_algorithmic','lds_bank_conflict_share','hbm_bytes_per_launch')})"
 cat $O/r04_power_probe.jsonl | cut -c1-400; cat $O/r04_s16_stamps.txt | head -30
