@@ -929,7 +929,7 @@ def test_split16_conv64_follows_the_data_scale(scale):
 def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, data_ranges):
     """A run of 64->64 layers as ONE launch (deqsci_conv3x3_c64_split16_stack: workgroup = tile, a tile's next layer waits for its eight
     neighbours' progress words; activations written through and fetched at agent scope) against the same layers as single launches:
-    the same bits, launch after launch (the progress words count on: five launches on the same words), with images that straddle XCDs,
+    the same bits, launch after launch (the progress words count on: five launches on the same words, through the 32-bit wrap), with images that straddle XCDs,
     ragged edges, no-bias and no-ReLU layers, measured and fixed ranges.  Both ping-pong buffers are poisoned before every launch - a
     tile that ran ahead of a neighbour would read the poison."""
     g = torch.Generator(device=DEV).manual_seed(100 * n + n_layers)
@@ -953,6 +953,7 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
     assert _hip.split16_stack_fits(n, H, W)
     stack = _hip.Split16Stack(list(zip(Ws, bs, relus)), DEV)
     flags, bufs = stack.state(n, H, W)
+    flags.view(-1, 32)[:-1, 0] = -20                            # the words count on for ever: start them 20 below the 32-bit wrap
     for rep in range(5):
         for b in bufs:
             b.t.fill_(float("nan"))
@@ -961,7 +962,7 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
         assert torch.equal(out.t, want), (rep, float((out.t.float() - want.float()).abs().max()))
         assert out.exponents() == h.exponents()
     fl = flags.cpu().view(-1, 32)[:, 0]
-    assert int(fl[-1]) == 0 and bool((fl[:-1] == 5 * n_layers).all())      # every tile: five launches of n_layers layers, no time-out
+    assert int(fl[-1]) == 0 and bool((fl[:-1] == 5 * n_layers - 20).all())      # every tile: five launches of n_layers layers, no time-out
     assert not stack.timed_out()
 
 
@@ -1015,23 +1016,26 @@ def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
     assert torch.equal(eng.reconstruct(y, Phi), want)           # ... and stays on per-layer launches
 
 
-@pytest.mark.parametrize("kind", ["ffdnet", "SimpleCNN"])
+@pytest.mark.parametrize("kind", ["ffdnet", "SimpleCNN", "SimpleCNN-128"])
 def test_engine_stack_launch_matches_per_layer_launches(kind):
     """One measurement per call - the reference's usage (test_ffdnet.sh: batch 1) - takes the stack launch from the second f-call on (the
     first measures the ranges layer by layer): the reconstruction is bit-identical to the engine with stack=False, eagerly and as a
-    replayed hipGraph, and last_info says how many stack launches ran."""
+    replayed hipGraph, and last_info says how many stack launches ran.  SimpleCNN works at full resolution: 8 frames of 256 x 256 are four
+    tiles per CU (a launch per layer), a 128 x 128 crop of the measurement is one (its two 64->64 layers as one launch)."""
     d = _clip("traffic_cacti.mat")
     Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 1].contiguous().to(DEV)
     if kind == "ffdnet":
         net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 10)[0].nonlinear_op
     else:
         net = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 10)[0].nonlinear_op
+    if kind == "SimpleCNN-128":
+        Phi, y = Phi[:, 64:192, 100:228].contiguous(), y[:, 64:192, 100:228].contiguous()
     ref = DEQSCIEngine(net, max_iter=10, use_graph=False, stack=False)
     want = ref.reconstruct(y, Phi)
     assert ref.last_info["stack_launches"] == 0
     eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
     got = eng.reconstruct(y, Phi)
-    fits = _hip.split16_stack_fits(8, 128, 128) if kind == "ffdnet" else _hip.split16_stack_fits(8, 256, 256)
+    fits = _hip.split16_stack_fits(8, 256, 256) if kind == "SimpleCNN" else _hip.split16_stack_fits(8, 128, 128)
     assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if fits else 0)
     assert torch.equal(got, want)
     gr = DEQSCIEngine(net, max_iter=10, use_graph=True)
