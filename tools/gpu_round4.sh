@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerates everything committed under profiles/r04_* that profiles/README.md lists in its first round-4 table (run on the GPU box through
 # gpurun).  Stages can be skipped: R4_SKIP="parity pmc"
+# The two stamp files need the profiling build first: bash tools/s16_variants.sh "stamp:-DS16_STAMP"  (build/s16v/lib_stamp.so)
 mkdir -p gpurun_out/pmc gpurun_out/r04p
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
