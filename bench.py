@@ -202,6 +202,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-winograd", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
+    ap.add_argument("--stack-max-launches", type=int, default=None, help="a run of 64->64 layers goes out as stack launches up to this many slices of the batch (A/B)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -230,6 +231,8 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
         kw["act_range"] = args.act_range
     if args.no_stack:
         kw["stack"] = False
+    if args.stack_max_launches is not None:
+        kw["stack_max_launches"] = args.stack_max_launches
     return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                         channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
                         fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,

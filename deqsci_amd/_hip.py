@@ -48,7 +48,7 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16_stack_fits": [_i64, _i64, _i64],
-    "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _int, _int, _ptr, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -60,7 +60,7 @@ SIGNATURES = {
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
 }
 OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
-                 "deqsci_partials_bytes", "deqsci_gram_bytes")
+                 "deqsci_partials_bytes", "deqsci_gram_bytes", "deqsci_conv3x3_c64_split16_stack_images")
 
 
 class DeqsciHipError(RuntimeError):
@@ -88,6 +88,8 @@ def load():
     lib.deqsci_version.restype = ctypes.c_char_p
     lib.deqsci_error_string.restype = ctypes.c_char_p
     lib.deqsci_error_string.argtypes = [_int]
+    lib.deqsci_conv3x3_c64_split16_stack_images.restype = _i64
+    lib.deqsci_conv3x3_c64_split16_stack_images.argtypes = [_i64, _i64]
     lib.deqsci_anderson_chunks.restype = _i64
     lib.deqsci_anderson_chunks.argtypes = [_i64, _i64]
     lib.deqsci_partials_bytes.restype = ctypes.c_size_t
@@ -786,34 +788,54 @@ class Split16Stack:
         self.n_layers, self.keep, self._state = len(layers), keep, {}
 
     def state(self, n, H, W):
-        """(flags, (Sp16, Sp16)) of the launch shape: 32 (n_tiles + 1) zeroed words (a 128-byte line per tile + the time-out word), two
-        output buffers."""
-        st = self._state.get((n, H, W))
+        """(Sp16, Sp16) ping-pong outputs of a batch of n images (kept: a captured hipGraph carries their addresses)."""
+        st = self._state.get(("out", n, H, W))
         if st is None:
-            n_tiles = n * (-(-H // 16)) * (-(-W // 32))
             dev = self.table.device
-            st = self._state[(n, H, W)] = (torch.zeros(32 * (n_tiles + 1), dtype=torch.int32, device=dev), (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev)))
+            st = self._state[("out", n, H, W)] = (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev))
         return st
+
+    def flags(self, n, H, W):
+        """The progress words of a LAUNCH of n images: 32 (n_tiles + 1) words (a 128-byte line per tile + the time-out word), zeroed once.
+        Launches of one shape share them (they run one after the other on a stream and each advances every word by n_layers)."""
+        fl = self._state.get(("flags", n, H, W))
+        if fl is None:
+            n_tiles = n * (-(-H // 16)) * (-(-W // 32))
+            fl = self._state[("flags", n, H, W)] = torch.zeros(32 * (n_tiles + 1), dtype=torch.int32, device=self.table.device)
+        return fl
 
     def timed_out(self):
         """(host sync) True if a wait of any launch since the last call timed out - the outputs since then are invalid; the words are
         rearmed."""
         bad = False
-        for flags, _ in self._state.values():
-            if int(flags[-32]) != 0:
-                flags.zero_()
+        for key, fl in self._state.items():
+            if key[0] == "flags" and int(fl[-32]) != 0:
+                fl.zero_()
                 bad = True
         return bad
 
 
 def split16_stack_fits(n, H, W):
-    """Whether a launch of n images of H x W is at most one block tile per CU - what deqsci_conv3x3_c64_split16_stack takes."""
+    """Whether a launch of n images of H x W is at most one block tile per CU - what ONE deqsci_conv3x3_c64_split16_stack launch takes."""
     return bool(load().deqsci_conv3x3_c64_split16_stack_fits(n, H, W))
 
 
+def split16_stack_images(H, W):
+    """Images of H x W that make at most one block tile per CU: what ONE stack launch takes (0: not even one image)."""
+    return int(load().deqsci_conv3x3_c64_split16_stack_images(H, W))
+
+
+def split16_stack_launches(n, H, W):
+    """How many stack launches a batch of n images of H x W goes out as (slices of split16_stack_images images), 0 when one image does
+    not fit."""
+    per = split16_stack_images(H, W)
+    return 0 if per == 0 else -(-n // per)
+
+
 def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None):
-    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack) in ONE launch (csrc/conv_s16.hip, STACK: workgroup = tile, a layer of a
-    tile waits for the layer before of its eight neighbours); ranges: the (n_layers + 1, n) range slots of the run - its input's first -
+    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack), each launch a whole run (csrc/conv_s16.hip, STACK: workgroup = tile, a
+    layer of a tile waits for the layer before of its eight neighbours) over as many images as make one block tile per CU - a batch of
+    more images goes out as slices, one launch after the other; ranges: the (n_layers + 1, n) range slots of the run - its input's first -
     or None (fixed exponents: the input's, then 2^8).  Returns the Sp16 the last layer wrote (one of the stack's two buffers of this
     shape).  stack.timed_out() afterwards tells whether a wait gave up (foreign work on the device's CUs): the result is invalid then."""
     if not isinstance(x, Sp16) or not isinstance(stack, Split16Stack) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
@@ -826,12 +848,18 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None):
         raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, {n}) tensor on the input's device")
     if (ranges is None) != (x.rng is None):
         raise DeqsciHipError("conv3x3_c64_split16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
-    flags, bufs = stack.state(n, H, W)
+    per = split16_stack_images(H, W)
+    if per == 0:
+        _check(-4, "conv3x3_c64_split16_stack (one image is more than one block tile per CU)")
+    bufs = stack.state(n, H, W)
     ev = events or (None, None)
     with _dev(x.t):
-        _check(load().deqsci_conv3x3_c64_split16_stack(x.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), stack.table.data_ptr(), stack.n_layers,
-                                                       n, H, W, None if ranges is None else ranges.data_ptr(), x.exp, SP16_DEFAULT_EXP,
-                                                       flags.data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_split16_stack")
+        for a in range(0, n, per):
+            m = min(per, n - a)
+            _check(load().deqsci_conv3x3_c64_split16_stack(x.t[a:a + m].data_ptr(), bufs[0].t[a:a + m].data_ptr(), bufs[1].t[a:a + m].data_ptr(),
+                                                           stack.table.data_ptr(), stack.n_layers, m, H, W,
+                                                           None if ranges is None else ranges.data_ptr() + 4 * a, n, x.exp, SP16_DEFAULT_EXP,
+                                                           stack.flags(m, H, W).data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_split16_stack")
     out = bufs[(stack.n_layers - 1) % 2]
     out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers]), SP16_DEFAULT_EXP
     return out

@@ -125,8 +125,8 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // its stores have been acknowledged and its neighbours poll.  Coherence without cache maintenance: the activations are stored
 // write-through and fetched with agent-scope loads (sc1 - the tiles of one image may sit on different XCDs, whose L2s do not snoop each other),
 // the words are agent-scope atomics.  Layer l reads x (l = 0) or the buffer layer l - 1 wrote and writes y (l even) / y2 (l odd); its
-// weights, bias, w_exp, relu come from `layers`, its ranges from in_amax[l][image] -> in_amax[l + 1][image] (in_amax = the run's slot
-// table, or NULL: in_exp for the run's input, out_exp for every output).  flags[32 n_tiles] != 0: a wait timed out (a workgroup of the
+// weights, bias, w_exp, relu come from `layers`, its ranges from in_amax[l range_stride + image] -> in_amax[(l + 1) range_stride + image]
+// (in_amax = the run's slot table, or NULL: in_exp for the run's input, out_exp for every output).  flags[32 n_tiles] != 0: a wait timed out (a workgroup of the
 // launch was not resident) - the launch never hangs, the result is invalid and says so.
 struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
 constexpr unsigned STACK_SPIN_LIMIT = 1u << 21;                // polls, one every ~0.1 us: a wait gives up after a quarter of a second
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                                                           char* __restrict__ y, int H, int W, int relu, int w_exp, const float* __restrict__ in_amax, int in_exp,
                                                           const float* __restrict__ out_amax, int out_exp, float* __restrict__ track, int tiles_x, int tiles_y,
                                                           int n_tiles, uint32_t mg_img, uint32_t sh_img, uint32_t mg_tx, uint32_t sh_tx,
-                                                          char* __restrict__ y2, const StackLayer* __restrict__ layers, int n_layers, unsigned* flags) {
+                                                          char* __restrict__ y2, const StackLayer* __restrict__ layers, int n_layers, unsigned* flags,
+                                                          int range_stride) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
     __shared__ __attribute__((aligned(16))) float bias_s[64];
@@ -523,12 +524,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0, 0.0f, 0.0f, 0};
     char* const y_even = y;
     const float* const ranges = in_amax;                        // (STACK) the run's slot table [layer][image]
-    int n_img = 0;
+    const int n_img = range_stride;                            // (STACK) floats between two layers' rows of the slot table (>= the launch's images: a launch may be a slice of a batch)
     unsigned fbase = 0, fgiveup = 0;
     if (STACK) {
         const StackLayer l0 = layers[0];                       // (wave-uniform: scalar loads)
         Wp = l0.w; bias = l0.bias; w_exp = l0.w_exp; relu = l0.relu;
-        n_img = mdiv(n_tiles, mg_img, sh_img);
         const int img0 = mdiv(t_first, mg_img, sh_img);
         se_in = ranges ? sp16_act_exp(ranges[img0]) : in_exp;
         se_out = ranges ? sp16_act_exp(ranges[n_img + img0]) : out_exp;
@@ -1034,7 +1034,7 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
     hipExtLaunchKernelGGL(KERNEL, grid, dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16), static_cast<const char*>(w_packed), \
                           bias, static_cast<char*>(y), (int)H, (int)W, relu, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, (int)tiles_x,       \
                           (int)tiles_y, (int)n_tiles, mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(nullptr),                                        \
-                          static_cast<const s16::StackLayer*>(nullptr), 1, static_cast<unsigned*>(nullptr))
+                          static_cast<const s16::StackLayer*>(nullptr), 1, static_cast<unsigned*>(nullptr), 0)
     if (out_f32) S16_LAUNCH((s16::conv_s16_kernel<1, 0, 0>));
     else if (track_amax) S16_LAUNCH((s16::conv_s16_kernel<0, 1, 0>));
     else S16_LAUNCH((s16::conv_s16_kernel<0, 0, 0>));
@@ -1044,17 +1044,21 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
 
 static_assert(sizeof(s16::StackLayer) == 24, "the layer table of deqsci_conv3x3_c64_split16_stack is three 8-byte words per layer");
 
+extern "C" int64_t deqsci_conv3x3_c64_split16_stack_images(int64_t H, int64_t W) {
+    if (H <= 0 || W <= 0) return 0;
+    return (int64_t)num_cus() / (ceil_div(W, s16::OUT_COLS) * ceil_div(H, s16::OUT_ROWS));
+}
+
 extern "C" int deqsci_conv3x3_c64_split16_stack_fits(int64_t n, int64_t H, int64_t W) {
-    if (n <= 0 || H <= 0 || W <= 0) return 0;
-    return n * ceil_div(W, s16::OUT_COLS) * ceil_div(H, s16::OUT_ROWS) <= (int64_t)num_cus() ? 1 : 0;
+    return n > 0 && n <= deqsci_conv3x3_c64_split16_stack_images(H, W) ? 1 : 0;
 }
 
 extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
-                                                int64_t n, int64_t H, int64_t W, const float* ranges, int in_exp, int out_exp, void* flags,
-                                                deqsci_stream_t stream, void* start_event, void* stop_event) {
+                                                int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
+                                                void* flags, deqsci_stream_t stream, void* start_event, void* stop_event) {
     if (!x_sp16 || !y_even || !layers || !flags || (n_layers > 1 && !y_odd)) return DEQSCI_ERR_NULL;
     if ((start_event == nullptr) != (stop_event == nullptr)) return DEQSCI_ERR_NULL;
-    if (n <= 0 || H <= 0 || W <= 0 || n_layers <= 0) return DEQSCI_ERR_SHAPE;
+    if (n <= 0 || H <= 0 || W <= 0 || n_layers <= 0 || (ranges && (range_stride < n || range_stride > INT32_MAX))) return DEQSCI_ERR_SHAPE;
     if (x_sp16 == y_even || x_sp16 == y_odd || y_even == y_odd || n_layers > 64 || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
     if (!aligned16(x_sp16) || !aligned16(y_even) || !aligned16(y_odd) || (reinterpret_cast<uintptr_t>(layers) & 7u) || (reinterpret_cast<uintptr_t>(flags) & 3u))
         return DEQSCI_ERR_ALIGN;
@@ -1073,7 +1077,7 @@ extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even
                           static_cast<const char*>(nullptr), static_cast<const float*>(nullptr), static_cast<char*>(y_even), (int)H, (int)W, 0, 0, ranges,
                           in_exp, static_cast<const float*>(nullptr), out_exp, static_cast<float*>(nullptr), (int)tiles_x, (int)tiles_y, (int)n_tiles,
                           mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(y_odd), static_cast<const s16::StackLayer*>(layers), n_layers,
-                          static_cast<unsigned*>(flags));
+                          static_cast<unsigned*>(flags), (int)range_stride);
     return launch_status();
 }
 

@@ -64,7 +64,7 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True, stack=True):
+                 act_range="data", blk32=True, stack=True, stack_max_launches=2):
         from .networks import FFDNet
         self.net = net
         # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch (_hip.conv3x3_c64_split16_stack) whenever the
@@ -72,6 +72,10 @@ class _Denoiser:
         # boundary per layer costs a fifth of the layer; bit-identical to the per-layer launches, which larger batches and the measuring
         # f-call keep
         self.stack = bool(stack)
+        # ... and a batch of two measurements as two stack launches, one after the other (each the whole chip for its slice of the
+        # batch): 118 -> 124 frames/s; from three slices on the per-layer launches have tiles enough to overlap their own edges and win
+        # (128 vs 126 at three measurements, 135 vs 128 at eight)
+        self.stack_max_launches = int(stack_max_launches)
         self._stacks = {}                                           # first layer of a run -> _hip.Split16Stack
         self.stack_launches = 0
         self.fused_edges = fused_edges
@@ -218,8 +222,8 @@ class _Denoiser:
     def _run_layers(self, h, idx, fused):
         if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= 2 and self._native_out and not self._calibrating
                 and idx[0] in self._stacks and self._stacks[idx[0]].n_layers == len(idx) and (h.rng is None) == (self.ranges is None)
-                and _hip.split16_stack_fits(h.n, h.H, h.W)):
-            # the whole run in one launch: sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
+                and 0 < _hip.split16_stack_launches(h.n, h.H, h.W) <= self.stack_max_launches):
+            # the whole run in one launch (per slice of the batch): sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
             self.stack_launches += 1
             return _hip.conv3x3_c64_split16_stack(h, self._stack_for(idx, h.t.device), None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2])
         for pos, i in enumerate(idx):
@@ -368,7 +372,7 @@ class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
                  fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64",
-                 stack=True):
+                 stack=True, stack_max_launches=2):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if anderson_arith not in ("float64", "reference"):
@@ -401,7 +405,8 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack,
+                             stack_max_launches=stack_max_launches)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)

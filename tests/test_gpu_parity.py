@@ -952,7 +952,7 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
     assert bool(torch.isfinite(want).all())
     assert _hip.split16_stack_fits(n, H, W)
     stack = _hip.Split16Stack(list(zip(Ws, bs, relus)), DEV)
-    flags, bufs = stack.state(n, H, W)
+    flags, bufs = stack.flags(n, H, W), stack.state(n, H, W)
     flags.view(-1, 32)[:-1, 0] = -20                            # the words count on for ever: start them 20 below the 32-bit wrap
     for rep in range(5):
         for b in bufs:
@@ -966,6 +966,35 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
     assert not stack.timed_out()
 
 
+@pytest.mark.parametrize("n,H,W", [(16, 128, 128), (20, 128, 128), (7, 100, 76)])
+def test_split16_stack_slices_a_batch(n, H, W):
+    """A batch of more images than one launch takes (8 of 128 x 128 on 256 CUs) goes out as slices, one stack launch after the other - 2
+    x 8, 8 + 8 + 4 (two launch shapes, each with its own progress words), and on small images a single launch: the same bits as the
+    per-layer launches over the whole batch, per-image ranges read through the slice's offset into the slot table."""
+    n_layers = 4
+    g = torch.Generator(device=DEV).manual_seed(n)
+    x = (torch.relu(torch.randn(n, 64, H, W, device=DEV, generator=g)) * torch.logspace(0, -3, n, device=DEV).view(n, 1, 1, 1))
+    x = x.contiguous(memory_format=torch.channels_last)
+    Ws = [_hip.Split16Weights(torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.06) for _ in range(n_layers)]
+    bs = [torch.randn(64, device=DEV, generator=g) * 0.1 for _ in range(n_layers)]
+    rng = torch.zeros(n_layers + 1, n, device=DEV)
+    _hip.absmax(x, rng[0])
+    h0 = _hip.to_split16(x, rng=rng[0])
+    h = h0
+    for i in range(n_layers):
+        _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, track=rng[i + 1])
+        h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, out_rng=rng[i + 1])
+    stack = _hip.Split16Stack([(w, b, True) for w, b in zip(Ws, bs)], DEV)
+    per = _hip.split16_stack_images(H, W)
+    assert _hip.split16_stack_launches(n, H, W) == -(-n // per)
+    for rep in range(3):
+        for b in stack.state(n, H, W):
+            b.t.fill_(float("nan"))
+        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng)
+        assert torch.equal(out.t, h.t), rep
+    assert not stack.timed_out()
+
+
 def test_split16_stack_limits_and_errors():
     """More than one tile per CU is refused (a launch per layer there), and so are aliased buffers, a missing odd buffer and ranges of the
     wrong shape."""
@@ -974,20 +1003,44 @@ def test_split16_stack_limits_and_errors():
     g = torch.Generator(device=DEV).manual_seed(3)
     Ws = [_hip.Split16Weights(torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05) for _ in range(2)]
     stack = _hip.Split16Stack([(w, None, True) for w in Ws], DEV)
-    big = _hip.Sp16.empty(2 * cus, 16, 32, DEV)
+    assert _hip.split16_stack_images(16, 32) == cus and _hip.split16_stack_images(128, 128) == cus // 32 and _hip.split16_stack_images(4096, 4096) == 0
+    assert _hip.split16_stack_launches(3 * cus + 1, 16, 32) == 4 and _hip.split16_stack_launches(1, 4096, 4096) == 0
+    big = _hip.Sp16.empty(1, 16 * 40, 32 * 8, DEV)                # 320 tiles in ONE image: no launch takes it
     big.t.zero_()
     with pytest.raises(_hip.DeqsciHipError, match="unsupported"):
         _hip.conv3x3_c64_split16_stack(big, stack)
+    lib0 = _hip.load()
+    two = _hip.Sp16.empty(2 * cus, 16, 32, DEV)                   # the C entry point takes one launch's worth, the wrapper slices
+    assert lib0.deqsci_conv3x3_c64_split16_stack(two.t.data_ptr(), two.t.data_ptr() + 16, two.t.data_ptr() + 32, stack.table.data_ptr(), 2, 2 * cus, 16, 32,
+                                                 None, 0, 8, 8, stack.flags(2, 16, 32).data_ptr(), None, None, None) == -4
     small = _hip.Sp16.empty(2, 16, 32, DEV)
     small.t.zero_()
     with pytest.raises(_hip.DeqsciHipError, match="ranges"):
         _hip.conv3x3_c64_split16_stack(small, stack, torch.zeros(2, 2, device=DEV))
     lib = _hip.load()
-    flags, bufs = stack.state(2, 16, 32)
-    args = lambda x, y0, y1, fl: (x, y0, y1, stack.table.data_ptr(), 2, 2, 16, 32, None, 8, 8, fl, None, None, None)   # noqa: E731
+    flags, bufs = stack.flags(2, 16, 32), stack.state(2, 16, 32)
+    args = lambda x, y0, y1, fl: (x, y0, y1, stack.table.data_ptr(), 2, 2, 16, 32, None, 2, 8, 8, fl, None, None, None)   # noqa: E731
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), small.t.data_ptr(), bufs[1].t.data_ptr(), flags.data_ptr())) == -4
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), None, flags.data_ptr())) == -1
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), None)) == -1
+
+
+def test_engine_two_measurements_take_two_stack_launches():
+    """Two measurements per call = 16 images of 128 x 128 = two slices of one tile per CU: two stack launches per f-call (the default
+    stack_max_launches), bit-identical to the per-layer launches and - ranges are per image - to the two measurements reconstructed
+    alone."""
+    d = _clip("traffic_cacti.mat")
+    Phi = d["mask"][None].to(DEV)
+    y = d["meas"].permute(2, 0, 1)[1:3].contiguous().to(DEV)
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 8)[0].nonlinear_op
+    want = DEQSCIEngine(net, max_iter=8, use_graph=False, stack=False).reconstruct(y, Phi)
+    eng = DEQSCIEngine(net, max_iter=8, use_graph=False)
+    got = eng.reconstruct(y, Phi)
+    if _hip.split16_stack_images(128, 128) == 8:
+        assert eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1
+    assert torch.equal(got, want)
+    one = DEQSCIEngine(net, max_iter=8, use_graph=False)
+    assert torch.equal(one.reconstruct(y[1:2], Phi), want[1:2])
 
 
 def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
@@ -1005,7 +1058,7 @@ def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
     eng = DEQSCIEngine(net, max_iter=4, use_graph=False)
     assert torch.equal(eng.reconstruct(y, Phi), want) and eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1 > 0
     stack = eng.den._stacks[1]
-    flags, _ = stack.state(8, 128, 128)
+    flags = stack.flags(8, 128, 128)
     flags[32 * 37] -= 1000                                      # tile 37 of 256
     t0 = time.time()
     with pytest.warns(RuntimeWarning, match="stack launch timed out"):
@@ -1035,8 +1088,9 @@ def test_engine_stack_launch_matches_per_layer_launches(kind):
     assert ref.last_info["stack_launches"] == 0
     eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
     got = eng.reconstruct(y, Phi)
-    fits = _hip.split16_stack_fits(8, 256, 256) if kind == "SimpleCNN" else _hip.split16_stack_fits(8, 128, 128)
-    assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if fits else 0)
+    side = 256 if kind == "SimpleCNN" else 128                  # (FFDNet's layers work at half resolution)
+    fits = 0 < _hip.split16_stack_launches(8, side, side) <= eng.den.stack_max_launches
+    assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if fits else 0) and (fits or kind == "SimpleCNN")
     assert torch.equal(got, want)
     gr = DEQSCIEngine(net, max_iter=10, use_graph=True)
     for _ in range(3):                                          # eager warm-up, capture, replay

@@ -15,6 +15,8 @@ timeout 900 python bench.py --steps 3 --warmup 1 --denoiser SimpleCNN --no-cpu-b
   timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-graph --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 6 --warmup 2 --batch-per-gpu 1 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
+  timeout 900 python bench.py --steps 4 --warmup 2 --batch-per-gpu 2 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
+  timeout 900 python bench.py --steps 4 --warmup 2 --batch-per-gpu 2 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --batch-per-gpu 32 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --global-batch 64 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 3 --warmup 1 --act-range fixed --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{" ) > $O/r04_bench_other_shapes.jsonl
