@@ -1752,8 +1752,9 @@ def test_engine_conv_layout_and_kernel_choice():
     assert not torch.equal(a, c) and rel_l2(a.cpu().numpy(), c.cpu().numpy()) < 2e-5
     e22 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="f22")
     assert torch.equal(e22.reconstruct(ys, Phi), c)
-    # the default: split-fp16 at this size
-    dflt = DEQSCIEngine(net, max_iter=6, use_graph=False)
+    # the default: split-fp16 at this size (stack=False: a launch per layer, so that the hook sees every layer - two measurements would
+    # otherwise go out as two stack launches per f-call; es16 below takes those, bit-identically)
+    dflt = DEQSCIEngine(net, max_iter=6, use_graph=False, stack=False)
     assert dflt.conv64 == "auto" and dflt.conv64_policy == "fast" and dflt.conv64_f22_calls is None
     seen = []
     _hip.CONV64_EVENT_HOOK = lambda kind, n, H, W: seen.append(kind)
@@ -1765,7 +1766,7 @@ def test_engine_conv_layout_and_kernel_choice():
         assert not torch.equal(s_, c) and rel_l2(s_.cpu().numpy(), c.cpu().numpy()) < 2e-5
         # conv64_f22_calls = K: the first K f-calls on F(2x2,3x3), the rest on the policy's kernel; K >= all calls == "f22" bit for bit
         del seen[:]
-        mixed = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64_f22_calls=3)
+        mixed = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64_f22_calls=3, stack=False)
         mixed.reconstruct(ys, Phi)
         assert seen == ["f22"] * 39 + ["s16"] * (13 * (mixed.last_info["f_calls"] - 3))
         allf = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64_f22_calls=100)
