@@ -524,7 +524,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0, 0.0f, 0.0f, 0};
     char* const y_even = y;
     const float* const ranges = in_amax;                        // (STACK) the run's slot table [layer][image]
-    const int n_img = range_stride;                            // (STACK) floats between two layers' rows of the slot table (>= the launch's images: a launch may be a slice of a batch)
+    const int n_img = range_stride;                            // (STACK) floats between two layers' rows of the slot table (a launch may be a slice of a batch)
     unsigned fbase = 0, fgiveup = 0;
     if (STACK) {
         const StackLayer l0 = layers[0];                       // (wave-uniform: scalar loads)
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             // The neighbours finish within a fraction of a microsecond of this tile, and a poll is a round trip to memory (~1 us under the
             // layer's store burst): one poll at a time almost always needs two.  So STACK_POLLS polls are kept in flight, one every ~200
             // cycles, and the last neighbour's word is seen half a round trip after it lands.  Loads return in order: with STACK_POLLS
-            // outstanding - this wave has no other memory operation in flight; the tile's own word is published by wave 1 - the oldest
+            // outstanding - this wave has no other memory operation in flight: the tile's own word is published by wave 2, the bias read by wave 1 - the oldest
             // has landed once vmcnt <= STACK_POLLS - 1.
             if (!fgiveup) {
                 unsigned v[STACK_POLLS], spins = 0;
