@@ -792,6 +792,8 @@ class Split16Stack:
         st = self._state.get(("out", n, H, W))
         if st is None:
             dev = self.table.device
+            for key in [k for k in self._state if k[0] == "out"]:      # one live batch shape at a time (2 x 256 bytes per pixel and image)
+                del self._state[key]
             st = self._state[("out", n, H, W)] = (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev))
         return st
 
