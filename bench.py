@@ -77,7 +77,7 @@ def parity_spot_check(args, dev, H, W, B, n_meas=2, iters=10):
         args.iters = saved
     y, Phi, _ = make_batch(0, n_meas, H, W, B, 1234, dev)
     kinds = set()
-    hook, _hip.CONV64_EVENT_HOOK = _hip.CONV64_EVENT_HOOK, (lambda k, n, h, w: kinds.add(k))
+    hook, _hip.CONV64_EVENT_HOOK = _hip.CONV64_EVENT_HOOK, (lambda k, n, h, w, layers=1: kinds.add(k))
     try:
         rec = eng.reconstruct(y, Phi).cpu()
     finally:
@@ -202,7 +202,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-winograd", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
-    ap.add_argument("--stack-max-launches", type=int, default=None, help="a run of 64->64 layers goes out as stack launches up to this many slices of the batch (A/B)")
+    ap.add_argument("--stack-per-launch", type=int, default=None, help="images per stack launch (A/B; default: the engine's choice)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -231,12 +231,13 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
         kw["act_range"] = args.act_range
     if args.no_stack:
         kw["stack"] = False
-    if args.stack_max_launches is not None:
-        kw["stack_max_launches"] = args.stack_max_launches
-    return DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
-                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
-                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
-                        conv64=args.conv64 if conv64 is None else conv64, conv64_f22_calls=args.conv64_f22_calls if f22_calls == "args" else f22_calls, **kw)
+    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
+                       channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
+                       fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
+                       conv64=args.conv64 if conv64 is None else conv64, conv64_f22_calls=args.conv64_f22_calls if f22_calls == "args" else f22_calls, **kw)
+    if args.stack_per_launch is not None:
+        eng.den.stack_per_launch = args.stack_per_launch
+    return eng
 
 
 def make_step(eng, y_local, Phi_local, M, gather_timer):
@@ -281,7 +282,7 @@ def run_rank(args):
             step()
     timing = not (selftest or args.no_kernel_timing or graph_mode) and rank == 0
     timer = None
-    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0}
+    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0, "s16stack": 0}
     if timing:
         timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
         conv_timers = {k: _hip.KernelTimer(capacity=400) for k in conv_launches}   # a sample of launches of each kernel is enough
@@ -294,11 +295,11 @@ def run_rank(args):
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
 
-        def conv_hook(kind, n, H, W):                          # _hip.CONV64_EVENT_HOOK: a (start, stop) event pair per 64->64 launch
-            if not timing_on[0]:
+        def conv_hook(kind, n, H, W, layers=1):                # _hip.CONV64_EVENT_HOOK: a (start, stop) event pair per 64->64 launch
+            if not timing_on[0]:                               # ("s16stack": ONE launch = `layers` layers over a slice of n images)
                 return None
             conv_launches[kind] += 1
-            conv_shape[kind] = [n, H, W]
+            conv_shape[kind] = [n, H, W, layers]
             return conv_timers[kind].pair()
         _hip.CONV64_EVENT_HOOK = conv_hook
 
@@ -412,22 +413,27 @@ def run_rank(args):
             cms = ct.durations_ms()
             if not cms:
                 continue
-            nimg, ch, cw = conv_shape[kind]
-            direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg
-            mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS), "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
+            nimg, ch, cw, nlay = conv_shape[kind]
+            direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg * nlay      # (a stack launch: all its layers)
+            mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "s16stack": (3.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS),
+                          "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
             cavg = 1e-3 * sum(cms) / len(cms)
             share = cavg * conv_launches[kind] / elapsed
             wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
-            for wname in {"s16": ("r04_pmc_conv_s16.json", "r03_pmc_conv_s16.json"), "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
+            for wname in {"s16": ("r04_pmc_conv_s16.json", "r03_pmc_conv_s16.json"), "s16stack": ("r04_pmc_conv_s16_stack.json",),
+                          "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
                           "f22": ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")}[kind]:
                 wfile = os.path.join(ROOT, "profiles", wname)
                 if wtraffic is None and os.path.exists(wfile):
                     with open(wfile) as fh:
                         rec = json.load(fh)
-                    if rec.get("shape") == [nimg, 64, ch, cw]:
+                    if rec.get("shape") == [nimg, 64, ch, cw] and rec.get("layers", 1) == nlay:
                         wtraffic = rec["hbm_bytes_per_launch"]
-            kname = {"s16": "deqsci::s16::conv_s16_kernel (conv3x3 64->64 + bias + ReLU, direct convolution on the f16 matrix cores: fp32 operands as hi + lo "
+            kname = {"s16": "deqsci::s16::conv_s16_kernel<0, 0, 0> (conv3x3 64->64 + bias + ReLU, direct convolution on the f16 matrix cores: fp32 operands as hi + lo "
                             "fp16 pairs, three MFMAs per product, fp32 accumulation)",
+                     "s16stack": f"deqsci::s16::conv_s16_kernel<0, 0, 1> (the same arithmetic; ONE launch = the denoiser's {nlay} consecutive conv3x3 64->64 + bias + ReLU "
+                                 f"layers over a slice of {nimg} images, tiles synchronised by per-tile progress words, the slice's activations resident in the "
+                                 "Infinity Cache; flops and time are the whole launch's)",
                      "f44": "deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
                      "f22": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)"}[kind]
             forms[kind] = {"kernel": kname,
@@ -439,8 +445,11 @@ def run_rank(args):
                            "achieved_useful": direct / cavg / 1e12, "frac_useful": direct / cavg / 1e12 / peak,
                            "avg_launch_us": 1e6 * cavg, "launches_timed": len(cms), "launches_per_step": conv_launches[kind] // max(args.steps, 1),
                            "share_of_step_time": round(share, 3),
+                           "layers_per_launch": nlay, "images_per_launch": nimg,
                            "note": {"s16": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; on random operands the kernel runs against the chip's power limit "
                                            "(1.9-2.0 GHz, not 2.4): see DESIGN.md section 6",
+                                    "s16stack": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; the launch runs against the chip's power limit (1.6 GHz, not 2.4): "
+                                                "see DESIGN.md section 6.4",
                                     "f44": "F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA work",
                                     "f22": "F(2x2,3x3): the launcher's choice below one wave of 16 x 32 block tiles"}[kind]}
         if forms:

@@ -47,7 +47,6 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_timed_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_split16_stack_fits": [_i64, _i64, _i64],
     "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
@@ -60,7 +59,7 @@ SIGNATURES = {
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
 }
 OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
-                 "deqsci_partials_bytes", "deqsci_gram_bytes", "deqsci_conv3x3_c64_split16_stack_images")
+                 "deqsci_partials_bytes", "deqsci_gram_bytes")
 
 
 class DeqsciHipError(RuntimeError):
@@ -88,8 +87,6 @@ def load():
     lib.deqsci_version.restype = ctypes.c_char_p
     lib.deqsci_error_string.restype = ctypes.c_char_p
     lib.deqsci_error_string.argtypes = [_int]
-    lib.deqsci_conv3x3_c64_split16_stack_images.restype = _i64
-    lib.deqsci_conv3x3_c64_split16_stack_images.argtypes = [_i64, _i64]
     lib.deqsci_anderson_chunks.restype = _i64
     lib.deqsci_anderson_chunks.argtypes = [_i64, _i64]
     lib.deqsci_partials_bytes.restype = ctypes.c_size_t
@@ -460,11 +457,18 @@ ACT_NHWC, ACT_BLK32 = 0, 1
 CONV64_EVENT_HOOK = None
 
 
-def _hook_events(kind, n, H, W, events):
+def _hook_events(kind, n, H, W, events, layers=1):
+    """kind "s16stack": one launch that runs `layers` 64->64 layers over n images; the hook is told through its `layers` keyword (a hook
+    that does not take it is not asked about those launches)."""
     if events is not None:
         return events
     if CONV64_EVENT_HOOK is not None:
-        return CONV64_EVENT_HOOK(kind, n, H, W)
+        if layers == 1:
+            return CONV64_EVENT_HOOK(kind, n, H, W)
+        try:
+            return CONV64_EVENT_HOOK(kind, n, H, W, layers=layers)
+        except TypeError:
+            return None
     return None
 
 
@@ -817,29 +821,26 @@ class Split16Stack:
         return bad
 
 
-def split16_stack_fits(n, H, W):
-    """Whether a launch of n images of H x W is at most one block tile per CU - what ONE deqsci_conv3x3_c64_split16_stack launch takes."""
-    return bool(load().deqsci_conv3x3_c64_split16_stack_fits(n, H, W))
+STACK_SLICE_BYTES = 128 << 20      # activation bytes of one stack launch: its two ping-pong buffers share the 256 MiB Infinity Cache
 
 
-def split16_stack_images(H, W):
-    """Images of H x W that make at most one block tile per CU: what ONE stack launch takes (0: not even one image)."""
-    return int(load().deqsci_conv3x3_c64_split16_stack_images(H, W))
+def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES):
+    """Images per stack launch for a batch of n images of H x W: as many as keep one activation (256 bytes per pixel) within `slice_bytes`
+    (32 images of 128 x 128), the batch cut into equal slices (40 images: 20 + 20, not 32 + 8).  Measured on MI355X at 256 x 256 x 8,
+    FFDNet: 143-145 frames/s with slices of 16-32 images at every batch size from 2 measurements up, 138-141 with slices of 40-64
+    (and 138-141 with a launch per layer)."""
+    per = max(1, int(slice_bytes) // (H * W * 256))
+    launches = -(-n // per)
+    return -(-n // launches)
 
 
-def split16_stack_launches(n, H, W):
-    """How many stack launches a batch of n images of H x W goes out as (slices of split16_stack_images images), 0 when one image does
-    not fit."""
-    per = split16_stack_images(H, W)
-    return 0 if per == 0 else -(-n // per)
-
-
-def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None):
-    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack), each launch a whole run (csrc/conv_s16.hip, STACK: workgroup = tile, a
-    layer of a tile waits for the layer before of its eight neighbours) over as many images as make one block tile per CU - a batch of
-    more images goes out as slices, one launch after the other; ranges: the (n_layers + 1, n) range slots of the run - its input's first -
-    or None (fixed exponents: the input's, then 2^8).  Returns the Sp16 the last layer wrote (one of the stack's two buffers of this
-    shape).  stack.timed_out() afterwards tells whether a wait gave up (foreign work on the device's CUs): the result is invalid then."""
+def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None):
+    """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack), each launch a whole run (csrc/conv_s16.hip, STACK: the persistent
+    workgroups walk their tiles layer after layer, a tile waiting for the layer before of itself and its eight neighbours) over a slice
+    of the batch - per_launch images (None: split16_stack_per_launch, slices that fit the Infinity Cache), one launch after the other;
+    ranges: the (n_layers + 1, n) range slots of the run - its input's first - or None (fixed exponents: the input's, then 2^8).
+    Returns the Sp16 the last layer wrote (one of the stack's two buffers of this shape).  stack.timed_out() afterwards tells whether a
+    wait gave up (foreign work on the device's CUs): the result is invalid then."""
     if not isinstance(x, Sp16) or not isinstance(stack, Split16Stack) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
         raise DeqsciHipError("conv3x3_c64_split16_stack: a contiguous Sp16 GPU activation and a Split16Stack are required")
     n, H, W = x.n, x.H, x.W
@@ -850,14 +851,14 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None):
         raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, {n}) tensor on the input's device")
     if (ranges is None) != (x.rng is None):
         raise DeqsciHipError("conv3x3_c64_split16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
-    per = split16_stack_images(H, W)
-    if per == 0:
-        _check(-4, "conv3x3_c64_split16_stack (one image is more than one block tile per CU)")
+    per = split16_stack_per_launch(n, H, W) if per_launch is None else int(per_launch)
+    if per <= 0:
+        raise DeqsciHipError("conv3x3_c64_split16_stack: per_launch must be positive")
     bufs = stack.state(n, H, W)
-    ev = events or (None, None)
     with _dev(x.t):
         for a in range(0, n, per):
             m = min(per, n - a)
+            ev = _hook_events("s16stack", m, H, W, events, layers=stack.n_layers) or (None, None)
             _check(load().deqsci_conv3x3_c64_split16_stack(x.t[a:a + m].data_ptr(), bufs[0].t[a:a + m].data_ptr(), bufs[1].t[a:a + m].data_ptr(),
                                                            stack.table.data_ptr(), stack.n_layers, m, H, W,
                                                            None if ranges is None else ranges.data_ptr() + 4 * a, n, x.exp, SP16_DEFAULT_EXP,

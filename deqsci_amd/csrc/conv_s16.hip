@@ -117,16 +117,21 @@ __device__ __forceinline__ int mdiv(int t, uint32_t mg, uint32_t sh) { return (i
 // result does not depend on what else is in the batch: image i of the input holds 2^e_in x, e_in from in_amax[i] (or in_exp), of the sp16
 // output 2^e_out y, e_out from out_amax[i] (or out_exp); a tile's scales are formed where its output descriptor is (tile_done)
 //
-// STACK = 1: a RUN of n_layers 64->64 layers in ONE launch, for launches of at most ONE block tile per CU (the reference's usage: one
-// measurement per call, 8 x 128 x 128 = 256 tiles) - where a layer is a single tile per workgroup, nothing overlaps a launch's dispatch,
-// its first fetch and its last stores, and a kernel boundary per layer costs a fifth of the layer.  Workgroup = tile, for all the layers;
-// DATAFLOW synchronisation, no grid-wide barrier: a tile of layer l + 1 needs layer l of its EIGHT NEIGHBOURS and nothing else, so every
-// tile has a progress word (flags[32 tile] = layers finished - a 128-byte line per tile -, counted on from launch to launch: never reset) which its workgroup writes once
-// its stores have been acknowledged and its neighbours poll.  Coherence without cache maintenance: the activations are stored
-// write-through and fetched with agent-scope loads (sc1 - the tiles of one image may sit on different XCDs, whose L2s do not snoop each other),
-// the words are agent-scope atomics.  Layer l reads x (l = 0) or the buffer layer l - 1 wrote and writes y (l even) / y2 (l odd); its
-// weights, bias, w_exp, relu come from `layers`, its ranges from in_amax[l range_stride + image] -> in_amax[(l + 1) range_stride + image]
-// (in_amax = the run's slot table, or NULL: in_exp for the run's input, out_exp for every output).  flags[32 n_tiles] != 0: a wait timed out (a workgroup of the
+// STACK = 1: a RUN of n_layers 64->64 layers in ONE launch.  The persistent workgroups (one per CU, all resident) walk their tiles layer
+// after layer with DATAFLOW synchronisation instead of kernel boundaries: a tile of layer l + 1 needs layer l of itself and its EIGHT
+// NEIGHBOURS and nothing else, so every tile has a progress word (flags[32 tile] = layers finished - a 128-byte line per tile -, counted
+// on from launch to launch: never reset), written once the tile's stores have been acknowledged and polled by whoever reads the tile.
+// With several tiles per workgroup the words a tile waits for were written a tile-time or more ago: ONE poll in the shadow of stage 2
+// says so and the next tile's first chunk is fetched during stage 3 as within a layer - the layers run into one another without a
+// bubble.  With ONE tile per workgroup (one measurement per call) the next tile is this one, a layer on, and its neighbours finish when
+// it does: the workgroup waits for its stores, publishes, waits for the nine words, fetches (the slow path, ~10 k cycles per layer
+// against ~14 k for a kernel boundary).  Coherence without cache maintenance: the activations are stored write-through and fetched with
+// agent-scope loads (sc1 - the tiles of one image may sit on different XCDs, whose L2s do not snoop each other), the words are
+// agent-scope atomics.  What the single launch buys beyond the bubbles: a SLICE of a batch (32 images of 128 x 128: 128 MiB per
+// activation) runs its 13 layers back to back, its ping-pong buffers staying in the 256 MiB Infinity Cache - the caller slices.
+// Layer l reads x (l = 0) or the buffer layer l - 1 wrote and writes y (l even) / y2 (l odd); its weights, bias, w_exp, relu come from
+// `layers`, its ranges from in_amax[l range_stride + image] -> in_amax[(l + 1) range_stride + image] (in_amax = the run's slot table,
+// or NULL: in_exp for the run's input, out_exp for every output).  flags[32 n_tiles] != 0: a wait timed out (a workgroup of the
 // launch was not resident) - the launch never hangs, the result is invalid and says so.
 struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
 constexpr unsigned STACK_SPIN_LIMIT = 1u << 21;                // polls, one every ~0.1 us: a wait gives up after a quarter of a second
@@ -144,7 +149,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                                                           int range_stride) {
     __shared__ __attribute__((aligned(16))) char Raw[2 * RAW_BUF];
     __shared__ __attribute__((aligned(16))) char Wt[2 * W_CHUNK];
-    __shared__ __attribute__((aligned(16))) float bias_s[64];
+    __shared__ __attribute__((aligned(16))) float bias_s[STACK ? 128 : 64];     // (STACK: per layer parity - a wave may be a tile ahead of its partner's epilogue)
+    __shared__ uint32_t ready_s;                               // (STACK) wave 0's verdict on the next tile's inputs, for all waves
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     int t_first, t_step, t_end;
@@ -175,12 +181,12 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         slot_rc[j] = s < RAW_SLOTS ? (uint32_t)(row | (p << 5) | (col << 8)) : 0xFFFFFF00u;
     }
     int ft_py0 = 0, ft_px0 = 0;
-    auto fetch_tile_uniform = [&](int t) __attribute__((always_inline)) {
+    auto fetch_tile_uniform = [&](int t, const char* xb) __attribute__((always_inline)) {
         const int n = mdiv(t, mg_img, sh_img), r = t - n * (tiles_x * tiles_y);
         const int by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
         // the descriptor starts RAW_BIAS bytes BELOW the image: four of a wave's instructions differ only in their immediate offset, which
         // the hardware adds to the LDS AND the global address; the per-lane offsets take it back out
-        const uint64_t base = (uint64_t)(x + (int64_t)n * HW * 256) - RAW_BIAS;
+        const uint64_t base = (uint64_t)(xb + (int64_t)n * HW * 256) - RAW_BIAS;
         rsrc.x = (int)uniform((uint32_t)base);
         rsrc.y = (int)uniform((uint32_t)(base >> 32));
         rsrc.z = (int)uniform((uint32_t)(HW * 256) + RAW_BIAS);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             }
         }
     };
-    int se_in = 0, se_out = 0;                                 // (STACK) the exponents of the tile's image: input and output of the current layer
+    int L = 0;                                                 // (STACK) the layer the workgroup is on
     auto tile_done = [&](int t) -> Done {
         Done d;
         const int n = mdiv(t, mg_img, sh_img), rr_ = t - n * (tiles_x * tiles_y);
@@ -358,9 +364,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         d.orsrc.z = (int)uniform((uint32_t)(HW * 256));
         d.orsrc.w = 0x00020000;
         {
-            // (wave-uniform: scalar loads; the measuring launch: true units; STACK: one tile, its exponents are formed between the layers)
-            const int e_in = STACK ? se_in : in_amax ? sp16_act_exp(in_amax[n]) : in_exp;
-            const int e_out = STACK ? se_out : (OUT_F32 || TRACK) ? 0 : out_amax ? sp16_act_exp(out_amax[n]) : out_exp;
+            // (wave-uniform: scalar loads; the measuring launch: true units; STACK: in_amax is the run's slot table [layer][image])
+            const int e_in = STACK ? (in_amax ? sp16_act_exp(in_amax[(int64_t)L * range_stride + n]) : L == 0 ? in_exp : out_exp)
+                                   : in_amax ? sp16_act_exp(in_amax[n]) : in_exp;
+            const int e_out = STACK ? (in_amax ? sp16_act_exp(in_amax[(int64_t)(L + 1) * range_stride + n]) : out_exp)
+                                    : (OUT_F32 || TRACK) ? 0 : out_amax ? sp16_act_exp(out_amax[n]) : out_exp;
             d.oscale = sp16_pow2(e_out - e_in - w_exp);
             d.bscale = sp16_pow2(e_out);
             d.img = n;
@@ -381,6 +389,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     };
 
     const char* Wnx = nullptr;                                 // (STACK) the next layer's weights
+    bool s3_raw = false;                                       // (STACK) stage 3 may fetch the next tile's first activation chunk (the tiles it reads are written)
+    const char* s3_w = nullptr;                                // (STACK) ... and whose weights go with it (this layer's or the next one's)
     // One stage = chunk c of the current tile: Raw[c & 1], Wt[c & 1] hold it; chunk c + 1 (of this tile, or chunk 0 of
     // the next one) is fetched into the other buffers from inside the MFMA stream, one DMA instruction at a time.
     // `before_barrier` runs between the stage's last MFMA and its barrier, `shadow(i)` inside group i behind four of its MFMAs.
@@ -407,10 +417,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         };
         auto dma = [&](int j) __attribute__((always_inline)) {    // the next chunk: 10 DMA instructions, two per group in the first five groups
             if (more && j < 2 * RAW_INSTR && !(S16_ABL & 1)) {
-                // (STACK, last stage: the next chunk is chunk 0 of the NEXT LAYER - its weights can come now, its activations only once the
-                // neighbours have written them)
-                if (j < RAW_INSTR) { if (!(STACK && c == 3)) raw_piece(cn, nb, j); }
-                else w_piece((STACK && c == 3) ? Wnx : Wp, cn, nb, j - RAW_INSTR);
+                // (STACK, last stage: the next chunk is chunk 0 of the next tile - maybe of the NEXT LAYER: its weights can come now, its
+                // activations only if the tiles it reads have been written: s3_raw)
+                if (j < RAW_INSTR) { if (!(STACK && c == 3) || s3_raw) raw_piece(cn, nb, j); }
+                else w_piece((STACK && c == 3) ? s3_w : Wp, cn, nb, j - RAW_INSTR);
             }
         };
         S16_MARK(4);
@@ -494,8 +504,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #endif
             if (more && i < 2 * RAW_INSTR && !(S16_ABL & 1)) {   // the next chunk: 10 DMA instructions, one per group in the FIRST half of the
                                                                // stage - the last one needs the second half (an HBM round trip) to land
-                if (i < RAW_INSTR) { if (!(STACK && c == 3)) raw_piece(cn, nb, i); }
-                else w_piece((STACK && c == 3) ? Wnx : Wp, cn, nb, i - RAW_INSTR);
+                if (i < RAW_INSTR) { if (!(STACK && c == 3) || s3_raw) raw_piece(cn, nb, i); }
+                else w_piece((STACK && c == 3) ? s3_w : Wp, cn, nb, i - RAW_INSTR);
             }
             shadow(i);                                         // (tile bookkeeping rides here, behind four of the group's MFMAs)
 #if S16_INTERLEAVE
@@ -523,16 +533,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #endif
     const Done none = {(i32x4){0, 0, 0, 0}, {RAW_OOB, RAW_OOB}, 0, 0.0f, 0.0f, 0};
     char* const y_even = y;
-    const float* const ranges = in_amax;                        // (STACK) the run's slot table [layer][image]
-    const int n_img = range_stride;                            // (STACK) floats between two layers' rows of the slot table (a launch may be a slice of a batch)
     unsigned fbase = 0, fgiveup = 0;
     if (STACK) {
         const StackLayer l0 = layers[0];                       // (wave-uniform: scalar loads)
         Wp = l0.w; bias = l0.bias; w_exp = l0.w_exp; relu = l0.relu;
-        const int img0 = mdiv(t_first, mg_img, sh_img);
-        se_in = ranges ? sp16_act_exp(ranges[img0]) : in_exp;
-        se_out = ranges ? sp16_act_exp(ranges[n_img + img0]) : out_exp;
-        fbase = __hip_atomic_load(flags + (int64_t)t_first * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // where the launch before left the tile's word
+        fbase = __hip_atomic_load(flags + (int64_t)t_first * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // where the launch before left the words (all the same)
         fgiveup = __hip_atomic_load(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // an earlier time-out: no more waiting
     }
     // ---- prologue: bias, chunk 0 of the first tile
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
 #else
     if (wave == 0) bias_s[lane] = bias ? bias[lane] : 0.0f;     // (scaled per tile: the sp16 output of image i carries 2^e_out(i) y, so does its bias)
 #endif
-    fetch_tile_uniform(t_first);
+    fetch_tile_uniform(t_first, x);
 #if S16_TILE_VOFF
 #pragma unroll
     for (int j = 0; j < RAW_INSTR; ++j) voff[j] = fetch_lane_offset(j);
@@ -560,12 +565,29 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
     // pinned MFMA / operand-read / DMA interleave and the tile bookkeeping moved into MFMA shadows took a wave's cycles per launch from
     // 294 k to 280 k (tools/s16_stamps.py, profiles/r03_s16_stamps_*.txt) and the launch from 183 to 180 us - the clock gave the rest back.)
     S16_MARK(4);
+    // (STACK) the words of the nine tiles the inputs of tile t come from - its own and its eight neighbours' -, one per lane 0..8 (a lane
+    // without a neighbour: the tile's own)
+    auto flag_word = [&](int t) __attribute__((always_inline)) -> const unsigned* {
+        const int tpi = tiles_x * tiles_y;
+        const int n = mdiv(t, mg_img, sh_img), r = t - n * tpi, by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
+        const int k = lane < 9 ? lane : 4;
+        const int ny = by + k / 3 - 1, nx = bx + k % 3 - 1;
+        const bool ok = ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x;
+        return flags + (int64_t)(ok ? n * tpi + ny * tiles_x + nx : t) * STACK_FLAG_STRIDE;
+    };
+    int pend_t = -1;                                           // (STACK) a finished tile whose word is published behind the next stage barrier its stores are waited for at
+    unsigned pend_v = 0;
+    const unsigned* pf = nullptr;                              // (STACK, wave 0) the words the next tile waits for, and what the poll of stage 2 read
+    unsigned pv = 0;
 #pragma unroll 1
-    for (int L = 0; L < (STACK ? n_layers : 1); ++L) {
-    const bool more_layers = STACK && L + 1 < n_layers;
-    if (more_layers) Wnx = layers[L + 1].w;
-#pragma unroll 1
-    for (int t_cur = t_first; t_cur < t_end; t_cur += t_step) {
+    for (int t_cur = t_first;;) {
+        // what comes next: the workgroup's next tile of this layer, or its first tile of the next layer
+        const bool new_layer = STACK && !(t_cur + t_step < t_end);
+        const int t_next = new_layer ? t_first : t_cur + t_step;
+        const bool next = STACK ? (!new_layer || L + 1 < n_layers) : t_next < t_end;
+        const int L_next = L + (new_layer ? 1 : 0);
+        const bool poll = STACK && next && L_next > 0;         // (a tile of layer 0 reads the run's input: nothing to wait for)
+        if (STACK && new_layer && next) Wnx = layers[L + 1].w;
 #if !(S16_ZEROC && S16_ROWS4)
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -575,18 +597,40 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 for (int i = 0; i < 16; ++i) acc[0][g][r][i] = acc[CH1][g][r][i] = 0.0f;
 #endif
         stage(0, true, nothing, no_shadow);
-        stage(1, true, nothing, no_shadow);
-        const bool next = t_cur + t_step < t_end;
+        // (STACK) behind stage 0's wait and barrier every store of the tile before has been acknowledged: its word goes out
+        stage(1, true, nothing, [&](int i) __attribute__((always_inline)) {
+            if (STACK && i == 0 && pend_t >= 0 && wave == 2 && lane == 0)
+                __hip_atomic_store(flags + (int64_t)pend_t * STACK_FLAG_STRIDE, pend_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        });
+        pend_t = -1;
         // the NEXT tile's fetch descriptor and origin, in the shadow of this stage's MFMA group 10 (its own DMA instructions - the last ones
         // that use this tile's - sit in groups 0..9; the per-lane offsets are formed where each DMA instruction is issued).  Between the
         // tiles this arithmetic cost every wave 1.5 us with the matrix pipe idle
-        stage(2, true, nothing, [&](int i) __attribute__((always_inline)) {
-            if (STACK) return;                                 // (the same tile again, of another buffer: set up behind the wait for the neighbours)
-            if (i == 10) fetch_tile_uniform(t_cur + t_step);
+        // (STACK) ... and ONE poll of the words of the tiles the next tile reads (wave 0: asked in group 0, landed by the stage's wait, the
+        // verdict through LDS behind its barrier): with several tiles per workgroup they were written a tile or more ago
+        stage(2, true, [&]() __attribute__((always_inline)) {
+            if (STACK && wave == 0) {
+                const unsigned target = fbase + (unsigned)L_next;
+                const bool late = poll && lane < 9 && (int)(pv - target) < 0;
+                const uint32_t ok = (!poll || fgiveup) ? 1u : (__builtin_amdgcn_ballot_w64(late) == 0 ? 1u : 0u);
+                if (lane == 0) ready_s = ok;
+            }
+        }, [&](int i) __attribute__((always_inline)) {
+            if (STACK && i == 0 && wave == 0 && poll) {
+                pf = flag_word(t_next);
+                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(pv) : "v"(pf) : "memory");
+            }
+            if (i == 10 && next) fetch_tile_uniform(t_next, (STACK && new_layer) ? y : x);
 #if S16_TILE_VOFF
             if (i >= 11 && i < 11 + RAW_INSTR) voff[i - 11] = fetch_lane_offset(i - 11);     // (this tile's last raw pieces went out in groups 0..4)
 #endif
         });
+        bool ready = true;
+        if (STACK) {
+            ready = uniform(ready_s) != 0;
+            s3_raw = next && ready;
+            s3_w = new_layer ? Wnx : Wp;
+        }
         // The epilogue, out of step between the two waves of a SIMD.  Waves 0-3 (one per SIMD, dispatched first: the issue arbiter favours
         // them, they finish a stage's MFMAs in 55 % of its time and idle at the barrier) run their epilogue BEFORE the last stage's barrier,
         // under the MFMAs their SIMD partner is still issuing; waves 4-7 run theirs BEHIND it, under the partner's first MFMAs of the next
@@ -598,14 +642,15 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
                 // the lane's 32 bias values in one burst of LDS reads (operand registers are free here): read piece by piece, each read
                 // was a round trip through an LDS the partner wave keeps busy - 16 of them made the epilogue twice as long
                 f32x4 bz4[2][4];
+                const __attribute__((address_space(3))) float* bsl = (const __attribute__((address_space(3))) float*)bias_s + (STACK ? 64 * (L & 1) : 0);
 #if S16_ROWS4
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bz4[0][q] = bz4[1][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * wg + 8 * q + 4 * kb) * d.bscale;
+                for (int q = 0; q < 4; ++q) bz4[0][q] = bz4[1][q] = *reinterpret_cast<const lds_f32x4*>(bsl + 32 * wg + 8 * q + 4 * kb) * d.bscale;
 #else
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>((const __attribute__((address_space(3))) float*)bias_s + 32 * g + 8 * q + 4 * kb) * d.bscale;
+                    for (int q = 0; q < 4; ++q) bz4[g][q] = *reinterpret_cast<const lds_f32x4*>(bsl + 32 * g + 8 * q + 4 * kb) * d.bscale;
 #endif
                 float tmax = 0.0f;
 #pragma unroll
@@ -617,86 +662,93 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
             }
         };
 #if S16_EPI_LOCKSTEP
-        stage(3, STACK ? more_layers : next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
+        stage(3, next, nothing, [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
         epilogue();
 #else
-        stage(3, STACK ? more_layers : next, [&]() __attribute__((always_inline)) { if (wave < 4) epilogue(); },
+        stage(3, next, [&]() __attribute__((always_inline)) { if (wave < 4) epilogue(); },
               [&](int i) __attribute__((always_inline)) { if (i == 12) d = tile_done(t_cur); });
         if (wave >= 4) epilogue();
 #endif
         S16_MARK(3);
-    }
-    if (more_layers) {
-        // ---- between two layers of a STACK launch.  Every wave waits for its stores (write-through: acknowledged = visible to the device);
-        // behind the barrier one lane publishes the tile's progress and eight lanes wait for the neighbours', while the other waves
-        // switch to the next layer's parameters; then chunk 0 of the same tile of the buffer just written.
-        const StackLayer ln = layers[L + 1];                   // (scalar loads, under the wait for the stores)
-        const float nx_amax = ranges ? ranges[(int64_t)(L + 2) * n_img + mdiv(t_first, mg_img, sh_img)] : 0.0f;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        S16_MARK(5);
-        __syncthreads();
-        S16_MARK(6);
-        const unsigned target = fbase + (unsigned)(L + 1);
-        if (wave == 2 && lane == 0) __hip_atomic_store(flags + (int64_t)t_first * STACK_FLAG_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        x = y;
-        y = ((L + 1) & 1) ? y2 : y_even;
-        Wp = ln.w; bias = ln.bias; w_exp = ln.w_exp; relu = ln.relu;
-        se_in = se_out;
-        se_out = ranges ? sp16_act_exp(nx_amax) : out_exp;
+        if (STACK) {
+            const unsigned done_v = fbase + (unsigned)(L + 1);     // this tile's word once its stores have landed
+            if (new_layer && next) {
+                // the next tile is of the next layer: this wave's copy of the layer's parameters (the last stage fetched its first weight chunk)
+                const StackLayer ln = layers[L + 1];
+                x = y;
+                y = ((L + 1) & 1) ? y2 : y_even;
+                Wp = ln.w; bias = ln.bias; w_exp = ln.w_exp; relu = ln.relu;
 #ifndef S16_STAMP
-        if (wave == 1) bias_s[lane] = bias ? bias[lane] : 0.0f;
+                if (wave == 1) bias_s[64 * ((L + 1) & 1) + lane] = bias ? bias[lane] : 0.0f;
 #endif
-        fetch_tile_uniform(t_first);
-        if (wave == 0) {
-            const int tpi = tiles_x * tiles_y;
-            const int n = mdiv(t_first, mg_img, sh_img), r = t_first - n * tpi, by = mdiv(r, mg_tx, sh_tx), bx = r - by * tiles_x;
-            const int k = lane < 4 ? lane : lane + 1;          // lanes 0..7: the 3 x 3 neighbourhood without its centre
-            const int ny = by + k / 3 - 1, nx = bx + k % 3 - 1;
-            const bool valid = lane < 8 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x;
-            const unsigned* f = flags + (int64_t)(valid ? n * tpi + ny * tiles_x + nx : t_first) * STACK_FLAG_STRIDE;
-            // The neighbours finish within a fraction of a microsecond of this tile, and a poll is a round trip to memory (~1 us under the
-            // layer's store burst): one poll at a time almost always needs two.  So STACK_POLLS polls are kept in flight, one every ~200
-            // cycles, and the last neighbour's word is seen half a round trip after it lands.  Loads return in order: with STACK_POLLS
-            // outstanding - this wave has no other memory operation in flight: the tile's own word is published by wave 2, the bias read by wave 1 - the oldest
-            // has landed once vmcnt <= STACK_POLLS - 1.
-            if (!fgiveup) {
-                unsigned v[STACK_POLLS], spins = 0;
+            }
+            if (next && !ready) {
+                // ---- the tiles the next tile reads are not all written (always so with ONE tile per workgroup: the next tile is this one, a
+                // layer on, and its neighbours finish when it does).  Every wave waits for its stores (write-through: acknowledged = visible
+                // to the device); behind the barrier one lane publishes the tile's word and nine lanes wait for the words the next tile
+                // needs; then its first chunk.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                S16_MARK(5);
+                __syncthreads();
+                S16_MARK(6);
+                if (wave == 2 && lane == 0)
+                    __hip_atomic_store(flags + (int64_t)t_cur * STACK_FLAG_STRIDE, done_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wave == 0) {
+                    const unsigned target = fbase + (unsigned)L_next;
+                    const unsigned* f = flag_word(t_next);
+                    // The neighbours finish within a fraction of a microsecond of this tile, and a poll is a round trip to memory (~1 us under the
+                    // layer's store burst): one poll at a time almost always needs two.  So STACK_POLLS polls are kept in flight, one every ~200
+                    // cycles, and the last neighbour's word is seen half a round trip after it lands.  Loads return in order: with STACK_POLLS
+                    // outstanding - this wave has no other memory operation in flight: the tile's own word is published by wave 2, the bias read
+                    // by wave 1 - the oldest has landed once vmcnt <= STACK_POLLS - 1.
+                    if (!fgiveup) {
+                        unsigned v[STACK_POLLS], spins = 0;
 #pragma unroll
-                for (int q = 0; q < STACK_POLLS; ++q) {
-                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
-                    __builtin_amdgcn_s_sleep(3);
-                }
-                bool waiting = true;
-                while (waiting) {
-#pragma unroll
-                    for (int q = 0; q < STACK_POLLS; ++q) {
-                        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[q]) : "n"(STACK_POLLS - 1) : "memory");
-                        if (__builtin_amdgcn_ballot_w64(valid && (int)(v[q] - target) < 0) == 0) { waiting = false; break; }   // (wrap-safe: the words count on for ever)
-                        if (++spins > STACK_SPIN_LIMIT) {
-                            fgiveup = 1;
-                            if (lane == 0) __hip_atomic_fetch_or(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            waiting = false;
-                            break;
+                        for (int q = 0; q < STACK_POLLS; ++q) {
+                            asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
+                            __builtin_amdgcn_s_sleep(3);
                         }
-                        asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
-                        __builtin_amdgcn_s_sleep(3);
+                        bool waiting = true;
+                        while (waiting) {
+#pragma unroll
+                            for (int q = 0; q < STACK_POLLS; ++q) {
+                                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[q]) : "n"(STACK_POLLS - 1) : "memory");
+                                if (__builtin_amdgcn_ballot_w64(lane < 9 && (int)(v[q] - target) < 0) == 0) { waiting = false; break; }   // (wrap-safe: the words count on for ever)
+                                if (++spins > STACK_SPIN_LIMIT) {
+                                    fgiveup = 1;
+                                    if (lane == 0) __hip_atomic_fetch_or(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    waiting = false;
+                                    break;
+                                }
+                                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[q]) : "v"(f) : "memory");
+                                __builtin_amdgcn_s_sleep(3);
+                            }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the polls still in flight write registers)
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the polls still in flight write registers)
-            }
-        }
-        __syncthreads();
-        S16_MARK(7);
+                __syncthreads();
+                S16_MARK(7);
 #pragma unroll
-        for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        S16_MARK(8);
+                for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                S16_MARK(8);
+            } else {
+                pend_t = t_cur;                                // (its stores are waited for at the end of the next tile's stage 0, or at the end of the launch)
+                pend_v = done_v;
+            }
+            if (new_layer) ++L;
+        }
+        if (!next) break;
+        t_cur = t_next;
     }
-    }                                                          // (layers)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (STACK && threadIdx.x == 0)
-        __hip_atomic_store(flags + (int64_t)t_first * STACK_FLAG_STRIDE, fbase + (unsigned)n_layers, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (STACK) {                                               // the last tile's word (its stores: every wave's, hence the barrier)
+        __syncthreads();
+        if (pend_t >= 0 && threadIdx.x == 0)
+            __hip_atomic_store(flags + (int64_t)pend_t * STACK_FLAG_STRIDE, pend_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #ifdef S16_STAMP
     if (lane == 0)
         for (int i = 0; i < (STACK ? 9 : 5); ++i) st_out[((int)blockIdx.x * WAVES + wave) * (STACK ? 9 : 5) + i] = st_sum[i];
@@ -1044,15 +1096,6 @@ extern "C" int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_pack
 
 static_assert(sizeof(s16::StackLayer) == 24, "the layer table of deqsci_conv3x3_c64_split16_stack is three 8-byte words per layer");
 
-extern "C" int64_t deqsci_conv3x3_c64_split16_stack_images(int64_t H, int64_t W) {
-    if (H <= 0 || W <= 0) return 0;
-    return (int64_t)num_cus() / (ceil_div(W, s16::OUT_COLS) * ceil_div(H, s16::OUT_ROWS));
-}
-
-extern "C" int deqsci_conv3x3_c64_split16_stack_fits(int64_t n, int64_t H, int64_t W) {
-    return n > 0 && n <= deqsci_conv3x3_c64_split16_stack_images(H, W) ? 1 : 0;
-}
-
 extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
                                                 int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
                                                 void* flags, deqsci_stream_t stream, void* start_event, void* stop_event) {
@@ -1065,15 +1108,16 @@ extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even
     const int64_t tiles_x = ceil_div(W, s16::OUT_COLS), tiles_y = ceil_div(H, s16::OUT_ROWS);
     const int64_t n_tiles = n * tiles_x * tiles_y;
     if (H * W * 256 + s16::RAW_BIAS + 4096 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
-    // workgroup = tile, and every workgroup of the launch has to be RESIDENT (they wait for one another): one per CU - the kernel's 152 KB
-    // of LDS admit no second one - so never more tiles than CUs.  Larger launches have tiles to overlap and take a launch per layer.
-    if (n_tiles > (int64_t)num_cus()) return DEQSCI_ERR_UNSUPPORTED;
+    // every workgroup of the launch has to be RESIDENT (they wait for one another): one per CU - the kernel's 152 KB of LDS admit no
+    // second one - so never more workgroups than CUs; each walks its tiles layer after layer
+    if (n_tiles > (int64_t)INT32_MAX / (16 * 32)) return DEQSCI_ERR_UNSUPPORTED;
+    const int64_t resident = (int64_t)num_cus();
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t mg_img, sh_img, mg_tx, sh_tx;
     s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);
     s16_magic((uint32_t)tiles_x, &mg_tx, &sh_tx);
     hipEvent_t ev0 = static_cast<hipEvent_t>(start_event), ev1 = static_cast<hipEvent_t>(stop_event);
-    hipExtLaunchKernelGGL((s16::conv_s16_kernel<0, 0, 1>), dim3((unsigned)n_tiles), dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16),
+    hipExtLaunchKernelGGL((s16::conv_s16_kernel<0, 0, 1>), dim3((unsigned)(n_tiles < resident ? n_tiles : resident)), dim3(s16::TBW), 0, st, ev0, ev1, 0, static_cast<const char*>(x_sp16),
                           static_cast<const char*>(nullptr), static_cast<const float*>(nullptr), static_cast<char*>(y_even), (int)H, (int)W, 0, 0, ranges,
                           in_exp, static_cast<const float*>(nullptr), out_exp, static_cast<float*>(nullptr), (int)tiles_x, (int)tiles_y, (int)n_tiles,
                           mg_img, sh_img, mg_tx, sh_tx, static_cast<char*>(y_odd), static_cast<const s16::StackLayer*>(layers), n_layers,

@@ -64,18 +64,14 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True, stack=True, stack_max_launches=2):
+                 act_range="data", blk32=True, stack=True):
         from .networks import FFDNet
         self.net = net
-        # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch (_hip.conv3x3_c64_split16_stack) whenever the
-        # launch is at most one block tile per CU - one measurement of 256 x 256 x 8 per call, the reference's usage - where a kernel
-        # boundary per layer costs a fifth of the layer; bit-identical to the per-layer launches, which larger batches and the measuring
-        # f-call keep
+        # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch per slice of the batch
+        # (_hip.conv3x3_c64_split16_stack: tiles synchronised by per-tile progress words instead of kernel boundaries, slices that keep
+        # their activations in the Infinity Cache); bit-identical to the per-layer launches, which the measuring f-call keeps
         self.stack = bool(stack)
-        # ... and a batch of two measurements as two stack launches, one after the other (each the whole chip for its slice of the
-        # batch): 118 -> 124 frames/s; from three slices on the per-layer launches have tiles enough to overlap their own edges and win
-        # (128 vs 126 at three measurements, 135 vs 128 at eight)
-        self.stack_max_launches = int(stack_max_launches)
+        self.stack_per_launch = None                                # images per stack launch (None: _hip.split16_stack_per_launch; an A/B of the tools)
         self._stacks = {}                                           # first layer of a run -> _hip.Split16Stack
         self.stack_launches = 0
         self.fused_edges = fused_edges
@@ -201,6 +197,11 @@ class _Denoiser:
             return F.conv2d(self._run_layers(h, idx[:-1], fused), w, None, padding=1), b
         return self._run_layers(h, idx, fused)
 
+    # a run shorter than this keeps its per-layer launches: the stack launch earns its keep over many layers on a cache-resident slice
+    # (FFDNet's 13: 138.8 -> 144.8 frames/s); on SimpleCNN's two layers it costs 4 % (180.6 vs 188.7: agent-scope loads re-read the halo
+    # overlap from memory instead of the L2, and there is no kernel boundary worth saving between two 100 us launches)
+    STACK_MIN_LAYERS = 3
+
     def _stack_for(self, idx, device):
         """The Split16Stack of the run of layers idx (an H2D copy of its table: built by prepare(), never inside a hipGraph capture)."""
         st = self._stacks.get(idx[0])
@@ -220,12 +221,12 @@ class _Denoiser:
         return any(st.timed_out() for st in self._stacks.values())
 
     def _run_layers(self, h, idx, fused):
-        if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= 2 and self._native_out and not self._calibrating
-                and idx[0] in self._stacks and self._stacks[idx[0]].n_layers == len(idx) and (h.rng is None) == (self.ranges is None)
-                and 0 < _hip.split16_stack_launches(h.n, h.H, h.W) <= self.stack_max_launches):
+        if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= self.STACK_MIN_LAYERS and self._native_out and not self._calibrating
+                and idx[0] in self._stacks and self._stacks[idx[0]].n_layers == len(idx) and (h.rng is None) == (self.ranges is None)):
             # the whole run in one launch (per slice of the batch): sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
             self.stack_launches += 1
-            return _hip.conv3x3_c64_split16_stack(h, self._stack_for(idx, h.t.device), None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2])
+            return _hip.conv3x3_c64_split16_stack(h, self._stack_for(idx, h.t.device), None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2],
+                                                  per_launch=self.stack_per_launch)
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
             nxt = idx[pos + 1] if pos + 1 < len(idx) else None
@@ -277,7 +278,7 @@ class _Denoiser:
         if n_img is not None:
             self._alloc_ranges(n_img, device)
         run = self._middle_run() if (self.stack and torch.device(device).type == "cuda") else None
-        if run is not None and self.wino[run[0]].s16.packed.is_cuda:
+        if run is not None and len(run) >= self.STACK_MIN_LAYERS and self.wino[run[0]].s16.packed.is_cuda:
             self._stack_for(run, device)
         if self.tag == "ffdnet":
             t = self.sigma_table
@@ -372,7 +373,7 @@ class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
                  fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64",
-                 stack=True, stack_max_launches=2):
+                 stack=True):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if anderson_arith not in ("float64", "reference"):
@@ -405,8 +406,7 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack,
-                             stack_max_launches=stack_max_launches)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)

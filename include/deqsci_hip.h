@@ -217,24 +217,23 @@ int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const f
                                int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
                                const float* out_amax, int out_exp, float* track_amax, int out_f32,
                                deqsci_stream_t stream, void* start_event, void* stop_event);
-/* A RUN of n_layers such layers (the denoisers' 13 / 2 middle layers, each feeding the next) in ONE launch, for launches of at most one
- *     16 x 32 block tile per CU (deqsci_conv3x3_c64_split16_stack_images / _fits: the reference's one-measurement-per-call usage, 8
- *     images of 128 x 128 = 256 tiles; a batch of a few measurements goes out as that many launches, one after the other) - where a kernel boundary per layer costs a fifth of the layer.  Workgroup = tile for all the layers, with
- *     DATAFLOW synchronisation: a tile of layer l + 1 waits for layer l of its eight neighbour tiles only (one progress word per tile,
- *     agent-scope atomics; activations stored write-through and fetched with agent-scope loads - no cache maintenance, no grid-wide
- *     barrier).  Bit-identical to n_layers single launches.  layers: DEVICE table of n_layers x { const void* w_packed; const float* bias
- *     (may be NULL); int32 w_exp; int32 relu } (24 bytes each).  Layer l reads x_sp16 (l = 0) or the buffer layer l - 1 wrote, and
- *     writes y_even (l even) / y_odd (l odd); all sp16, none aliasing another.  ranges: n_layers + 1 rows of range slots, range_stride
- *     (>= n) floats apart - ranges[l * range_stride + i] = max |image i of the input of layer l| - so that a launch can take a slice of
- *     a larger batch (a batch of k x 8 images of 128 x 128 as k launches); NULL: the input holds 2^in_exp x, every output 2^out_exp y.
+/* A RUN of n_layers such layers (the denoisers' 13 / 2 middle layers, each feeding the next) in ONE launch: the kernel's persistent
+ *     workgroups walk their tiles layer after layer with DATAFLOW synchronisation instead of kernel boundaries - a tile of layer l + 1
+ *     waits for layer l of itself and its eight neighbour tiles only (one progress word per tile, agent-scope atomics; activations
+ *     stored write-through and fetched with agent-scope loads - no cache maintenance, no grid-wide barrier).  Bit-identical to n_layers
+ *     single launches.  Two things it buys: at one measurement per call (8 images of 128 x 128 = one tile per CU, the reference's
+ *     usage) the kernel boundary that cost a fifth of a layer; and at any batch size a SLICE of the batch whose activations fit the
+ *     Infinity Cache (n x H x W x 256 bytes <= 128 MiB: 32 images of 128 x 128) runs all its layers back to back out of that cache -
+ *     the caller slices the batch (pointers into it, range_stride = the batch's images) and launches slice after slice.
+ *     layers: DEVICE table of n_layers x { const void* w_packed; const float* bias (may be NULL); int32 w_exp; int32 relu } (24 bytes
+ *     each).  Layer l reads x_sp16 (l = 0) or the buffer layer l - 1 wrote, and writes y_even (l even) / y_odd (l odd); all sp16,
+ *     none aliasing another.  ranges: n_layers + 1 rows of range slots, range_stride (>= n) floats apart - ranges[l * range_stride + i]
+ *     = max |image i of the input of layer l|; NULL: the input holds 2^in_exp x, every output 2^out_exp y.
  *     flags: 32 (n_tiles + 1) 32-bit DEVICE words (n_tiles = n ceil(H/16) ceil(W/32); tile t's word is flags[32 t], a 128-byte line
- *     each), zeroed ONCE by the caller and then left alone: the progress words count on from launch to launch (a different shape
- *     needs its own words).  flags[32 n_tiles] != 0 after a launch = a
- *     wait timed out - a workgroup of the launch was not resident, i.e. somebody else holds CUs of this device - and the output of that
- *     launch is invalid; the launch never hangs, and later launches on the same words do not wait at all (zero the words to rearm).
- *     DEQSCI_ERR_UNSUPPORTED beyond one tile per CU: use a launch per layer there (the tiles overlap one another's edges). */
-int64_t deqsci_conv3x3_c64_split16_stack_images(int64_t H, int64_t W);   /* images of H x W one launch takes (0: not even one) */
-int deqsci_conv3x3_c64_split16_stack_fits(int64_t n, int64_t H, int64_t W);
+ *     each), zeroed ONCE by the caller and then left alone: the progress words count on from launch to launch (launches of one shape
+ *     may share them when they run one after the other; another shape needs its own).  flags[32 n_tiles] != 0 after a launch = a wait
+ *     timed out - a workgroup of the launch was not resident, i.e. somebody else holds CUs of this device - and the output of that
+ *     launch is invalid; the launch never hangs, and later launches on the same words do not wait at all (zero the words to rearm). */
 int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
                                      int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
                                      void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);

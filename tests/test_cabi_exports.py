@@ -32,7 +32,6 @@ def test_scratch_size_queries_and_error_strings():
     assert n > 0 and lib.deqsci_partials_bytes(8, 256 * 256 * 8) == 8 * n * _hip.PART_STRIDE * 4
     assert lib.deqsci_gram_bytes(3) == (3 * 80 + 2) * 8
     assert lib.deqsci_anderson_chunks(0, 10) == 0
-    assert lib.deqsci_conv3x3_c64_split16_stack_images(0, 128) == 0 and lib.deqsci_conv3x3_c64_split16_stack_fits(0, 128, 128) == 0
     assert lib.deqsci_conv3x3_c64_split16_stack(None, None, None, None, 13, 8, 128, 128, None, 8, 8, 8, None, None, None, None) == -1
     for code in (-1, -2, -3, -4):
         assert len(lib.deqsci_error_string(code)) > 5

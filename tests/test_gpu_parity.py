@@ -921,14 +921,18 @@ def test_split16_conv64_follows_the_data_scale(scale):
         assert not math.isfinite(e_fixed)
 
 
-@pytest.mark.parametrize("n,H,W,n_layers,data_ranges", [(8, 128, 128, 13, True),      # the reference's usage: one measurement, FFDNet's 13 layers, one image per XCD
+@pytest.mark.parametrize("n,H,W,n_layers,data_ranges", [(8, 128, 128, 13, True),      # the reference's usage: one measurement, FFDNet's 13 layers, ONE tile per CU
                                                         (3, 128, 128, 5, True),       # 96 tiles: every image's tiles straddle XCDs
                                                         (5, 64, 96, 4, False),        # 60 tiles (not a multiple of 8), fixed exponents
                                                         (1, 100, 76, 2, True),        # ragged edges, 21 tiles, SimpleCNN's two layers
-                                                        (7, 16, 32, 3, True)])        # one tile per image: no neighbours at all
+                                                        (7, 16, 32, 3, True),         # one tile per image: no neighbours at all
+                                                        (32, 128, 128, 13, True),     # a slice of a batch: FOUR tiles per workgroup
+                                                        (19, 128, 128, 4, False),     # 608 tiles: workgroups with two and with three tiles
+                                                        (2, 256, 512, 3, True)])      # 512 tiles, a workgroup's own tiles are vertical neighbours
 def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, data_ranges):
-    """A run of 64->64 layers as ONE launch (deqsci_conv3x3_c64_split16_stack: workgroup = tile, a tile's next layer waits for its eight
-    neighbours' progress words; activations written through and fetched at agent scope) against the same layers as single launches:
+    """A run of 64->64 layers as ONE launch (deqsci_conv3x3_c64_split16_stack: the persistent workgroups walk their tiles layer after
+    layer, a tile waiting for the progress words of the tiles it reads; activations written through and fetched at agent scope) against
+    the same layers as single launches:
     the same bits, launch after launch (the progress words count on: five launches on the same words, through the 32-bit wrap), with images that straddle XCDs,
     ragged edges, no-bias and no-ReLU layers, measured and fixed ranges.  Both ping-pong buffers are poisoned before every launch - a
     tile that ran ahead of a neighbour would read the poison."""
@@ -950,14 +954,13 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
         h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], relus[i], out_rng=None if rng is None else rng[i + 1])
     want = h.t.clone()
     assert bool(torch.isfinite(want).all())
-    assert _hip.split16_stack_fits(n, H, W)
     stack = _hip.Split16Stack(list(zip(Ws, bs, relus)), DEV)
     flags, bufs = stack.flags(n, H, W), stack.state(n, H, W)
     flags.view(-1, 32)[:-1, 0] = -20                            # the words count on for ever: start them 20 below the 32-bit wrap
     for rep in range(5):
         for b in bufs:
             b.t.fill_(float("nan"))
-        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng)
+        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng, per_launch=n)
         assert out is bufs[(n_layers - 1) % 2]
         assert torch.equal(out.t, want), (rep, float((out.t.float() - want.float()).abs().max()))
         assert out.exponents() == h.exponents()
@@ -966,11 +969,11 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
     assert not stack.timed_out()
 
 
-@pytest.mark.parametrize("n,H,W", [(16, 128, 128), (20, 128, 128), (7, 100, 76)])
-def test_split16_stack_slices_a_batch(n, H, W):
-    """A batch of more images than one launch takes (8 of 128 x 128 on 256 CUs) goes out as slices, one stack launch after the other - 2
-    x 8, 8 + 8 + 4 (two launch shapes, each with its own progress words), and on small images a single launch: the same bits as the
-    per-layer launches over the whole batch, per-image ranges read through the slice's offset into the slot table."""
+@pytest.mark.parametrize("n,H,W,per", [(16, 128, 128, 8), (20, 128, 128, 8), (64, 128, 128, None), (40, 128, 128, None), (7, 100, 76, 3)])
+def test_split16_stack_slices_a_batch(n, H, W, per):
+    """A batch goes out as slices, one stack launch after the other - 2 x 8, 8 + 8 + 4 (two launch shapes, each with its own progress
+    words), and with the default policy 2 x 32 and 2 x 20 (equal slices that fit the Infinity Cache: _hip.split16_stack_per_launch): the
+    same bits as the per-layer launches over the whole batch, per-image ranges read through the slice's offset into the slot table."""
     n_layers = 4
     g = torch.Generator(device=DEV).manual_seed(n)
     x = (torch.relu(torch.randn(n, 64, H, W, device=DEV, generator=g)) * torch.logspace(0, -3, n, device=DEV).view(n, 1, 1, 1))
@@ -985,50 +988,40 @@ def test_split16_stack_slices_a_batch(n, H, W):
         _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, track=rng[i + 1])
         h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, out_rng=rng[i + 1])
     stack = _hip.Split16Stack([(w, b, True) for w, b in zip(Ws, bs)], DEV)
-    per = _hip.split16_stack_images(H, W)
-    assert _hip.split16_stack_launches(n, H, W) == -(-n // per)
+    assert _hip.split16_stack_per_launch(64, 128, 128) == 32 and _hip.split16_stack_per_launch(40, 128, 128) == 20
+    assert _hip.split16_stack_per_launch(8, 128, 128) == 8 and _hip.split16_stack_per_launch(8, 256, 256) == 8 and _hip.split16_stack_per_launch(3, 2048, 2048) == 1
     for rep in range(3):
         for b in stack.state(n, H, W):
             b.t.fill_(float("nan"))
-        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng)
+        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng, per_launch=per)
         assert torch.equal(out.t, h.t), rep
     assert not stack.timed_out()
 
 
-def test_split16_stack_limits_and_errors():
-    """More than one tile per CU is refused (a launch per layer there), and so are aliased buffers, a missing odd buffer and ranges of the
-    wrong shape."""
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    assert _hip.split16_stack_fits(8, 128, 128) == (cus >= 256) and not _hip.split16_stack_fits(8 * cus, 16, 32 + 1)
+def test_split16_stack_errors():
+    """Aliased buffers, a missing odd buffer, missing words, ranges of the wrong shape or stride."""
     g = torch.Generator(device=DEV).manual_seed(3)
     Ws = [_hip.Split16Weights(torch.randn(64, 64, 3, 3, device=DEV, generator=g) * 0.05) for _ in range(2)]
     stack = _hip.Split16Stack([(w, None, True) for w in Ws], DEV)
-    assert _hip.split16_stack_images(16, 32) == cus and _hip.split16_stack_images(128, 128) == cus // 32 and _hip.split16_stack_images(4096, 4096) == 0
-    assert _hip.split16_stack_launches(3 * cus + 1, 16, 32) == 4 and _hip.split16_stack_launches(1, 4096, 4096) == 0
-    big = _hip.Sp16.empty(1, 16 * 40, 32 * 8, DEV)                # 320 tiles in ONE image: no launch takes it
-    big.t.zero_()
-    with pytest.raises(_hip.DeqsciHipError, match="unsupported"):
-        _hip.conv3x3_c64_split16_stack(big, stack)
-    lib0 = _hip.load()
-    two = _hip.Sp16.empty(2 * cus, 16, 32, DEV)                   # the C entry point takes one launch's worth, the wrapper slices
-    assert lib0.deqsci_conv3x3_c64_split16_stack(two.t.data_ptr(), two.t.data_ptr() + 16, two.t.data_ptr() + 32, stack.table.data_ptr(), 2, 2 * cus, 16, 32,
-                                                 None, 0, 8, 8, stack.flags(2, 16, 32).data_ptr(), None, None, None) == -4
     small = _hip.Sp16.empty(2, 16, 32, DEV)
     small.t.zero_()
     with pytest.raises(_hip.DeqsciHipError, match="ranges"):
         _hip.conv3x3_c64_split16_stack(small, stack, torch.zeros(2, 2, device=DEV))
+    with pytest.raises(_hip.DeqsciHipError, match="per_launch"):
+        _hip.conv3x3_c64_split16_stack(small, stack, per_launch=0)
     lib = _hip.load()
     flags, bufs = stack.flags(2, 16, 32), stack.state(2, 16, 32)
-    args = lambda x, y0, y1, fl: (x, y0, y1, stack.table.data_ptr(), 2, 2, 16, 32, None, 2, 8, 8, fl, None, None, None)   # noqa: E731
+    rng = torch.zeros(3, 2, device=DEV)
+    args = lambda x, y0, y1, fl, r=None, rs=2: (x, y0, y1, stack.table.data_ptr(), 2, 2, 16, 32, r, rs, 8, 8, fl, None, None, None)   # noqa: E731
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), small.t.data_ptr(), bufs[1].t.data_ptr(), flags.data_ptr())) == -4
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), None, flags.data_ptr())) == -1
     assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), None)) == -1
+    assert lib.deqsci_conv3x3_c64_split16_stack(*args(small.t.data_ptr(), bufs[0].t.data_ptr(), bufs[1].t.data_ptr(), flags.data_ptr(), rng.data_ptr(), 1)) == -2
 
 
-def test_engine_two_measurements_take_two_stack_launches():
-    """Two measurements per call = 16 images of 128 x 128 = two slices of one tile per CU: two stack launches per f-call (the default
-    stack_max_launches), bit-identical to the per-layer launches and - ranges are per image - to the two measurements reconstructed
-    alone."""
+def test_engine_two_measurements_in_one_stack_launch():
+    """Two measurements per call = 16 images of 128 x 128 = two tiles per workgroup in one stack launch per f-call: bit-identical to the
+    per-layer launches and - ranges are per image - to the two measurements reconstructed alone."""
     d = _clip("traffic_cacti.mat")
     Phi = d["mask"][None].to(DEV)
     y = d["meas"].permute(2, 0, 1)[1:3].contiguous().to(DEV)
@@ -1036,8 +1029,7 @@ def test_engine_two_measurements_take_two_stack_launches():
     want = DEQSCIEngine(net, max_iter=8, use_graph=False, stack=False).reconstruct(y, Phi)
     eng = DEQSCIEngine(net, max_iter=8, use_graph=False)
     got = eng.reconstruct(y, Phi)
-    if _hip.split16_stack_images(128, 128) == 8:
-        assert eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1
+    assert eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1
     assert torch.equal(got, want)
     one = DEQSCIEngine(net, max_iter=8, use_graph=False)
     assert torch.equal(one.reconstruct(y[1:2], Phi), want[1:2])
@@ -1048,9 +1040,6 @@ def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
     device's CUs) a wait gives up after a quarter of a second instead of hanging: the launch says so in its words, later launches on the
     same words do not wait at all, and the engine redoes the call with a launch per layer and stays there.  Simulated by setting one
     tile's progress word back: its neighbours can never see it reach their target."""
-    cus = torch.cuda.get_device_properties(0).multi_processor_count
-    if cus < 256:
-        pytest.skip("the 8 x 128 x 128 run of FFDNet needs 256 CUs for the stack launch")
     d = _clip("traffic_cacti.mat")
     Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 2].contiguous().to(DEV)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 4)[0].nonlinear_op
@@ -1074,7 +1063,7 @@ def test_engine_stack_launch_matches_per_layer_launches(kind):
     """One measurement per call - the reference's usage (test_ffdnet.sh: batch 1) - takes the stack launch from the second f-call on (the
     first measures the ranges layer by layer): the reconstruction is bit-identical to the engine with stack=False, eagerly and as a
     replayed hipGraph, and last_info says how many stack launches ran.  SimpleCNN works at full resolution: 8 frames of 256 x 256 are four
-    tiles per CU (a launch per layer), a 128 x 128 crop of the measurement is one (its two 64->64 layers as one launch)."""
+    tiles per workgroup, a 128 x 128 crop of the measurement is one (its two 64->64 layers as one launch either way)."""
     d = _clip("traffic_cacti.mat")
     Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 1].contiguous().to(DEV)
     if kind == "ffdnet":
@@ -1088,10 +1077,12 @@ def test_engine_stack_launch_matches_per_layer_launches(kind):
     assert ref.last_info["stack_launches"] == 0
     eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
     got = eng.reconstruct(y, Phi)
-    side = 256 if kind == "SimpleCNN" else 128                  # (FFDNet's layers work at half resolution)
-    fits = 0 < _hip.split16_stack_launches(8, side, side) <= eng.den.stack_max_launches
-    assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if fits else 0) and (fits or kind == "SimpleCNN")
+    assert eng.last_info["stack_launches"] == (eng.last_info["f_calls"] - 1 if kind == "ffdnet" else 0)     # (SimpleCNN's run is two layers: below STACK_MIN_LAYERS)
     assert torch.equal(got, want)
+    if kind != "ffdnet":                                        # ... but its two layers as one launch are the same bits too
+        eng.den.STACK_MIN_LAYERS = 2
+        eng.den.prepare(16, DEV)
+        assert torch.equal(eng.reconstruct(y, Phi), want) and eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1
     gr = DEQSCIEngine(net, max_iter=10, use_graph=True)
     for _ in range(3):                                          # eager warm-up, capture, replay
         out = gr.reconstruct(y, Phi)

@@ -19,9 +19,12 @@ timeout 900 python bench.py --steps 3 --warmup 1 --denoiser SimpleCNN --no-cpu-b
   timeout 900 python bench.py --steps 4 --warmup 2 --batch-per-gpu 2 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --batch-per-gpu 32 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
   timeout 900 python bench.py --steps 1 --warmup 1 --global-batch 64 --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
-  timeout 900 python bench.py --steps 3 --warmup 1 --act-range fixed --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{" ) > $O/r04_bench_other_shapes.jsonl
+  timeout 900 python bench.py --steps 3 --warmup 1 --act-range fixed --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
+  timeout 900 python bench.py --steps 3 --warmup 1 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{";
+  timeout 900 python bench.py --steps 1 --warmup 1 --batch-per-gpu 32 --no-stack --no-cpu-baseline --no-hbm-stream --no-other-kernel --no-parity-check 2>&1 | grep "^{" ) > $O/r04_bench_other_shapes.jsonl
 timeout 300 python tools/kernel_bench.py 2>&1 | grep "^{" > $O/r04_kernel_bench_bsz64.jsonl
 timeout 300 python tools/conv_bench.py 2>&1 | grep "^{" > $O/r04_conv_bench.jsonl
+( timeout 300 python tools/stack_bench.py 2>&1 | grep "^{"; STACK_IMAGES=8 timeout 300 python tools/stack_bench.py 2>&1 | grep "^{" ) > $O/r04_stack_bench.jsonl
 timeout 300 python tools/s16_check.py both 2>&1 | grep -v amdgpu > $O/r04_s16_check.txt
 ( for n in 64 8; do PROBE_IMAGES=$n timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1; done
   PROBE_IMAGES=8 PROBE_KERNEL=stack timeout 200 python tools/power_probe.py 2>&1 | grep "^{" | tail -1 ) > $O/r04_power_probe.jsonl
@@ -59,6 +62,7 @@ cd $R
 if ! skip pmc; then
   bash tools/pmc_winograd.sh > /dev/null 2>&1
   cp gpurun_out/pmc_conv_s16.json $O/r04_pmc_conv_s16.json
+  cp gpurun_out/pmc_conv_s16_stack.json $O/r04_pmc_conv_s16_stack.json
   cp gpurun_out/pmc_winograd44.json $O/r04_pmc_winograd44.json
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE; do

@@ -13,7 +13,30 @@ for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VA
   i=$((i+1))
   rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc_wg/p$i -o k -- python3 $R/tools/conv_bench.py --shape 64 128 128 > $R/gpurun_out/pmc_wg/p$i.log 2>&1
 done
+# the stack launch (13 layers over a slice of 32 images in one launch of conv_s16_kernel<0, 0, 1>): HBM bytes per launch
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_wg/stack_$C -o k -- python3 $R/tools/stack_bench.py > $R/gpurun_out/pmc_wg/stack_$C.log 2>&1
+done
 cd $R
+python - <<'PY'
+import csv, glob, json
+vals = {}
+for C in ("FETCH_SIZE", "WRITE_SIZE"):
+    v = []
+    for f in sorted(glob.glob(f'gpurun_out/pmc_wg/stack_{C}/**/k_counter_collection.csv', recursive=True)):
+        for r in csv.DictReader(open(f)):
+            if "conv_s16_kernel<0, 0, 1>" in r["Kernel_Name"] and r["Counter_Name"] == C:
+                v.append(float(r["Counter_Value"]))
+    vals[C] = sorted(v)[len(v) // 2] if v else 0.0
+n, L, H, W = 32, 13, 128, 128
+rd, wr = vals["FETCH_SIZE"] * 1024 * 2.0, vals["WRITE_SIZE"] * 1024 * 1.0          # (units and corrections as tools/pmc_summarize.py calibrates them)
+alg = L * (2 * n * H * W * 256 + 64 * 64 * 9 * 4)
+json.dump({"kernel": "deqsci::s16::conv_s16_kernel<0, 0, 1> (stack launch: 13 layers over a slice of 32 images)", "shape": [n, 64, H, W], "layers": L,
+           "counters_median": vals, "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr), "hbm_bytes_per_launch": int(rd + wr),
+           "algorithmic_hbm_bytes": alg, "traffic_over_algorithmic": round((rd + wr) / alg, 3),
+           "note": "algorithmic = every layer reads its input and writes its output once; FETCH_SIZE / WRITE_SIZE count at the L2's fabric side, "
+                   "in front of the Infinity Cache: what that cache serves of the slice's activations is not subtracted"}, open("gpurun_out/pmc_conv_s16_stack.json", "w"), indent=1)
+PY
 python - <<'PY'
 import csv, collections, glob, json
 n, H, W = 64, 128, 128
@@ -40,4 +63,4 @@ for kern, fname, pos, outs, name in (("winograd_conv64_kernel", "gpurun_out/pmc_
            "lds_bank_conflict_share": round(med.get("SQ_LDS_BANK_CONFLICT", 0) / max(med.get("SQ_LDS_IDX_ACTIVE", 1), 1), 3)}
     json.dump(out, open(fname, "w"), indent=1)
 PY
-cat gpurun_out/pmc_winograd.json gpurun_out/pmc_winograd44.json gpurun_out/pmc_conv_s16.json
+cat gpurun_out/pmc_winograd.json gpurun_out/pmc_winograd44.json gpurun_out/pmc_conv_s16.json gpurun_out/pmc_conv_s16_stack.json
