@@ -203,6 +203,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
     ap.add_argument("--stack-per-launch", type=int, default=None, help="images per stack launch (A/B; default: the engine's choice)")
+    ap.add_argument("--no-slice-edges", action="store_true", help="FFDNet's first and last layer over the whole batch instead of slice by slice around the stack launches (A/B)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -237,6 +238,8 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
                        conv64=args.conv64 if conv64 is None else conv64, conv64_f22_calls=args.conv64_f22_calls if f22_calls == "args" else f22_calls, **kw)
     if args.stack_per_launch is not None:
         eng.den.stack_per_launch = args.stack_per_launch
+    if args.no_slice_edges:
+        eng.den.slice_edges = False
     return eng
 
 

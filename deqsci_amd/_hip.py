@@ -801,6 +801,16 @@ class Split16Stack:
             st = self._state[("out", n, H, W)] = (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev))
         return st
 
+    def head_buffer(self, n, H, W):
+        """An Sp16 for the run's INPUT of a slice of n images (the engine runs first layer -> run -> last layer slice by slice, so that each
+        hands its output to the next through the Infinity Cache); kept like the output buffers."""
+        hb = self._state.get(("head", n, H, W))
+        if hb is None:
+            for key in [k for k in self._state if k[0] == "head"]:
+                del self._state[key]
+            hb = self._state[("head", n, H, W)] = Sp16.empty(n, H, W, self.table.device)
+        return hb
+
     def flags(self, n, H, W):
         """The progress words of a LAUNCH of n images: 32 (n_tiles + 1) words (a 128-byte line per tile + the time-out word), zeroed once.
         Launches of one shape share them (they run one after the other on a stream and each advances every word by n_layers)."""
@@ -834,37 +844,45 @@ def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES):
     return -(-n // launches)
 
 
-def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None):
+def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
     """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack), each launch a whole run (csrc/conv_s16.hip, STACK: the persistent
     workgroups walk their tiles layer after layer, a tile waiting for the layer before of itself and its eight neighbours) over a slice
     of the batch - per_launch images (None: split16_stack_per_launch, slices that fit the Infinity Cache), one launch after the other;
     ranges: the (n_layers + 1, n) range slots of the run - its input's first - or None (fixed exponents: the input's, then 2^8).
     Returns the Sp16 the last layer wrote (one of the stack's two buffers of this shape).  stack.timed_out() afterwards tells whether a
-    wait gave up (foreign work on the device's CUs): the result is invalid then."""
+    wait gave up (foreign work on the device's CUs): the result is invalid then.  x may itself be a slice of a larger batch: then
+    `ranges` are the whole batch's (n_layers + 1, n_total) slots and rng_offset the slice's first image in them; out_bufs: two Sp16 of at
+    least x.n images to write into instead of the stack's own."""
     if not isinstance(x, Sp16) or not isinstance(stack, Split16Stack) or not x.t.is_contiguous() or x.t.dtype != torch.float16 or not x.t.is_cuda:
         raise DeqsciHipError("conv3x3_c64_split16_stack: a contiguous Sp16 GPU activation and a Split16Stack are required")
     n, H, W = x.n, x.H, x.W
     if x.t.device != stack.table.device:
         raise DeqsciHipError("conv3x3_c64_split16_stack: the stack was built for another device")
-    if ranges is not None and (not isinstance(ranges, torch.Tensor) or ranges.dtype != torch.float32 or tuple(ranges.shape) != (stack.n_layers + 1, n)
+    n_total = n if ranges is None or not isinstance(ranges, torch.Tensor) or ranges.dim() != 2 else ranges.shape[1]
+    if ranges is not None and (not isinstance(ranges, torch.Tensor) or ranges.dtype != torch.float32 or ranges.dim() != 2
+                               or ranges.shape[0] != stack.n_layers + 1 or rng_offset < 0 or rng_offset + n > n_total
                                or not ranges.is_contiguous() or ranges.device != x.t.device):
-        raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, {n}) tensor on the input's device")
+        raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, >= {rng_offset + n}) tensor on the input's device")
     if (ranges is None) != (x.rng is None):
         raise DeqsciHipError("conv3x3_c64_split16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
     per = split16_stack_per_launch(n, H, W) if per_launch is None else int(per_launch)
     if per <= 0:
         raise DeqsciHipError("conv3x3_c64_split16_stack: per_launch must be positive")
-    bufs = stack.state(n, H, W)
+    bufs = stack.state(n, H, W) if out_bufs is None else out_bufs
+    if len(bufs) != 2 or any(not isinstance(b, Sp16) or b.n < n or (b.H, b.W) != (H, W) or not b.t.is_contiguous() or b.t.device != x.t.device for b in bufs):
+        raise DeqsciHipError("conv3x3_c64_split16_stack: out_bufs must be two contiguous Sp16 of the input's H x W with at least its images")
     with _dev(x.t):
         for a in range(0, n, per):
             m = min(per, n - a)
             ev = _hook_events("s16stack", m, H, W, events, layers=stack.n_layers) or (None, None)
             _check(load().deqsci_conv3x3_c64_split16_stack(x.t[a:a + m].data_ptr(), bufs[0].t[a:a + m].data_ptr(), bufs[1].t[a:a + m].data_ptr(),
                                                            stack.table.data_ptr(), stack.n_layers, m, H, W,
-                                                           None if ranges is None else ranges.data_ptr() + 4 * a, n, x.exp, SP16_DEFAULT_EXP,
+                                                           None if ranges is None else ranges.data_ptr() + 4 * (rng_offset + a), n_total, x.exp, SP16_DEFAULT_EXP,
                                                            stack.flags(m, H, W).data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_split16_stack")
     out = bufs[(stack.n_layers - 1) % 2]
-    out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers]), SP16_DEFAULT_EXP
+    if out.n != n:
+        out = Sp16(out.t[:n], n, H, W)
+    out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers][rng_offset:rng_offset + n]), SP16_DEFAULT_EXP
     return out
 
 

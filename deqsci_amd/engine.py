@@ -72,6 +72,7 @@ class _Denoiser:
         # their activations in the Infinity Cache); bit-identical to the per-layer launches, which the measuring f-call keeps
         self.stack = bool(stack)
         self.stack_per_launch = None                                # images per stack launch (None: _hip.split16_stack_per_launch; an A/B of the tools)
+        self.slice_edges = True                                     # FFDNet: first layer -> run -> last layer slice by slice (False: an A/B of the tools)
         self._stacks = {}                                           # first layer of a run -> _hip.Split16Stack
         self.stack_launches = 0
         self.fused_edges = fused_edges
@@ -316,6 +317,25 @@ class _Denoiser:
                 # a run of 64->64 layers on the split-fp16 kernel: the head writes its sp16 layout, the tail reads it - no conversion pass
                 sp = (x.is_cuda and self.head_w is not None and self.tail_w is not None and all(u is not None for u in self.wino[1:-1])
                       and _hip.conv64_kernel_for(bsz * B, H // 2, W // 2, x.device, self._policy) == "s16")
+                run = self._middle_run()
+                if (sp and not cal and self.stack and self.slice_edges and run is not None and len(run) >= self.STACK_MIN_LAYERS
+                        and run[0] in self._stacks and self._stacks[run[0]].n_layers == len(run)):
+                    # slice by slice: first layer -> the run of 64->64 layers as one stack launch -> last layer, each handing its output to the
+                    # next through the Infinity Cache (a slice's activation is at most 128 MiB: _hip.split16_stack_per_launch)
+                    n, st, sg = bsz * B, self._stacks[run[0]], self.sigma_table[call:call + 1]
+                    per = self.stack_per_launch or _hip.split16_stack_per_launch(n, H // 2, W // 2)
+                    bufs, hbuf = st.state(min(per, n), H // 2, W // 2), st.head_buffer(min(per, n), H // 2, W // 2)
+                    rows = None if self.ranges is None else self.ranges[run[0]:run[-1] + 2]
+                    out = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)
+                    for a in range(0, n, per):
+                        m = min(per, n - a)
+                        hin = hbuf if m == hbuf.n else _hip.Sp16(hbuf.t[:m], m, hbuf.H, hbuf.W)
+                        hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=None if self.ranges is None else self._slot(0)[a:a + m],
+                                                      out_rng=None if self.ranges is None else self._slot(1)[a:a + m])
+                        ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
+                        _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
+                    self.stack_launches += 1
+                    return out.reshape(bsz, B, H, W), True
                 if self.head_w is not None and x.is_cuda:
                     sg = self.sigma_table[call:call + 1]
                     if sp:
