@@ -928,14 +928,18 @@ def test_split16_conv64_follows_the_data_scale(scale):
                                                         (7, 16, 32, 3, True),         # one tile per image: no neighbours at all
                                                         (32, 128, 128, 13, True),     # a slice of a batch: FOUR tiles per workgroup
                                                         (19, 128, 128, 4, False),     # 608 tiles: workgroups with two and with three tiles
-                                                        (2, 256, 512, 3, True)])      # 512 tiles, a workgroup's own tiles are vertical neighbours
+                                                        (2, 256, 512, 3, True),       # 512 tiles, a workgroup's own tiles are vertical neighbours
+                                                        (4, 64, 64, 13, True),        # 32 tiles, 1 MB per activation: EVERYTHING stays in the L2s for 13 layers,
+                                                        (6, 48, 80, 12, False)])      # 54 tiles dealt round-robin over the XCDs: a stale line would be read
 def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, data_ranges):
     """A run of 64->64 layers as ONE launch (deqsci_conv3x3_c64_split16_stack: the persistent workgroups walk their tiles layer after
     layer, a tile waiting for the progress words of the tiles it reads; activations written through and fetched at agent scope) against
     the same layers as single launches:
     the same bits, launch after launch (the progress words count on: five launches on the same words, through the 32-bit wrap), with images that straddle XCDs,
-    ragged edges, no-bias and no-ReLU layers, measured and fixed ranges.  Both ping-pong buffers are poisoned before every launch - a
-    tile that ran ahead of a neighbour would read the poison."""
+    ragged edges, no-bias and no-ReLU layers, measured and fixed ranges, and batches small enough to live in the L2s of the eight XCDs for
+    the whole launch (the L2s do not snoop one another: a tile's neighbours on another XCD are read with agent-scope loads - a stale line
+    of the buffer as it was two layers ago would show here).  Both ping-pong buffers are poisoned before every launch - a tile that ran
+    ahead of a neighbour would read the poison."""
     g = torch.Generator(device=DEV).manual_seed(100 * n + n_layers)
     x = (torch.relu(torch.randn(n, 64, H, W, device=DEV, generator=g)) * torch.logspace(0, -2, n, device=DEV).view(n, 1, 1, 1))
     x = x.contiguous(memory_format=torch.channels_last)
