@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py - headline metric of BASELINE.json on MI355X: reconstructed frames/s at 256x256x8,
 180 DEQ (Anderson) iterations, FFDNet denoiser, plus the MFMA roofline of the dominant kernel (the
-denoiser's 64->64 layers: the split-fp16 direct convolution on the f16 matrix cores under the default policy), the HBM
+denoiser's 64->64 layers: the split-fp16 direct convolution on the f16 matrix cores under the default policy - as the STACK launch,
+one launch of deqsci::s16::conv_s16_kernel<0, 0, 1> per 13 layers and slice of 32 images; --no-stack: one launch per layer), the HBM
 roofline of the fused Phi/Phi^T + GAP-update kernel, a parity spot check of the very configuration that is timed against
 the CPU oracle, and the reference algorithm timed on the host CPU.
 
