@@ -1039,20 +1039,23 @@ def test_engine_two_measurements_in_one_stack_launch():
     assert torch.equal(one.reconstruct(y[1:2], Phi), want[1:2])
 
 
-def test_split16_stack_timeout_is_reported_and_the_engine_falls_back():
+@pytest.mark.parametrize("bsz", [1, 3])
+def test_split16_stack_timeout_is_reported_and_the_engine_falls_back(bsz):
     """A stack launch waits for its own workgroups only - all resident when the device is ours.  When they are not (another process on the
     device's CUs) a wait gives up after a quarter of a second instead of hanging: the launch says so in its words, later launches on the
     same words do not wait at all, and the engine redoes the call with a launch per layer and stays there.  Simulated by setting one
-    tile's progress word back: its neighbours can never see it reach their target."""
+    tile's progress word back: its neighbours can never see it reach their target.  One measurement per call (a tile per workgroup: the
+    wait behind every layer) and three (three tiles per workgroup: the poll in the shadow of stage 2, then the same wait)."""
     d = _clip("traffic_cacti.mat")
-    Phi, y = d["mask"][None].to(DEV), d["meas"][None, ..., 2].contiguous().to(DEV)
+    Phi, y = d["mask"][None].to(DEV), d["meas"].permute(2, 0, 1)[2:2 + bsz].contiguous().to(DEV)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 4)[0].nonlinear_op
     want = DEQSCIEngine(net, max_iter=4, use_graph=False, stack=False).reconstruct(y, Phi)
     eng = DEQSCIEngine(net, max_iter=4, use_graph=False)
     assert torch.equal(eng.reconstruct(y, Phi), want) and eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1 > 0
     stack = eng.den._stacks[1]
-    flags = stack.flags(8, 128, 128)
-    flags[32 * 37] -= 1000                                      # tile 37 of 256
+    flags = stack.flags(8 * bsz, 128, 128)
+    flags[32 * 5] -= 1000                                       # tile 5: the FIRST tile of its workgroup, which takes the words' common base from
+                                                                # it (any other tile's word is simply rewritten when the tile is finished)
     t0 = time.time()
     with pytest.warns(RuntimeWarning, match="stack launch timed out"):
         got = eng.reconstruct(y, Phi)
