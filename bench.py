@@ -202,6 +202,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-fused-edges", action="store_true")
     ap.add_argument("--no-winograd", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the reconstruction as a hipGraph whatever the batch size (default: up to 4 measurements per call)")
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
     ap.add_argument("--stack-per-launch", type=int, default=None, help="images per stack launch (A/B; default: the engine's choice)")
     ap.add_argument("--no-slice-edges", action="store_true", help="FFDNet's first and last layer over the whole batch instead of slice by slice around the stack launches (A/B)")
@@ -229,6 +230,8 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
     kw = {}
     if args.no_graph:
         kw["use_graph"] = False
+    if args.graph:
+        kw["use_graph"] = True
     if args.act_range != "data":
         kw["act_range"] = args.act_range
     if args.no_stack:
