@@ -5,6 +5,7 @@ tensors, passes raw device pointers + the current HIP stream to the library and 
 torch tensors.  There is NO CPU fallback: a missing library or a non-GPU tensor raises.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -834,14 +835,19 @@ class Split16Stack:
 STACK_SLICE_BYTES = 128 << 20      # activation bytes of one stack launch: its two ping-pong buffers share the 256 MiB Infinity Cache
 
 
-def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES):
+def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES, cus=None):
     """Images per stack launch for a batch of n images of H x W: as many as keep one activation (256 bytes per pixel) within `slice_bytes`
-    (32 images of 128 x 128), the batch cut into equal slices (40 images: 20 + 20, not 32 + 8).  Measured on MI355X at 256 x 256 x 8,
-    FFDNet: 143-145 frames/s with slices of 16-32 images at every batch size from 2 measurements up, 138-141 with slices of 40-64
-    (and 138-141 with a launch per layer)."""
+    (32 images of 128 x 128) - rounded down to a whole number of 16 x 32 tiles per CU when the device's CU count is given (a launch of
+    2.75 tiles per workgroup takes as long as one of 3): a batch goes out as full slices and a remainder (40 images: 32 + 8).  Measured
+    on MI355X at 256 x 256 x 8, FFDNet, 8 measurements per call: slices of 32 / 16 images 148 / 147 frames/s, of 22 / 11 images (704 / 352
+    tiles on 256 CUs) 140 / 122, of 40-64 images 138-141 (as with a launch per layer)."""
     per = max(1, int(slice_bytes) // (H * W * 256))
-    launches = -(-n // per)
-    return -(-n // launches)
+    if cus:
+        tiles = (-(-H // 16)) * (-(-W // 32))
+        unit = int(cus) // math.gcd(tiles, int(cus))             # images whose tiles are a multiple of the CUs
+        if per >= unit:
+            per -= per % unit
+    return min(per, n)
 
 
 def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
@@ -865,7 +871,8 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=Non
         raise DeqsciHipError(f"conv3x3_c64_split16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, >= {rng_offset + n}) tensor on the input's device")
     if (ranges is None) != (x.rng is None):
         raise DeqsciHipError("conv3x3_c64_split16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
-    per = split16_stack_per_launch(n, H, W) if per_launch is None else int(per_launch)
+    per = (split16_stack_per_launch(n, H, W, cus=torch.cuda.get_device_properties(x.t.device).multi_processor_count) if per_launch is None
+           else int(per_launch))
     if per <= 0:
         raise DeqsciHipError("conv3x3_c64_split16_stack: per_launch must be positive")
     bufs = stack.state(n, H, W) if out_bufs is None else out_bufs

@@ -323,7 +323,8 @@ class _Denoiser:
                     # slice by slice: first layer -> the run of 64->64 layers as one stack launch -> last layer, each handing its output to the
                     # next through the Infinity Cache (a slice's activation is at most 128 MiB: _hip.split16_stack_per_launch)
                     n, st, sg = bsz * B, self._stacks[run[0]], self.sigma_table[call:call + 1]
-                    per = self.stack_per_launch or _hip.split16_stack_per_launch(n, H // 2, W // 2)
+                    per = self.stack_per_launch or _hip.split16_stack_per_launch(n, H // 2, W // 2,
+                                                                                  cus=torch.cuda.get_device_properties(x.device).multi_processor_count)
                     bufs, hbuf = st.state(min(per, n), H // 2, W // 2), st.head_buffer(min(per, n), H // 2, W // 2)
                     rows = None if self.ranges is None else self.ranges[run[0]:run[-1] + 2]
                     out = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)

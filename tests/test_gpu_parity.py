@@ -976,7 +976,8 @@ def test_split16_stack_is_bit_identical_to_single_launches(n, H, W, n_layers, da
 @pytest.mark.parametrize("n,H,W,per", [(16, 128, 128, 8), (20, 128, 128, 8), (64, 128, 128, None), (40, 128, 128, None), (7, 100, 76, 3)])
 def test_split16_stack_slices_a_batch(n, H, W, per):
     """A batch goes out as slices, one stack launch after the other - 2 x 8, 8 + 8 + 4 (two launch shapes, each with its own progress
-    words), and with the default policy 2 x 32 and 2 x 20 (equal slices that fit the Infinity Cache: _hip.split16_stack_per_launch): the
+    words), and with the default policy 2 x 32 and 32 + 8 (slices that fit the Infinity Cache, whole tiles per CU:
+    _hip.split16_stack_per_launch): the
     same bits as the per-layer launches over the whole batch, per-image ranges read through the slice's offset into the slot table."""
     n_layers = 4
     g = torch.Generator(device=DEV).manual_seed(n)
@@ -992,8 +993,10 @@ def test_split16_stack_slices_a_batch(n, H, W, per):
         _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, track=rng[i + 1])
         h = _hip.conv3x3_c64_split16(h, Ws[i], bs[i], True, out_rng=rng[i + 1])
     stack = _hip.Split16Stack([(w, b, True) for w, b in zip(Ws, bs)], DEV)
-    assert _hip.split16_stack_per_launch(64, 128, 128) == 32 and _hip.split16_stack_per_launch(40, 128, 128) == 20
+    assert _hip.split16_stack_per_launch(64, 128, 128) == 32 and _hip.split16_stack_per_launch(40, 128, 128, cus=256) == 32
     assert _hip.split16_stack_per_launch(8, 128, 128) == 8 and _hip.split16_stack_per_launch(8, 256, 256) == 8 and _hip.split16_stack_per_launch(3, 2048, 2048) == 1
+    assert _hip.split16_stack_per_launch(64, 128, 96, cus=256) == 32          # 42 images fit 128 MiB; 32 x 24 tiles are 3 per CU
+    assert _hip.split16_stack_per_launch(64, 100, 76, cus=256) == 64          # 21 tiles per image: no multiple within the 68 that fit
     for rep in range(3):
         for b in stack.state(n, H, W):
             b.t.fill_(float("nan"))
