@@ -1191,7 +1191,10 @@ def test_ranges_are_measured_by_the_first_split16_call():
     assert bool(torch.isfinite(rb).all()) and all(v > 0 for v in rng_b[:15])
     assert rel_l2(rb.cpu().numpy(), ra.cpu().numpy()) < 2e-5
     fixed = DEQSCIEngine(net, max_iter=8, use_graph=False, act_range="fixed")
-    assert rel_l2(fixed.reconstruct(y, Phi).cpu().numpy(), ra.cpu().numpy()) < 2e-5 and fixed.last_info["act_ranges"] is None
+    rf = fixed.reconstruct(y, Phi)
+    assert rel_l2(rf.cpu().numpy(), ra.cpu().numpy()) < 2e-5 and fixed.last_info["act_ranges"] is None
+    assert fixed.last_info["stack_launches"] == fixed.last_info["f_calls"]     # (nothing to measure: every f-call takes the stack launch)
+    assert torch.equal(DEQSCIEngine(net, max_iter=8, use_graph=False, act_range="fixed", stack=False).reconstruct(y, Phi), rf)
     # a second input through the same engine is measured afresh: 1000 x larger measurements, 1000 x larger image range
     a.reconstruct(y * 1000.0, Phi)
     assert 500 < a.last_info["act_ranges"][0] / rng_a[0] < 2000
