@@ -3,7 +3,7 @@ HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -Ideqsci_amd/csrc -Wall -Wno-unused-function
 LIB        := deqsci_amd/lib/libdeqsci_hip.so
-SRCS       := deqsci_amd/csrc/sci_ops.hip deqsci_amd/csrc/anderson.hip deqsci_amd/csrc/epilogue.hip deqsci_amd/csrc/ffdnet_edges.hip deqsci_amd/csrc/winograd.hip deqsci_amd/csrc/winograd44.hip deqsci_amd/csrc/conv_s16.hip
+SRCS       := deqsci_amd/csrc/conv_w16.hip deqsci_amd/csrc/sci_ops.hip deqsci_amd/csrc/anderson.hip deqsci_amd/csrc/epilogue.hip deqsci_amd/csrc/ffdnet_edges.hip deqsci_amd/csrc/winograd.hip deqsci_amd/csrc/winograd44.hip deqsci_amd/csrc/conv_s16.hip
 HDRS       := include/deqsci_hip.h deqsci_amd/csrc/common.hpp
 ORACLE_LIB := oracle/libdeqsci_oracle.so
 

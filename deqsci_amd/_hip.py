@@ -49,6 +49,8 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_wino16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_wino16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -775,14 +777,16 @@ class Split16Stack:
     """A RUN of 64->64 layers for deqsci_conv3x3_c64_split16_stack: the device table of (weights, bias, w_exp, relu) per layer - three
     8-byte words each - the tensors it points to (kept alive here), and per launch shape the progress words of the tiles (zeroed once:
     they count on from launch to launch) and the two ping-pong buffers (kept: a captured hipGraph carries their addresses)."""
-    __slots__ = ("table", "n_layers", "keep", "_state")
+    __slots__ = ("table", "n_layers", "keep", "_state", "act")
+    TILE = (16, 32)                                                   # block tile of the kernel: rows x columns of output pixels
 
     def __init__(self, layers, device):
         """layers: [(Split16Weights, bias tensor or None, relu), ...]"""
         rows, keep = [], []
+        self.act = Sp16
         for w16, bias, relu in layers:
-            if not isinstance(w16, Split16Weights):
-                raise DeqsciHipError("Split16Stack: every layer needs Split16Weights")
+            if not isinstance(w16, self._weights_class()):
+                raise DeqsciHipError(f"{type(self).__name__}: every layer needs {self._weights_class().__name__}")
             wp = w16.packed if w16.packed.device == torch.device(device) else w16.packed.to(device)
             b = None if bias is None else f32c(bias.detach().to(device))
             if b is not None and b.numel() < 64:
@@ -792,6 +796,10 @@ class Split16Stack:
         self.table = torch.tensor(rows, dtype=torch.int64).to(device)
         self.n_layers, self.keep, self._state = len(layers), keep, {}
 
+    @staticmethod
+    def _weights_class():
+        return Split16Weights
+
     def state(self, n, H, W):
         """(Sp16, Sp16) ping-pong outputs of a batch of n images (kept: a captured hipGraph carries their addresses)."""
         st = self._state.get(("out", n, H, W))
@@ -799,7 +807,7 @@ class Split16Stack:
             dev = self.table.device
             for key in [k for k in self._state if k[0] == "out"]:      # one live batch shape at a time (2 x 256 bytes per pixel and image)
                 del self._state[key]
-            st = self._state[("out", n, H, W)] = (Sp16.empty(n, H, W, dev), Sp16.empty(n, H, W, dev))
+            st = self._state[("out", n, H, W)] = (self.act.empty(n, H, W, dev), self.act.empty(n, H, W, dev))
         return st
 
     def head_buffer(self, n, H, W):
@@ -809,7 +817,7 @@ class Split16Stack:
         if hb is None:
             for key in [k for k in self._state if k[0] == "head"]:
                 del self._state[key]
-            hb = self._state[("head", n, H, W)] = Sp16.empty(n, H, W, self.table.device)
+            hb = self._state[("head", n, H, W)] = self.act.empty(n, H, W, self.table.device)
         return hb
 
     def flags(self, n, H, W):
@@ -817,7 +825,7 @@ class Split16Stack:
         Launches of one shape share them (they run one after the other on a stream and each advances every word by n_layers)."""
         fl = self._state.get(("flags", n, H, W))
         if fl is None:
-            n_tiles = n * (-(-H // 16)) * (-(-W // 32))
+            n_tiles = n * (-(-H // self.TILE[0])) * (-(-W // self.TILE[1]))
             fl = self._state[("flags", n, H, W)] = torch.zeros(32 * (n_tiles + 1), dtype=torch.int32, device=self.table.device)
         return fl
 
@@ -835,7 +843,7 @@ class Split16Stack:
 STACK_SLICE_BYTES = 128 << 20      # activation bytes of one stack launch: its two ping-pong buffers share the 256 MiB Infinity Cache
 
 
-def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES, cus=None):
+def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES, cus=None, tile=(16, 32)):
     """Images per stack launch for a batch of n images of H x W: as many as keep one activation (256 bytes per pixel) within `slice_bytes`
     (32 images of 128 x 128) - rounded down to a whole number of 16 x 32 tiles per CU when the device's CU count is given (a launch of
     2.75 tiles per workgroup takes as long as one of 3): a batch goes out as full slices and a remainder (40 images: 32 + 8).  Measured
@@ -843,7 +851,7 @@ def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES, cus=None):
     tiles on 256 CUs) 140 / 122, of 40-64 images 138-141 (as with a launch per layer)."""
     per = max(1, int(slice_bytes) // (H * W * 256))
     if cus:
-        tiles = (-(-H // 16)) * (-(-W // 32))
+        tiles = (-(-H // tile[0])) * (-(-W // tile[1]))
         unit = int(cus) // math.gcd(tiles, int(cus))             # images whose tiles are a multiple of the CUs
         if per >= unit:
             per -= per % unit
@@ -889,6 +897,158 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=Non
     out = bufs[(stack.n_layers - 1) % 2]
     if out.n != n:
         out = Sp16(out.t[:n], n, H, W)
+    out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers][rng_offset:rng_offset + n]), SP16_DEFAULT_EXP
+    return out
+
+
+# ----------------------------------------------------------------------------- split-fp16 Winograd F(2,3) x direct (csrc/conv_w16.hip)
+ACT_SP16, ACT_P32 = 2, 3
+
+
+class P32:
+    """An activation (n,64,H,W) in the "p32" layout of csrc/conv_w16.hip: t is (n, 8, 2, H, W, 4) float32 =
+    [8-channel block][half of 4][H][W][4 channels] holding 2^e x, e from the range (rng, exp) exactly as for Sp16 - the same 16 planes of
+    16-byte pixels, unsplit.  Only exists between 64->64 layers."""
+    __slots__ = ("t", "n", "H", "W", "rng", "exp")
+
+    def __init__(self, t, n, H, W, rng=None, exp=SP16_DEFAULT_EXP):
+        self.t, self.n, self.H, self.W, self.rng, self.exp = t, n, H, W, rng, exp
+
+    is_cuda = property(lambda self: self.t.is_cuda)
+    device = property(lambda self: self.t.device)
+    shape = property(lambda self: (self.n, 64, self.H, self.W))
+
+    @staticmethod
+    def empty(n, H, W, device):
+        return P32(torch.empty((n, 8, 2, H, W, 4), dtype=torch.float32, device=device), n, H, W)
+
+    def exponents(self):
+        return [self.exp] * self.n if self.rng is None else [act_exp(v) for v in self.rng.tolist()]
+
+    def to_nchw(self):
+        """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: t / 2^e(image), exactly."""
+        sc = torch.tensor([2.0 ** (-e) for e in self.exponents()], dtype=torch.float32, device=self.t.device).view(-1, 1, 1, 1, 1, 1)
+        v = self.t * sc                                                                          # (n, 8, 2, H, W, 4)
+        return v.permute(0, 1, 2, 5, 3, 4).reshape(self.n, 64, self.H, self.W).contiguous(memory_format=torch.channels_last)
+
+    @staticmethod
+    def from_nchw(x, rng=None, exp=SP16_DEFAULT_EXP):
+        """(tests / tools; torch ops) x (n,64,H,W) fp32 -> P32 holding 2^e x."""
+        n, c, H, W = x.shape
+        o = P32.empty(n, H, W, x.device)
+        o.rng, o.exp = rng, int(exp)
+        sc = torch.tensor([2.0 ** e for e in o.exponents()], dtype=torch.float32, device=x.device).view(-1, 1, 1, 1, 1, 1)
+        o.t.copy_(x.reshape(n, 8, 2, 4, H, W).permute(0, 1, 2, 4, 5, 3) * sc)
+        return o
+
+
+_W16_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))      # G of Winograd F(2,3)
+
+
+class Wino16Weights:
+    """(64,64,3,3) fp32 conv weight for csrc/conv_w16.hip: U[dy][xi] = sum_dx G[xi][dx] w[:, :, dy, dx] formed in float64, rounded to fp32,
+    as two fp16 pieces of 2^sw U (max |U| in [2^13, 2^14)) in the kernel's LDS order
+    [cin chunk c (4)][xi half h (2)][xi' (2)][dy (3)][piece: hi, lo (2)][cout group g (2)][lane (64)][j (8)],
+    xi = 2 h + xi', cout = 32 g + lane % 32, cin = 16 c + 8 (lane // 32) + j."""
+    __slots__ = ("packed", "sw")
+
+    def __init__(self, w):
+        if tuple(w.shape) != (64, 64, 3, 3):
+            raise DeqsciHipError(f"wino16 conv expects a (64,64,3,3) weight, got {tuple(w.shape)}")
+        g = torch.tensor(_W16_G, dtype=torch.float64, device=w.device)
+        u = torch.einsum('xk,ocyk->yxoc', g, w.detach().double()).float()           # [dy][xi][cout][cin]
+        self.sw = _weight_exp(u)
+        us = u * (2.0 ** self.sw)
+        hi = us.half()
+        lo = (us - hi.float()).half()
+        if not bool(torch.isfinite(hi).all()):
+            raise DeqsciHipError("wino16 weights overflow fp16")
+        p = torch.stack((hi, lo), 0)                                   # (hl, dy, xi, cout, cin)
+        p = p.reshape(2, 3, 2, 2, 2, 32, 4, 2, 8)                      # [hl][dy][h][xp][g][m][c][kb][j]
+        self.packed = p.permute(6, 2, 3, 1, 0, 4, 7, 5, 8).contiguous()   # [c][h][xp][dy][hl][g][kb][m][j]  (lane = 32 kb + m)
+
+
+def _act_check(x, what):
+    if isinstance(x, Sp16):
+        ok = tuple(x.t.shape) == (x.n, 4, 2, 2, x.H, x.W, 8) and x.t.dtype == torch.float16
+    elif isinstance(x, P32):
+        ok = tuple(x.t.shape) == (x.n, 8, 2, x.H, x.W, 4) and x.t.dtype == torch.float32
+    else:
+        ok = False
+    if not ok or not x.t.is_contiguous() or not x.t.is_cuda:
+        raise DeqsciHipError(f"{what}: a contiguous Sp16 or P32 GPU activation is required")
+    return ACT_P32 if isinstance(x, P32) else ACT_SP16
+
+
+def conv3x3_c64_wino16(x, weights, bias=None, relu=True, out=None, events=None, out_rng=None, out_exp=SP16_DEFAULT_EXP):
+    """x Sp16 | P32 -> relu(conv3x3(x, w, pad=1) + bias) in the SAME format with the range (out_rng, out_exp): the split-fp16 arithmetic
+    under Winograd F(2,3) along x nested in the direct sum along y (csrc/conv_w16.hip).  `weights` = Wino16Weights(w)."""
+    fmt = _act_check(x, "conv3x3_c64_wino16")
+    if not isinstance(weights, Wino16Weights) or weights.packed.numel() != 4 * 2 * 2 * 3 * 2 * 2 * 64 * 8:
+        raise DeqsciHipError("conv3x3_c64_wino16: weights must be a Wino16Weights")
+    n, H, W, dev = x.n, x.H, x.W, x.t.device
+    wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
+    o = out if out is not None else (P32 if fmt == ACT_P32 else Sp16).empty(n, H, W, dev)
+    if type(o) is not type(x):
+        raise DeqsciHipError("conv3x3_c64_wino16: out must have the input's format")
+    o.rng, o.exp = out_rng, int(out_exp)
+    ev = _hook_events("w16", n, H, W, events) or (None, None)
+    with _dev(x.t):
+        _check(load().deqsci_conv3x3_c64_wino16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), o.t.data_ptr(), n, H, W, 1 if relu else 0,
+                                                weights.sw, _rng(x.rng, n), x.exp, _rng(out_rng, n), int(out_exp), fmt, _stream(), ev[0], ev[1]),
+               "conv3x3_c64_wino16")
+    return o
+
+
+class Wino16Stack(Split16Stack):
+    """A RUN of 64->64 layers for deqsci_conv3x3_c64_wino16_stack: Split16Stack with Wino16Weights, block tiles of 8 x 64 pixels and
+    activations in `fmt` (P32 by default)."""
+    __slots__ = ()
+    TILE = (8, 64)
+
+    def __init__(self, layers, device, act=None):
+        super().__init__(layers, device)
+        self.act = P32 if act is None else act
+
+    @staticmethod
+    def _weights_class():
+        return Wino16Weights
+
+
+def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
+    """conv3x3_c64_split16_stack on the Winograd kernel: x (Sp16 | P32, = stack.act) -> the run of 64->64 layers `stack` (Wino16Stack), each
+    launch a whole run over a slice of the batch; same arguments, same time-out contract."""
+    fmt = _act_check(x, "conv3x3_c64_wino16_stack")
+    if not isinstance(stack, Wino16Stack) or type(x) is not stack.act:
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: a Wino16Stack of the input's format is required")
+    n, H, W = x.n, x.H, x.W
+    if x.t.device != stack.table.device:
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: the stack was built for another device")
+    n_total = n if ranges is None or not isinstance(ranges, torch.Tensor) or ranges.dim() != 2 else ranges.shape[1]
+    if ranges is not None and (not isinstance(ranges, torch.Tensor) or ranges.dtype != torch.float32 or ranges.dim() != 2
+                               or ranges.shape[0] != stack.n_layers + 1 or rng_offset < 0 or rng_offset + n > n_total
+                               or not ranges.is_contiguous() or ranges.device != x.t.device):
+        raise DeqsciHipError(f"conv3x3_c64_wino16_stack: ranges must be a contiguous fp32 ({stack.n_layers + 1}, >= {rng_offset + n}) tensor on the input's device")
+    if (ranges is None) != (x.rng is None):
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: the input's range and the run's ranges go together (both measured or both fixed)")
+    per = (split16_stack_per_launch(n, H, W, cus=torch.cuda.get_device_properties(x.t.device).multi_processor_count, tile=stack.TILE)
+           if per_launch is None else int(per_launch))
+    if per <= 0:
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: per_launch must be positive")
+    bufs = stack.state(n, H, W) if out_bufs is None else out_bufs
+    if len(bufs) != 2 or any(type(b) is not stack.act or b.n < n or (b.H, b.W) != (H, W) or not b.t.is_contiguous() or b.t.device != x.t.device for b in bufs):
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: out_bufs must be two contiguous activations of the input's format and H x W with at least its images")
+    with _dev(x.t):
+        for a in range(0, n, per):
+            m = min(per, n - a)
+            ev = _hook_events("w16stack", m, H, W, events, layers=stack.n_layers) or (None, None)
+            _check(load().deqsci_conv3x3_c64_wino16_stack(x.t[a:a + m].data_ptr(), bufs[0].t[a:a + m].data_ptr(), bufs[1].t[a:a + m].data_ptr(),
+                                                          stack.table.data_ptr(), stack.n_layers, m, H, W,
+                                                          None if ranges is None else ranges.data_ptr() + 4 * (rng_offset + a), n_total, x.exp, SP16_DEFAULT_EXP,
+                                                          fmt, stack.flags(m, H, W).data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_wino16_stack")
+    out = bufs[(stack.n_layers - 1) % 2]
+    if out.n != n:
+        out = stack.act(out.t[:n], n, H, W)
     out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers][rng_offset:rng_offset + n]), SP16_DEFAULT_EXP
     return out
 

@@ -237,6 +237,31 @@ int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const f
 int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
                                      int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
                                      void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);
+/* ---- the same layer with a third fewer matrix-core products (csrc/conv_w16.hip): the split-fp16 arithmetic under Winograd F(2,3) ALONG X
+ *     nested in the direct sum ALONG Y - per tap row dy and position xi = 0..3 the weights U[dy][xi] = G g[dy][.] (G of F(2,3), formed in
+ *     float64 by the caller), the input transform B^T d of every halo row in the kernel (fp32, then hi + lo), ONE fp32 accumulation chain of
+ *     36 MFMAs per position, y[2t] = M0 + M1 + M2, y[2t+1] = M1 - M2 - M3.  18 f16 MFMA products per output and (cin, cout) instead of 27;
+ *     per layer against float64 on FFDNet's own data the same 1.3e-7 as the direct kernel (tools/wino16_numerics.py).
+ *     Replaces nn.Conv2d(64,64,3,padding=1) + BatchNorm(eval) + ReLU, networks/ffdnet/models.py:53-58 (the 13 middle layers :46-64).
+ *     u_packed: 2^w_exp U as [4 cin chunks][2 xi halves][2 xi'][3 dy][2 pieces: hi, lo][2 cout groups of 32][64 lanes][8 halfs]
+ *     (xi = 2 half + xi', cout = 32 g + lane % 32, cin = 16 c + 8 (lane / 32) + j), w_exp the power of two that puts max |U| into [2^13, 2^14).
+ *     fmt: the activation format of BOTH x and y - DEQSCI_ACT_SP16 (as deqsci_conv3x3_c64_split16) or DEQSCI_ACT_P32: the same 16 planes
+ *     of 16-byte pixels holding 2^e x as fp32, [n][8 blocks of 8 channels][2 halves of 4][H][W][4 floats] (no hi + lo to join in front of the
+ *     transform, none to split behind the output transform).  Ranges (in_amax, in_exp), (out_amax, out_exp): as above, for either format
+ *     (B^T d is at most twice max |d|: the headroom against fp16's overflow is 8 x the measured maximum instead of 16 x).
+ *     Output = relu?(conv + bias) in `fmt`.  Block tiles of 8 x 64 output pixels, one persistent 256-thread workgroup per CU. */
+#define DEQSCI_ACT_SP16 2
+#define DEQSCI_ACT_P32 3
+int deqsci_conv3x3_c64_wino16(const void* x, const void* u_packed, const float* bias, void* y,
+                              int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
+                              const float* out_amax, int out_exp, int fmt,
+                              deqsci_stream_t stream, void* start_event, void* stop_event);
+/* A RUN of n_layers such layers in ONE launch: deqsci_conv3x3_c64_split16_stack's contract word for word (layer table, ranges, progress
+ *     words, time-out word, residency: never more workgroups than CUs, each of them alone on its CU by its LDS and register footprint),
+ *     with n_tiles = n ceil(H/8) ceil(W/64) and every activation (x, y_even, y_odd) in `fmt`. */
+int deqsci_conv3x3_c64_wino16_stack(const void* x, void* y_even, void* y_odd, const void* layers, int n_layers,
+                                    int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
+                                    int fmt, void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);
 /* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and, for x = n images of `count` contiguous floats each, max |x| of
  *     image i folded into amax[i] (zero them first): the range of an activation no sp16-writing kernel produced (the denoiser's input
  *     image; a converted fp32 activation). */
