@@ -49,8 +49,8 @@ SIGNATURES = {
     "deqsci_conv3x3_c64_winograd44_layout_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
     "deqsci_conv3x3_c64_split16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_wino16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _int, _ptr, _ptr, _ptr],
-    "deqsci_conv3x3_c64_wino16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _int, _ptr, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_wino16": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _int, _ptr, _int, _ptr, _int, _ptr, _ptr, _ptr],
+    "deqsci_conv3x3_c64_wino16_stack": [_ptr, _ptr, _ptr, _ptr, _int, _i64, _i64, _i64, _ptr, _i64, _int, _int, _ptr, _ptr, _ptr, _ptr],
     "deqsci_f32_to_split16": [_ptr, _ptr, _i64, _i64, _i64, _ptr, _int, _ptr],
     "deqsci_absmax_f32": [_ptr, _i64, _i64, _ptr, _ptr],
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
@@ -902,13 +902,13 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=Non
 
 
 # ----------------------------------------------------------------------------- split-fp16 Winograd F(2,3) x direct (csrc/conv_w16.hip)
-ACT_SP16, ACT_P32 = 2, 3
-
 
 class P32:
-    """An activation (n,64,H,W) in the "p32" layout of csrc/conv_w16.hip: t is (n, 8, 2, H, W, 4) float32 =
-    [8-channel block][half of 4][H][W][4 channels] holding 2^e x, e from the range (rng, exp) exactly as for Sp16 - the same 16 planes of
-    16-byte pixels, unsplit.  Only exists between 64->64 layers."""
+    """An activation (n,64,H,W) in the "p32" layout of csrc/conv_w16.hip: t is (n, 8, 2, H, ceil(W/64), 2, 32, 4) float32 =
+    [8-channel block][half of 4][H][block of 64 columns][column parity][32][4 channels] holding 2^e x, e from the range (rng, exp) exactly
+    as for Sp16 - the 16 planes of 16-byte pixels of sp16, unsplit, and inside every block of 64 columns the even columns first, then the
+    odd ones (the Winograd kernel's lanes own column PAIRS: with the parities apart its loads and stores are contiguous).  Columns >= W of
+    the last block are padding (never read as data).  Only exists between 64->64 layers."""
     __slots__ = ("t", "n", "H", "W", "rng", "exp")
 
     def __init__(self, t, n, H, W, rng=None, exp=SP16_DEFAULT_EXP):
@@ -920,25 +920,29 @@ class P32:
 
     @staticmethod
     def empty(n, H, W, device):
-        return P32(torch.empty((n, 8, 2, H, W, 4), dtype=torch.float32, device=device), n, H, W)
+        return P32(torch.empty((n, 8, 2, H, -(-W // 64), 2, 32, 4), dtype=torch.float32, device=device), n, H, W)
 
     def exponents(self):
         return [self.exp] * self.n if self.rng is None else [act_exp(v) for v in self.rng.tolist()]
 
     def to_nchw(self):
         """(tests / tools) back to an fp32 (n,64,H,W) channels_last tensor: t / 2^e(image), exactly."""
-        sc = torch.tensor([2.0 ** (-e) for e in self.exponents()], dtype=torch.float32, device=self.t.device).view(-1, 1, 1, 1, 1, 1)
-        v = self.t * sc                                                                          # (n, 8, 2, H, W, 4)
-        return v.permute(0, 1, 2, 5, 3, 4).reshape(self.n, 64, self.H, self.W).contiguous(memory_format=torch.channels_last)
+        sc = torch.tensor([2.0 ** (-e) for e in self.exponents()], dtype=torch.float32, device=self.t.device).view(-1, 1, 1, 1)
+        nb = self.t.shape[4]
+        v = self.t.permute(0, 1, 2, 7, 3, 4, 6, 5).reshape(self.n, 64, self.H, nb * 64)[..., :self.W]     # (n, b8, j, k, H, blk, i, par) -> col = 64 blk + 2 i + par
+        return (v * sc).contiguous(memory_format=torch.channels_last)
 
     @staticmethod
     def from_nchw(x, rng=None, exp=SP16_DEFAULT_EXP):
-        """(tests / tools; torch ops) x (n,64,H,W) fp32 -> P32 holding 2^e x."""
+        """(tests / tools; torch ops) x (n,64,H,W) fp32 -> P32 holding 2^e x (the padding columns zero)."""
         n, c, H, W = x.shape
         o = P32.empty(n, H, W, x.device)
         o.rng, o.exp = rng, int(exp)
-        sc = torch.tensor([2.0 ** e for e in o.exponents()], dtype=torch.float32, device=x.device).view(-1, 1, 1, 1, 1, 1)
-        o.t.copy_(x.reshape(n, 8, 2, 4, H, W).permute(0, 1, 2, 4, 5, 3) * sc)
+        sc = torch.tensor([2.0 ** e for e in o.exponents()], dtype=torch.float32, device=x.device).view(-1, 1, 1, 1)
+        nb = o.t.shape[4]
+        xp = torch.zeros((n, 64, H, nb * 64), dtype=torch.float32, device=x.device)
+        xp[..., :W] = x * sc
+        o.t.copy_(xp.reshape(n, 8, 2, 4, H, nb, 32, 2).permute(0, 1, 2, 4, 5, 7, 6, 3))
         return o
 
 
@@ -969,46 +973,40 @@ class Wino16Weights:
 
 
 def _act_check(x, what):
-    if isinstance(x, Sp16):
-        ok = tuple(x.t.shape) == (x.n, 4, 2, 2, x.H, x.W, 8) and x.t.dtype == torch.float16
-    elif isinstance(x, P32):
-        ok = tuple(x.t.shape) == (x.n, 8, 2, x.H, x.W, 4) and x.t.dtype == torch.float32
-    else:
-        ok = False
-    if not ok or not x.t.is_contiguous() or not x.t.is_cuda:
-        raise DeqsciHipError(f"{what}: a contiguous Sp16 or P32 GPU activation is required")
-    return ACT_P32 if isinstance(x, P32) else ACT_SP16
+    if (not isinstance(x, P32) or tuple(x.t.shape) != (x.n, 8, 2, x.H, -(-x.W // 64), 2, 32, 4) or x.t.dtype != torch.float32 or not x.t.is_contiguous()
+            or not x.t.is_cuda):
+        raise DeqsciHipError(f"{what}: a contiguous P32 GPU activation is required")
 
 
 def conv3x3_c64_wino16(x, weights, bias=None, relu=True, out=None, events=None, out_rng=None, out_exp=SP16_DEFAULT_EXP):
-    """x Sp16 | P32 -> relu(conv3x3(x, w, pad=1) + bias) in the SAME format with the range (out_rng, out_exp): the split-fp16 arithmetic
-    under Winograd F(2,3) along x nested in the direct sum along y (csrc/conv_w16.hip).  `weights` = Wino16Weights(w)."""
-    fmt = _act_check(x, "conv3x3_c64_wino16")
+    """x P32 -> relu(conv3x3(x, w, pad=1) + bias) as a P32 with the range (out_rng, out_exp): the split-fp16 arithmetic under Winograd F(2,3)
+    along x nested in the direct sum along y (csrc/conv_w16.hip).  `weights` = Wino16Weights(w)."""
+    _act_check(x, "conv3x3_c64_wino16")
     if not isinstance(weights, Wino16Weights) or weights.packed.numel() != 4 * 2 * 2 * 3 * 2 * 2 * 64 * 8:
         raise DeqsciHipError("conv3x3_c64_wino16: weights must be a Wino16Weights")
     n, H, W, dev = x.n, x.H, x.W, x.t.device
     wp = weights.packed if weights.packed.device == dev else weights.packed.to(dev)
-    o = out if out is not None else (P32 if fmt == ACT_P32 else Sp16).empty(n, H, W, dev)
-    if type(o) is not type(x):
-        raise DeqsciHipError("conv3x3_c64_wino16: out must have the input's format")
+    o = out if out is not None else P32.empty(n, H, W, dev)
+    if not isinstance(o, P32):
+        raise DeqsciHipError("conv3x3_c64_wino16: out must be a P32")
     o.rng, o.exp = out_rng, int(out_exp)
     ev = _hook_events("w16", n, H, W, events) or (None, None)
     with _dev(x.t):
         _check(load().deqsci_conv3x3_c64_wino16(x.t.data_ptr(), wp.data_ptr(), _p(bias, "bias", True), o.t.data_ptr(), n, H, W, 1 if relu else 0,
-                                                weights.sw, _rng(x.rng, n), x.exp, _rng(out_rng, n), int(out_exp), fmt, _stream(), ev[0], ev[1]),
+                                                weights.sw, _rng(x.rng, n), x.exp, _rng(out_rng, n), int(out_exp), _stream(), ev[0], ev[1]),
                "conv3x3_c64_wino16")
     return o
 
 
 class Wino16Stack(Split16Stack):
-    """A RUN of 64->64 layers for deqsci_conv3x3_c64_wino16_stack: Split16Stack with Wino16Weights, block tiles of 8 x 64 pixels and
-    activations in `fmt` (P32 by default)."""
+    """A RUN of 64->64 layers for deqsci_conv3x3_c64_wino16_stack: Split16Stack with Wino16Weights, block tiles of 8 x 64 pixels and P32
+    activations."""
     __slots__ = ()
     TILE = (8, 64)
 
-    def __init__(self, layers, device, act=None):
+    def __init__(self, layers, device):
         super().__init__(layers, device)
-        self.act = P32 if act is None else act
+        self.act = P32
 
     @staticmethod
     def _weights_class():
@@ -1016,11 +1014,11 @@ class Wino16Stack(Split16Stack):
 
 
 def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
-    """conv3x3_c64_split16_stack on the Winograd kernel: x (Sp16 | P32, = stack.act) -> the run of 64->64 layers `stack` (Wino16Stack), each
-    launch a whole run over a slice of the batch; same arguments, same time-out contract."""
-    fmt = _act_check(x, "conv3x3_c64_wino16_stack")
-    if not isinstance(stack, Wino16Stack) or type(x) is not stack.act:
-        raise DeqsciHipError("conv3x3_c64_wino16_stack: a Wino16Stack of the input's format is required")
+    """conv3x3_c64_split16_stack on the Winograd kernel: x P32 -> the run of 64->64 layers `stack` (Wino16Stack), each launch a whole run
+    over a slice of the batch; same arguments, same time-out contract."""
+    _act_check(x, "conv3x3_c64_wino16_stack")
+    if not isinstance(stack, Wino16Stack):
+        raise DeqsciHipError("conv3x3_c64_wino16_stack: a Wino16Stack is required")
     n, H, W = x.n, x.H, x.W
     if x.t.device != stack.table.device:
         raise DeqsciHipError("conv3x3_c64_wino16_stack: the stack was built for another device")
@@ -1045,7 +1043,7 @@ def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None
             _check(load().deqsci_conv3x3_c64_wino16_stack(x.t[a:a + m].data_ptr(), bufs[0].t[a:a + m].data_ptr(), bufs[1].t[a:a + m].data_ptr(),
                                                           stack.table.data_ptr(), stack.n_layers, m, H, W,
                                                           None if ranges is None else ranges.data_ptr() + 4 * (rng_offset + a), n_total, x.exp, SP16_DEFAULT_EXP,
-                                                          fmt, stack.flags(m, H, W).data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_wino16_stack")
+                                                          stack.flags(m, H, W).data_ptr(), _stream(), ev[0], ev[1]), "conv3x3_c64_wino16_stack")
     out = bufs[(stack.n_layers - 1) % 2]
     if out.n != n:
         out = stack.act(out.t[:n], n, H, W)

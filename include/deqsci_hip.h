@@ -245,23 +245,22 @@ int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_o
  *     Replaces nn.Conv2d(64,64,3,padding=1) + BatchNorm(eval) + ReLU, networks/ffdnet/models.py:53-58 (the 13 middle layers :46-64).
  *     u_packed: 2^w_exp U as [4 cin chunks][2 xi halves][2 xi'][3 dy][2 pieces: hi, lo][2 cout groups of 32][64 lanes][8 halfs]
  *     (xi = 2 half + xi', cout = 32 g + lane % 32, cin = 16 c + 8 (lane / 32) + j), w_exp the power of two that puts max |U| into [2^13, 2^14).
- *     fmt: the activation format of BOTH x and y - DEQSCI_ACT_SP16 (as deqsci_conv3x3_c64_split16) or DEQSCI_ACT_P32: the same 16 planes
- *     of 16-byte pixels holding 2^e x as fp32, [n][8 blocks of 8 channels][2 halves of 4][H][W][4 floats] (no hi + lo to join in front of the
- *     transform, none to split behind the output transform).  Ranges (in_amax, in_exp), (out_amax, out_exp): as above, for either format
- *     (B^T d is at most twice max |d|: the headroom against fp16's overflow is 8 x the measured maximum instead of 16 x).
- *     Output = relu?(conv + bias) in `fmt`.  Block tiles of 8 x 64 output pixels, one persistent 256-thread workgroup per CU. */
-#define DEQSCI_ACT_SP16 2
-#define DEQSCI_ACT_P32 3
-int deqsci_conv3x3_c64_wino16(const void* x, const void* u_packed, const float* bias, void* y,
+ *     Activations x, y in "p32": the 16 planes of 16-byte pixels of sp16 holding 2^e x as fp32 instead of hi + lo fp16 -
+ *     [n][8 blocks of 8 channels][2 halves of 4][H][W][4 floats] (nothing to join in front of the transform, nothing to split behind the output
+ *     transform); FFDNet's first and last layer write / read it (deqsci_ffdnet_head_p32, deqsci_ffdnet_tail_p32).  Ranges (in_amax, in_exp),
+ *     (out_amax, out_exp): as for sp16 (B^T d is at most twice max |d|: the headroom against fp16's overflow is 8 x the measured maximum
+ *     instead of 16 x).  Output = relu?(conv + bias).  Block tiles of 8 x 64 output pixels, one persistent 512-thread workgroup per CU
+ *     (a wave = one output row x 64 couts; 148 KB of LDS). */
+int deqsci_conv3x3_c64_wino16(const void* x_p32, const void* u_packed, const float* bias, void* y_p32,
                               int64_t n, int64_t H, int64_t W, int relu, int w_exp, const float* in_amax, int in_exp,
-                              const float* out_amax, int out_exp, int fmt,
+                              const float* out_amax, int out_exp,
                               deqsci_stream_t stream, void* start_event, void* stop_event);
 /* A RUN of n_layers such layers in ONE launch: deqsci_conv3x3_c64_split16_stack's contract word for word (layer table, ranges, progress
- *     words, time-out word, residency: never more workgroups than CUs, each of them alone on its CU by its LDS and register footprint),
- *     with n_tiles = n ceil(H/8) ceil(W/64) and every activation (x, y_even, y_odd) in `fmt`. */
-int deqsci_conv3x3_c64_wino16_stack(const void* x, void* y_even, void* y_odd, const void* layers, int n_layers,
+ *     words, time-out word, residency: never more workgroups than CUs, each of them alone on its CU by its LDS footprint), with
+ *     n_tiles = n ceil(H/8) ceil(W/64) and every activation (x, y_even, y_odd) in p32. */
+int deqsci_conv3x3_c64_wino16_stack(const void* x_p32, void* y_even, void* y_odd, const void* layers, int n_layers,
                                     int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
-                                    int fmt, void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);
+                                    void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);
 /* fp32 channels_last (n,H,W,64) -> sp16 with the range (amax, exp); and, for x = n images of `count` contiguous floats each, max |x| of
  *     image i folded into amax[i] (zero them first): the range of an activation no sp16-writing kernel produced (the denoiser's input
  *     image; a converted fp32 activation). */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Split-fp16 Winograd F(2,3) x direct convolution (csrc/conv_w16.hip): error against a float64 convolution on random data and several
-shapes (both activation formats, a two-layer chain, the stack launch against per-layer launches), and its time next to the split-fp16
+shapes (a two-layer chain, the stack launch against per-layer launches), and its time next to the split-fp16
 direct kernel at the bench shapes.  `python tools/w16_check.py [check|time|both]`"""
 import json
 import os
@@ -33,7 +33,7 @@ def check():
         ref1 = torch.relu(F.conv2d(x.double(), w1.double(), b1.double(), padding=1))
         ref2 = F.conv2d(ref1, w2.double(), b2.double(), padding=1)
         e = {}
-        for name, xin in (("sp16", _hip.to_split16(x)), ("p32", _hip.P32.from_nchw(x))):
+        for name, xin in (("p32", _hip.P32.from_nchw(x)),):
             o1 = _hip.conv3x3_c64_wino16(xin, W1, b1, True)
             o2 = _hip.conv3x3_c64_wino16(o1, W2, b2, False)
             e[name] = rel(o1.to_nchw(), ref1)
@@ -51,16 +51,16 @@ def check():
         ws = [torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.04 for _ in range(nl)]
         bs = [torch.randn(64, device="cuda", generator=g) * 0.1 for _ in range(nl)]
         packs = [_hip.Wino16Weights(w) for w in ws]
-        for act, xin in ((_hip.P32, _hip.P32.from_nchw(x)), (_hip.Sp16, _hip.to_split16(x))):
+        for act, xin in ((_hip.P32, _hip.P32.from_nchw(x)),):
             h = xin
             for i in range(nl):
                 h = _hip.conv3x3_c64_wino16(h, packs[i], bs[i], i % 3 != 2)
-            st = _hip.Wino16Stack([(packs[i], bs[i], i % 3 != 2) for i in range(nl)], "cuda", act=act)
+            st = _hip.Wino16Stack([(packs[i], bs[i], i % 3 != 2) for i in range(nl)], "cuda")
             for rep in range(2):
                 for b in st.state(n, H, W):
                     b.t.fill_(float("nan"))
                 o = _hip.conv3x3_c64_wino16_stack(xin, st)
-                same = bool(torch.equal(o.t, h.t))
+                same = bool(torch.equal(o.to_nchw(), h.to_nchw()))     # (the padding columns of a block are nobody's)
                 to = st.timed_out()
                 bad += (not same) or to
                 print("stack", shape, nl, act.__name__, "rep", rep, "bit-identical" if same else "DIFFERS", "TIMED OUT" if to else "", flush=True)
@@ -76,18 +76,15 @@ def timeit():
     for shape in ((64, 128, 128), (32, 128, 128), (8, 128, 128)):
         x = torch.relu(torch.randn(shape[0], 64, shape[1], shape[2], device="cuda", generator=g)).contiguous(memory_format=torch.channels_last)
         xs, xp = _hip.to_split16(x), _hip.P32.from_nchw(x)
-        os_, op, ow = _hip.Sp16.empty(*shape, "cuda"), _hip.P32.empty(*shape, "cuda"), _hip.Sp16.empty(*shape, "cuda")
+        os_, op = _hip.Sp16.empty(*shape, "cuda"), _hip.P32.empty(*shape, "cuda")
         Wsp, Ww = _hip.Split16Weights(w), _hip.Wino16Weights(w)
         st16 = _hip.Split16Stack([(_hip.Split16Weights(ws[i]), bs[i], True) for i in range(13)], "cuda")
         stw = _hip.Wino16Stack([(_hip.Wino16Weights(ws[i]), bs[i], True) for i in range(13)], "cuda")
-        stws = _hip.Wino16Stack([(_hip.Wino16Weights(ws[i]), bs[i], True) for i in range(13)], "cuda", act=_hip.Sp16)
         fns = {"s16 direct": lambda: _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=os_),
-               "w16 sp16": lambda: _hip.conv3x3_c64_wino16(xs, Ww, b, True, out=ow),
                "w16 p32": lambda: _hip.conv3x3_c64_wino16(xp, Ww, b, True, out=op)}
         if shape[0] <= 32:
             fns["s16 stack13 /13"] = lambda: _hip.conv3x3_c64_split16_stack(xs, st16)
             fns["w16 p32 stack13 /13"] = lambda: _hip.conv3x3_c64_wino16_stack(xp, stw)
-            fns["w16 sp16 stack13 /13"] = lambda: _hip.conv3x3_c64_wino16_stack(xs, stws)
         res = {k: [] for k in fns}
         for rnd in range(5):
             for k, fn in fns.items():
@@ -101,7 +98,7 @@ def timeit():
                 torch.cuda.synchronize()
                 res[k].append(e0.elapsed_time(e1) / 10 * 1e3 / (13 if "stack" in k else 1))
         med = {k: round(statistics.median(v), 1) for k, v in res.items()}
-        print(json.dumps({"shape": shape, "us_per_layer": med, "timed_out": [st16.timed_out(), stw.timed_out(), stws.timed_out()]}), flush=True)
+        print(json.dumps({"shape": shape, "us_per_layer": med, "timed_out": [st16.timed_out(), stw.timed_out()]}), flush=True)
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ w = torch.zeros(64, 64, 3, 3, device="cuda")
 for c in range(64):
     w[c, c, 1, 1] = 1.0
 Ww = _hip.Wino16Weights(w)
-for name, xin in (("sp16", _hip.to_split16(x)), ("p32", _hip.P32.from_nchw(x))):
+for name, xin in (("p32", _hip.P32.from_nchw(x)),):
     o = _hip.conv3x3_c64_wino16(xin, Ww, None, False).to_nchw()
     err = (o - x).abs()
     print(name, "max err", float(err.max()), "per channel max:", [round(float(v), 3) for v in err.amax(dim=(0, 2, 3))[:16]])
@@ -38,7 +38,7 @@ for shape, nl in (((8, 128, 128), 1), ((8, 128, 128), 2), ((8, 128, 128), 3), ((
     for i in range(nl):
         h = _hip.conv3x3_c64_wino16(h, packs[i], bs[i], True)
         hs.append(h)
-    st = _hip.Wino16Stack([(packs[i], bs[i], True) for i in range(nl)], "cuda", act=_hip.P32)
+    st = _hip.Wino16Stack([(packs[i], bs[i], True) for i in range(nl)], "cuda")
     bufs = st.state(n, H, W)
     for b in bufs:
         b.t.fill_(float("nan"))
