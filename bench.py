@@ -206,6 +206,8 @@ def parse_args(argv=None):
     ap.add_argument("--act-range", default="data", choices=["data", "fixed"], help="scales of the split-fp16 activations (A/B; fixed = 2^8, round 3)")
     ap.add_argument("--stack-per-launch", type=int, default=None, help="images per stack launch (A/B; default: the engine's choice)")
     ap.add_argument("--no-slice-edges", action="store_true", help="FFDNet's first and last layer over the whole batch instead of slice by slice around the stack launches (A/B)")
+    ap.add_argument("--stack-kernel", default="w16", choices=["w16", "s16"],
+                    help="kernel of FFDNet's stack launches: w16 = split-fp16 under Winograd F(2,3) x direct (csrc/conv_w16.hip), s16 = split-fp16 direct (A/B)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -236,6 +238,8 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
         kw["act_range"] = args.act_range
     if args.no_stack:
         kw["stack"] = False
+    if args.stack_kernel != "w16":
+        kw["stack_kernel"] = args.stack_kernel
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
@@ -289,7 +293,7 @@ def run_rank(args):
             step()
     timing = not (selftest or args.no_kernel_timing or graph_mode) and rank == 0
     timer = None
-    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0, "s16stack": 0}
+    conv_timers, conv_shape, conv_launches = {}, {}, {"f22": 0, "f44": 0, "s16": 0, "s16stack": 0, "w16": 0, "w16stack": 0}
     if timing:
         timer = _hip.KernelTimer(capacity=args.steps * max(args.iters, 1))
         conv_timers = {k: _hip.KernelTimer(capacity=400) for k in conv_launches}   # a sample of launches of each kernel is enough
@@ -371,13 +375,20 @@ def run_rank(args):
                    "launch_mode": "hipGraph replay of the whole reconstruction (captured before the warm-up steps)" if graph_mode else "eager launches",
                    # f-calls whose run of 64->64 layers went out as ONE launch (csrc/conv_s16.hip, STACK: at most one block tile per CU, i.e. one
                    # measurement of 256x256x8 per call); 0 = a launch per layer
-                   "stack_launches_per_step": info.get("stack_launches", 0)},
+                   "stack_launches_per_step": info.get("stack_launches", 0),
+                   "stack_kernel": None if selftest else getattr(eng.den, "stack_kernel", None),
+                   # reconstructions (warm-up included) whose stack launch timed out and were redone with a launch per layer: foreign work on the
+                   # device's CUs (two ranks on one GPU provoke it); 0 on a device of one's own
+                   "stack_timeouts": None if selftest else getattr(eng, "stack_timeouts_total", None),
+                   "anderson_arith": None if selftest else getattr(eng, "anderson_arith", None)},
         "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  64->64 conv layers under conv64 policy 'fast' (default): products on the f16 matrix "
-                       "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, two fp32 accumulation "
-                       "chains; the power-of-two scale of every activation follows max |activation| measured on the device at the first f-call, so "
-                       "the path is scale-free like fp32); rounding per layer against float64 on FFDNet's own data 1.6e-7 (fp32 Winograd F(2x2,3x3) "
-                       "2.0e-7, MIOpen's fp32 direct convolution 3.5e-7: profiles/r03_conv_error_real.json).  other_conv64_policies gives the same "
-                       "step on fp32-MFMA kernels only."),
+                       "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, fp32 accumulation; the "
+                       "power-of-two scale of every activation follows max |activation| measured on the device at the first f-call, so the path is "
+                       "scale-free like fp32).  stack_kernel 'w16' (default): FFDNet's 13 layers under Winograd F(2,3) along x nested in the direct sum "
+                       "along y (U = G g in float64, B^T d in fp32 then hi + lo, one accumulation chain of 36 MFMAs per position, fp32 activations "
+                       "between the layers), 1.2-1.5e-7 per layer against float64; 's16' / the measuring f-call: the direct convolution, 1.6e-7 "
+                       "(fp32 Winograd F(2x2,3x3) 2.0e-7, MIOpen's fp32 direct convolution 3.5e-7: profiles/r03_conv_error_real.json).  "
+                       "other_conv64_policies gives the same step on fp32-MFMA kernels only."),
         "final_res": info.get("res"),
         "allgather_ms_per_step": 1e3 * gather_timer.total_seconds() / max(args.steps, 1) if world > 1 else 0.0,
         "allgather_bytes_per_step": world * per * H * W * B * 4 if world > 1 else 0,      # what every rank receives: (R*per,H,W,B) fp32
@@ -422,12 +433,15 @@ def run_rank(args):
                 continue
             nimg, ch, cw, nlay = conv_shape[kind]
             direct = 2.0 * 64 * 64 * 9 * ch * cw * nimg * nlay      # (a stack launch: all its layers)
-            mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "s16stack": (3.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS),
-                          "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
+            # (split-fp16 under Winograd F(2,3) x direct: three f16 products per multiplication, 6 multiplications per output instead of 9)
+            mult, peak = {"s16": (3.0, MFMA_F16_PEAK_TFLOPS), "s16stack": (3.0, MFMA_F16_PEAK_TFLOPS), "w16": (2.0, MFMA_F16_PEAK_TFLOPS),
+                          "w16stack": (2.0, MFMA_F16_PEAK_TFLOPS), "f44": (1 / 4.0, MFMA_F32_PEAK_TFLOPS), "f22": (1 / 2.25, MFMA_F32_PEAK_TFLOPS)}[kind]
             cavg = 1e-3 * sum(cms) / len(cms)
             share = cavg * conv_launches[kind] / elapsed
-            wtraffic = None                                       # HBM bytes per launch from the PMC passes of tools/pmc_winograd.sh
+            wtraffic, wsource = None, None                        # fabric-side bytes per launch from the PMC passes of tools/pmc_winograd.sh (FETCH_SIZE +
+                                                                  # WRITE_SIZE count at the L2's memory side, IN FRONT of the Infinity Cache: not HBM bytes)
             for wname in {"s16": ("r04_pmc_conv_s16.json", "r03_pmc_conv_s16.json"), "s16stack": ("r04_pmc_conv_s16_stack.json",),
+                          "w16": ("r05_pmc_conv_w16.json",), "w16stack": ("r05_pmc_conv_w16_stack.json",),
                           "f44": ("r03_pmc_winograd44.json", "r02_pmc_winograd44.json"),
                           "f22": ("r03_pmc_winograd.json", "r02_pmc_winograd.json", "r01_pmc_winograd.json")}[kind]:
                 wfile = os.path.join(ROOT, "profiles", wname)
@@ -435,17 +449,25 @@ def run_rank(args):
                     with open(wfile) as fh:
                         rec = json.load(fh)
                     if rec.get("shape") == [nimg, 64, ch, cw] and rec.get("layers", 1) == nlay:
-                        wtraffic = rec["hbm_bytes_per_launch"]
+                        wtraffic, wsource = rec["hbm_bytes_per_launch"], "profiles/" + wname
             kname = {"s16": "deqsci::s16::conv_s16_kernel<0, 0, 0> (conv3x3 64->64 + bias + ReLU, direct convolution on the f16 matrix cores: fp32 operands as hi + lo "
                             "fp16 pairs, three MFMAs per product, fp32 accumulation)",
                      "s16stack": f"deqsci::s16::conv_s16_kernel<0, 0, 1> (the same arithmetic; ONE launch = the denoiser's {nlay} consecutive conv3x3 64->64 + bias + ReLU "
                                  f"layers over a slice of {nimg} images, tiles synchronised by per-tile progress words, the slice's activations resident in the "
                                  "Infinity Cache; flops and time are the whole launch's)",
+                     "w16": "deqsci::w16::conv_w16_kernel<0> (conv3x3 64->64 + bias + ReLU on the f16 matrix cores: fp32 operands as hi + lo fp16 pairs, three "
+                            "MFMAs per product, under Winograd F(2,3) along x nested in the direct sum along y - 6 multiplications per output instead of 9)",
+                     "w16stack": f"deqsci::w16::conv_w16_kernel<1> (split-fp16 arithmetic under Winograd F(2,3) along x nested in the direct sum along y; ONE launch = the "
+                                 f"denoiser's {nlay} consecutive conv3x3 64->64 + bias + ReLU layers over a slice of {nimg} images, tiles synchronised by per-tile "
+                                 "progress words, the slice's activations resident in the Infinity Cache; flops and time are the whole launch's)",
                      "f44": "deqsci::w44::winograd44_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(4x4,3x3) on fp32 MFMA)",
                      "f22": "deqsci::winograd_conv64_kernel (conv3x3 64->64 + bias + ReLU, Winograd F(2x2,3x3) on fp32 MFMA)"}[kind]
             forms[kind] = {"kernel": kname,
                            "bound": "mfma", "achieved": direct * mult / cavg / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": direct * mult / cavg / 1e12 / peak, "traffic": wtraffic,
+                           # where `traffic` comes from: a rocprofv3 --pmc pass of the same launch shape on another box (FETCH_SIZE / WRITE_SIZE:
+                           # bytes at the L2's fabric side, in front of the Infinity Cache - NOT HBM bytes for a cache-resident slice); null: no pass
+                           "traffic_source": wsource, "traffic_counts": "fabric-side bytes (L2 <-> Infinity Cache / HBM), not HBM bytes",
                            # executed = the MFMA flops the kernel's algorithm issues (what `achieved` / `frac` price: matrix-pipe utilisation);
                            # algorithmic = the direct-convolution flops of the layer, SURVEY 8(d) / section 6 (`frac_useful`)
                            "executed_mfma_flops_per_launch": direct * mult, "algorithmic_flops_per_launch": direct,
@@ -457,6 +479,9 @@ def run_rank(args):
                                            "(1.9-2.0 GHz, not 2.4): see DESIGN.md section 6",
                                     "s16stack": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; the launch runs against the chip's power limit (1.6 GHz, not 2.4): "
                                                 "see DESIGN.md section 6.4",
+                                    "w16": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; executed = 2 x the direct-convolution flops (3 products x 6 / 9)",
+                                    "w16stack": "v_mfma_f32_32x32x16_f16, peak = dense f16 MFMA; executed = 2 x the direct-convolution flops (three f16 products per "
+                                                "multiplication, 6 multiplications per output instead of 9): see DESIGN.md section 6.5",
                                     "f44": "F(4x4,3x3) executes 0.5625x the MFMA flops of F(2x2,3x3) for the same layer: frac prices executed MFMA work",
                                     "f22": "F(2x2,3x3): the launcher's choice below one wave of 16 x 32 block tiles"}[kind]}
         if forms:

@@ -56,6 +56,8 @@ SIGNATURES = {
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
     "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
+    "deqsci_ffdnet_head_p32": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr],
+    "deqsci_ffdnet_tail_p32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
     "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_event_create": [ctypes.POINTER(_ptr)],
     "deqsci_event_destroy": [_ptr],
@@ -998,6 +1000,39 @@ def conv3x3_c64_wino16(x, weights, bias=None, relu=True, out=None, events=None, 
     return o
 
 
+def ffdnet_head_p32(x, weights, sigma, out=None, in_rng=None, in_exp=SP16_DEFAULT_EXP, out_rng=None, out_exp=SP16_DEFAULT_EXP):
+    """ffdnet_head_split16 writing a P32 (the input of a run of conv3x3_c64_wino16 layers): same weights, same arithmetic, 2^e y unsplit."""
+    n, c, H2, W2 = x.shape
+    if c != 1 or H2 % 2 or W2 % 2 or not isinstance(weights, HeadSplit16Weights):
+        raise DeqsciHipError(f"ffdnet_head_p32: (n,1,even,even) image and HeadSplit16Weights required, got {tuple(x.shape)}")
+    if sigma.numel() not in (1, n) or sigma.dtype != torch.float32 or not sigma.is_cuda:
+        raise DeqsciHipError("ffdnet_head_p32: sigma must be a fp32 GPU tensor with 1 or n elements")
+    H, W = H2 // 2, W2 // 2
+    o = out if out is not None else P32.empty(n, H, W, x.device)
+    if not isinstance(o, P32) or (o.n, o.H, o.W) != (n, H, W):
+        raise DeqsciHipError("ffdnet_head_p32: out must be a P32 of the output's shape")
+    o.rng, o.exp = out_rng, int(out_exp)
+    wp = weights.packed if weights.packed.device == x.device else weights.packed.to(x.device)
+    with _dev(x):
+        _check(load().deqsci_ffdnet_head_p32(_p(x, "x"), wp.data_ptr(), sigma.data_ptr(), 0 if sigma.numel() == 1 else sigma.stride(0),
+                                             o.t.data_ptr(), n, H, W, weights.sw, _rng(in_rng, n), int(in_exp), _rng(out_rng, n), o.exp,
+                                             _stream()), "ffdnet_head_p32")
+    return o
+
+
+def ffdnet_tail_p32(h, weights, out=None):
+    """tail_split16 (COUT = 4: FFDNet's last layer + pixel shuffle) reading a P32; `weights` = TailSplit16Weights(w)."""
+    _act_check(h, "ffdnet_tail_p32")
+    if not isinstance(weights, TailSplit16Weights) or weights.cout != 4:
+        raise DeqsciHipError("ffdnet_tail_p32: TailSplit16Weights of a (4,64,3,3) weight are required")
+    o = out if out is not None else torch.empty((h.n, 1, 2 * h.H, 2 * h.W), device=h.t.device, dtype=torch.float32)
+    wp = weights.packed if weights.packed.device == h.t.device else weights.packed.to(h.t.device)
+    with _dev(h.t):
+        _check(load().deqsci_ffdnet_tail_p32(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng, h.n), h.exp,
+                                             _stream()), "ffdnet_tail_p32")
+    return o
+
+
 class Wino16Stack(Split16Stack):
     """A RUN of 64->64 layers for deqsci_conv3x3_c64_wino16_stack: Split16Stack with Wino16Weights, block tiles of 8 x 64 pixels and P32
     activations."""
@@ -1054,14 +1089,21 @@ def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None
 class Conv64Weights:
     """The weights of one 64->64 layer for all three kernels.  The split-fp16 pack (a host sync: max |w|) is made here when `s16` is set
     - the engine does whenever its policy can pick that kernel, so that the pack never falls inside a hipGraph capture - or on first use."""
-    __slots__ = ("f22", "f44", "_w", "_s16")
+    __slots__ = ("f22", "f44", "_w", "_s16", "_w16")
 
     def __init__(self, w, s16=False):
         self.f22 = pack_winograd_weights(w)
         self.f44 = pack_winograd44_weights(w)
-        self._w, self._s16 = w.detach(), None
+        self._w, self._s16, self._w16 = w.detach(), None, None
         if s16:
             self._s16 = Split16Weights(self._w)
+            self._w16 = Wino16Weights(self._w)
+
+    @property
+    def w16(self):
+        if self._w16 is None:
+            self._w16 = Wino16Weights(self._w)
+        return self._w16
 
     @property
     def s16(self):

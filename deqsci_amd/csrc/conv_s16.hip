@@ -809,7 +809,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // 128 x 128 against 45 us for reading its input once.
 constexpr int TL_H = 8, TL_W = 32, TL_IW = TL_W + 2, TL_IH = TL_H + 2, TL_PIX = TL_IH * TL_IW;      // 8 x 32 outputs, 10 x 34 = 340 halo pixels
 constexpr int TL_MB = (TL_PIX + 31) / 32;                                                      // 11 blocks of 32 halo pixels
-template <int COUT>
+// P32 = 1: the input is "p32" (csrc/conv_w16.hip: the same 16 planes holding 2^e x as fp32, plane 2 b8 + j = channels 8 b8 + 4 j .. + 4, the
+// columns of every block of 64 with the parities apart): two 16-byte loads per fragment, split into hi + lo on the fly
+template <int COUT, int P32>
 __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ x, const char* __restrict__ Wp, float* __restrict__ out, int H, int W,
                                                        int w_exp, const float* __restrict__ in_amax, int in_exp, int tiles_x, int tiles_y, int n_tiles) {
     constexpr int NCOL = 9 * COUT, NT = (NCOL + 31) / 32, PS = NCOL;              // P row stride in floats (36: float4-aligned; 9)
@@ -828,7 +830,8 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
     const int r0 = by * TL_H, c0 = (rt - by * tiles_x) * TL_W;
     const float oscale = sp16_pow2(-(in_amax ? sp16_act_exp(in_amax[n]) : in_exp) - w_exp);   // acc = 2^(e_in + w_exp) sum w x  ->  true units (the tile's image)
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
-    const int64_t HW = (int64_t)H * W;
+    const int Wq = P32 ? 64 * ((W + 63) / 64) : W;             // row pitch of a plane
+    const int64_t HW = (int64_t)H * Wq;
     const char* xn = x + (int64_t)n * HW * 256;
     // weight operands (B: column = lane % 32 of N tile nt, k block = lane / 32): [chunk][hl][nt][lane][8 halfs]
     h8 Bw[4][2][NT];
@@ -844,6 +847,26 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
         const int q = 32 * mb + pl, row = q / TL_IW, col = q - row * TL_IW;
         const int gr = r0 - 1 + row, gc = c0 - 1 + col;
         const bool ok = mb < TL_MB && q < TL_PIX && gr >= 0 && gr < H && gc >= 0 && gc < W;
+        if (P32) {
+            // plane 2 (2 c + kb) + j: + (4 c + j) HW 16 bytes from the lane's k block; 2^e x as fp32 -> hi + lo
+            const char* px = xn + ((int64_t)(2 * kb) * HW + (int64_t)gr * Wq + (gc & ~63) + ((gc & 1) << 5) + ((gc & 63) >> 1)) * 16;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+                if (ok) {
+                    v0 = *reinterpret_cast<const f32x4*>(px + (int64_t)(4 * c) * HW * 16);
+                    v1 = *reinterpret_cast<const f32x4*>(px + (int64_t)(4 * c + 1) * HW * 16);
+                }
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const _Float16 hh = (_Float16)v[k];
+                    A[c][0][k] = hh;
+                    A[c][1][k] = (_Float16)(v[k] - (float)hh);
+                }
+            }
+            return;
+        }
         const char* px = xn + ((int64_t)kb * HW + (int64_t)gr * W + gc) * 16;   // plane (c, hl, kb): + (4 c + 2 hl) HW 16 bytes
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -902,11 +925,11 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
     }
     if (r < H && cc < W) {
         if (COUT == 4) {        // pixel_shuffle(2): channel 2i+j -> (2r+i, 2c+j)
-            float* op = out + (int64_t)n * 4 * HW + (int64_t)(2 * r) * (2 * W) + 2 * cc;
+            float* op = out + (int64_t)n * 4 * H * W + (int64_t)(2 * r) * (2 * W) + 2 * cc;
             *reinterpret_cast<f32x2*>(op) = (f32x2){o[0], o[COUT > 1 ? 1 : 0]};
             *reinterpret_cast<f32x2*>(op + 2 * W) = (f32x2){o[COUT > 2 ? 2 : 0], o[COUT > 3 ? 3 : 0]};
         } else {
-            out[(int64_t)n * HW + (int64_t)r * W + cc] = o[0];
+            out[(int64_t)n * H * W + (int64_t)r * W + cc] = o[0];
         }
     }
 }
@@ -918,8 +941,9 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
 // the sigma plane in LDS, multiplies by 2^8 and splits them into hi + lo fp16 on the fly; the weight operands (12 fragments) stay in
 // registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
 constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
-template <int TRACK>   // 1: additionally folds max |output| into *track (the measuring launch of the first f-call; the per-value maximum costs the
-                       // gather-bound kernel a quarter of its time, so the other 180 calls run without it)
+template <int TRACK, int P32>   // TRACK = 1: additionally folds max |output| into *track (the measuring launch of the first f-call; the per-value maximum
+                                // costs the gather-bound kernel a quarter of its time, so the other 180 calls run without it); P32 = 1: the output is
+                                // "p32" (csrc/conv_w16.hip): 2^e y as fp32, the lane's four consecutive couts = its pixel's 16 bytes of plane 2 b8 + kb
 __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
                                                        int sigma_stride, char* __restrict__ y, int H, int W, int w_exp, const float* __restrict__ in_amax,
                                                        int in_exp, const float* __restrict__ out_amax, int out_exp, float* __restrict__ track) {
@@ -966,7 +990,8 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
 #pragma unroll
             for (int g = 0; g < 2; ++g) Aw[ks][hl][g] = *reinterpret_cast<const h8*>(Wp + ((((ks * 2 + hl) * 2 + g) * 64 + lane) * 16));
     __syncthreads();
-    const int64_t HW = (int64_t)H * W;
+    const int Wq = P32 ? 64 * ((W + 63) / 64) : W;             // row pitch of an output plane
+    const int64_t HW = (int64_t)H * Wq;
     i32x4 orsrc;
     {
         const uint64_t ob = (uint64_t)(y + (int64_t)n * HW * 256);
@@ -1014,7 +1039,25 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
             for (int g = 0; g < 2; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Aw[ks][0][g], Bh[ks], acc[g], 0, 0, 0);
         // D[g][i]: cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of position (r0 + lr, c0 + pl): ReLU, x 2^8, split, lane exchange, sp16 stores
         const int r = r0 + lr, c = c0 + pl;
-        const uint32_t pix = (r < H && c < W) ? (uint32_t)((kb * (int)HW + r * W + c) * 16) : RAW_OOB;
+        const uint32_t pix = !(r < H && c < W) ? RAW_OOB
+                             : P32 ? (uint32_t)((kb * (int)HW + r * Wq + (c & ~63) + ((c & 1) << 5) + ((c & 63) >> 1)) * 16)
+                                   : (uint32_t)((kb * (int)HW + r * W + c) * 16);
+        if (P32) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 t;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        t[k] = __builtin_elementwise_maximum(acc[g][4 * gq + k] * oscale, 0.0f);
+                        if (TRACK && pix != RAW_OOB) tmax = fmaxf(tmax, t[k]);
+                    }
+                    const uint32_t so = uniform((uint32_t)(2 * (4 * g + gq)) * (uint32_t)HW * 16u);
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(t), "v"(pix), "s"(orsrc), "s"(so) : "memory");
+                }
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -1149,7 +1192,7 @@ extern "C" int deqsci_absmax_f32(const float* x, int64_t n, int64_t count, float
     return launch_status();
 }
 
-template <int COUT>
+template <int COUT, int P32 = 0>
 static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax,
                          int in_exp, deqsci_stream_t stream) {
     if (!x_sp16 || !w_packed || !out) return DEQSCI_ERR_NULL;
@@ -1159,7 +1202,8 @@ static int tail_s16_impl(const void* x_sp16, const void* w_packed, float* out, i
     const int64_t tiles_x = ceil_div(W, s16::TL_W), tiles_y = ceil_div(H, s16::TL_H), n_tiles = n * tiles_x * tiles_y;
     if (n_tiles > (1 << 30)) return DEQSCI_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)(8 * ceil_div(n_tiles, 8)));
-    hipLaunchKernelGGL(s16::tail_s16_kernel<COUT>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
+    if (P32 && H * (64 * ceil_div(W, 64)) * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((s16::tail_s16_kernel<COUT, P32>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const char*>(x_sp16),
                        static_cast<const char*>(w_packed), out, (int)H, (int)W, w_exp, in_amax, in_exp, (int)tiles_x, (int)tiles_y, (int)n_tiles);
     return launch_status();
 }
@@ -1169,25 +1213,44 @@ extern "C" int deqsci_ffdnet_tail_split16(const void* x_sp16, const void* w_pack
     return tail_s16_impl<4>(x_sp16, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
 }
 
+extern "C" int deqsci_ffdnet_tail_p32(const void* x_p32, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
+                                      const float* in_amax, int in_exp, deqsci_stream_t stream) {
+    return tail_s16_impl<4, 1>(x_p32, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
+}
+
 extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
                                                const float* in_amax, int in_exp, deqsci_stream_t stream) {
     return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
 }
 
+template <int P32>
+static int head_s16_impl(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_out,
+                         int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp, const float* out_amax,
+                         int out_exp, float* track_amax, deqsci_stream_t stream) {
+    if (!x || !w_packed || !sigma || !h_out) return DEQSCI_ERR_NULL;
+    if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
+    const int64_t pitch = P32 ? 64 * ceil_div(W, 64) : W;
+    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || H * pitch * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
+    if (bad_exp(w_exp) || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(w_packed) || !aligned16(h_out)) return DEQSCI_ERR_ALIGN;
+    const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
+    if (track_amax)
+        hipLaunchKernelGGL((s16::head_s16_kernel<1, P32>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                           (int)sigma_stride, static_cast<char*>(h_out), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
+    else
+        hipLaunchKernelGGL((s16::head_s16_kernel<0, P32>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
+                           (int)sigma_stride, static_cast<char*>(h_out), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
+    return launch_status();
+}
+
 extern "C" int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_sp16,
                                           int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp, const float* out_amax,
                                           int out_exp, float* track_amax, deqsci_stream_t stream) {
-    if (!x || !w_packed || !sigma || !h_sp16) return DEQSCI_ERR_NULL;
-    if (n <= 0 || H <= 0 || W <= 0 || sigma_stride < 0) return DEQSCI_ERR_SHAPE;
-    if (n > 65535 || H > (1 << 20) || W > (1 << 20) || H * W * 256 + 16 > (int64_t)s16::RAW_OOB) return DEQSCI_ERR_UNSUPPORTED;
-    if (bad_exp(w_exp) || bad_exp(in_exp) || bad_exp(out_exp)) return DEQSCI_ERR_UNSUPPORTED;
-    if (!aligned16(w_packed) || !aligned16(h_sp16)) return DEQSCI_ERR_ALIGN;
-    const dim3 grid((unsigned)ceil_div(W, s16::HS_W), (unsigned)ceil_div(H, s16::HS_H), (unsigned)n);
-    if (track_amax)
-        hipLaunchKernelGGL(s16::head_s16_kernel<1>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
-                           (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
-    else
-        hipLaunchKernelGGL(s16::head_s16_kernel<0>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), x, static_cast<const char*>(w_packed), sigma,
-                           (int)sigma_stride, static_cast<char*>(h_sp16), (int)H, (int)W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax);
-    return launch_status();
+    return head_s16_impl<0>(x, w_packed, sigma, sigma_stride, h_sp16, n, H, W, w_exp, in_amax, in_exp, out_amax, out_exp, track_amax, stream);
+}
+
+extern "C" int deqsci_ffdnet_head_p32(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_p32,
+                                      int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp, const float* out_amax,
+                                      int out_exp, deqsci_stream_t stream) {
+    return head_s16_impl<1>(x, w_packed, sigma, sigma_stride, h_p32, n, H, W, w_exp, in_amax, in_exp, out_amax, out_exp, nullptr, stream);
 }

@@ -43,10 +43,14 @@
 #pragma clang diagnostic ignored "-Winline-asm"
 
 #ifndef W16_PHASES
-#define W16_PHASES 8        // the workgroups start in this many phases spread over W16_SPREAD shader cycles (see the kernel's prologue); 1: together
+#define W16_PHASES 1        // (A/B) > 1: the workgroups start in this many phases spread over W16_SPREAD shader cycles (see the kernel's prologue)
 #endif
 #ifndef W16_SPREAD
 #define W16_SPREAD 40000    // ~ one tile
+#endif
+#ifndef W16_PRIO
+#define W16_PRIO 0          // (A/B) issue priority of the two waves of a SIMD (w, w + 4): 0 = left to the arbiter (the older wave, 0-3, wins), 1 = waves 4-7
+                            // at s_setprio 1 throughout, 2 = the winner alternates half-stage by half-stage, 3 = group by group
 #endif
 #ifndef W16_ABL
 #define W16_ABL 0     // timing ablations only (results wrong): 1 = no DMA inside the half-stages, 2 = no transform, 4 = no epilogue, 8 = epilogue without its stores
@@ -311,9 +315,11 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
             else if (h == 1 && k < W_INSTR + RAW_INSTR) { if (rnext) raw_piece((c + 2) & 3, c & 1, k - W_INSTR); }
         };
         const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (W16_PRIO == 2) { if (((wave >> 2) ^ hs) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int slot = (3 * hs + dy) & 1;
+            if (W16_PRIO == 3) { if (((wave >> 2) ^ (3 * hs + dy)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
             if (dy == 2) {
                 W16_MARK(h);
                 // what the successor reads has to be there: its weights (issued a half-stage ago) and - h = 1 - its halo chunk (two ago); a halo
@@ -378,15 +384,14 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         fbase = __hip_atomic_load(flags + (int64_t)t_first * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fgiveup = __hip_atomic_load(flags + (int64_t)n_tiles * STACK_FLAG_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- de-phasing.  Every workgroup does the same work from the same start: left alone they all store their tile (128 KB each, 32 MB in
-    // all) in the same two microseconds and compute in the other twenty - the write path saturates (~4.5 TB/s, whether the lines stay in the
-    // Infinity Cache or not) and then idles.  Workgroups with more than one tile therefore start in W16_PHASES phases spread over about a
-    // tile's time, so that at any moment an eighth of them stores.  (Neighbouring tiles of a stack launch tolerate it: a tile's next layer
-    // is a whole pass over the workgroup's tiles away.)
+    // ---- (A/B, off) de-phasing: every workgroup does the same work from the same start and stores its tile at the same moment.  Starting them in
+    // phases took 18 % off a launch while the kernel's stores were half-line writes (116 -> 95 us at 32 images); with the column parities
+    // apart (full 128-byte lines) a tile's stores are 6 % of a launch and the phases change nothing (profiles/r05_w16_form2_phases*.txt).
     if (W16_PHASES > 1 && t_first + t_step < t_end) {
         const int phase = ((int)blockIdx.x >> 3) % W16_PHASES;
         for (int i = 0; i < phase * (W16_SPREAD / W16_PHASES / (64 * 100)); ++i) __builtin_amdgcn_s_sleep(100);
     }
+    if (W16_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     // ---- prologue: bias, chunks 0 and 1 and the first weight half of the first tile, the transform of its first halo row
 #ifdef W16_STAMP
     if (wave == 0) bias_s[lane] = 0.0f;                       // (the profiling build takes its stamp buffer through the bias pointer)
@@ -483,8 +488,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         const bool rn = STACK ? s3_raw : next;                 // the next tile's first two halo chunks go out in half-stages 5 and 7
         half_stage(5, true, rn, false, nothing, no_shadow);
         half_stage(6, next, false, rn, nothing, no_shadow);
-        Done d;
-        half_stage(7, next, rn, false, nothing, [&](int m) __attribute__((always_inline)) { if (m == 28) d = tile_done(t_cur); });
+        // (where this tile's outputs go: the tile before's went out in half-stage 0)
+        half_stage(7, next, rn, false, nothing, [&](int m) __attribute__((always_inline)) { if (m == 28) dp = tile_done(t_cur); });
         raw_flying = rn;
 
         // ---- epilogue: y[2t] = M0 + M1 + M2, y[2t + 1] = M1 - M2 - M3, x 2^(e_out - e_in - w_exp), + bias, ReLU (the NaN-propagating maximum).
@@ -497,18 +502,17 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
             for (int g = 0; g < 2; ++g) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    const f32x4 bz = *reinterpret_cast<const lds_f32x4*>(bsl + 32 * g + 8 * gq + 4 * kb) * d.bscale;
+                    const f32x4 bz = *reinterpret_cast<const lds_f32x4*>(bsl + 32 * g + 8 * gq + 4 * kb) * dp.bscale;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int i = 4 * gq + k;
                         const float m0 = acc[0][g][i], m1 = acc[1][g][i], m2 = acc[2][g][i], m3 = acc[3][g][i];
                         const float y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
-                        o[g][gq][0][k] = __builtin_elementwise_maximum(__builtin_fmaf(y0, d.oscale, bz[k]), floor_);
-                        o[g][gq][1][k] = __builtin_elementwise_maximum(__builtin_fmaf(y1, d.oscale, bz[k]), floor_);
+                        o[g][gq][0][k] = __builtin_elementwise_maximum(__builtin_fmaf(y0, dp.oscale, bz[k]), floor_);
+                        o[g][gq][1][k] = __builtin_elementwise_maximum(__builtin_fmaf(y1, dp.oscale, bz[k]), floor_);
                     }
                 }
             }
-            dp = d;
             have_o = true;
         }
         // the next tile's second weight half (issued in half-stage 7's last group, in front of a halo tile that may still fly) has to be there

@@ -64,9 +64,16 @@ class _Denoiser:
     solvers/equilibrium_solvers_yaping.py:402-425."""
 
     def __init__(self, net, fold_bn=True, channels_last=None, fused_epilogue=True, fused_edges=True, winograd=True, conv64="fast",
-                 act_range="data", blk32=True, stack=True):
+                 act_range="data", blk32=True, stack=True, stack_kernel="w16"):
         from .networks import FFDNet
         self.net = net
+        # stack_kernel: which kernel a stack launch of FFDNet's run runs - "w16" (default): the split-fp16 arithmetic under Winograd F(2,3) x
+        # direct (csrc/conv_w16.hip: a third fewer matrix-core products, p32 activations between FFDNet's first and last layer); "s16": the
+        # split-fp16 direct convolution (csrc/conv_s16.hip).  The measuring f-call and runs shorter than STACK_MIN_LAYERS keep the direct kernel.
+        if stack_kernel not in ("w16", "s16"):
+            raise ValueError(f"stack_kernel={stack_kernel!r}: expected 'w16' or 's16'")
+        self.stack_kernel = stack_kernel
+        self._wstacks = {}                                          # first layer of a run -> _hip.Wino16Stack
         # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch per slice of the batch
         # (_hip.conv3x3_c64_split16_stack: tiles synchronised by per-tile progress words instead of kernel boundaries, slices that keep
         # their activations in the Infinity Cache); bit-identical to the per-layer launches, which the measuring f-call keeps
@@ -157,6 +164,7 @@ class _Denoiser:
                          for w, _, _ in layers]
             self.ranges = None
             self._stacks = {}
+            self._wstacks = {}
 
             self.tail_w = self.head_w = None
             self.plain_head_w = self.plain_tail_w = None
@@ -210,6 +218,13 @@ class _Denoiser:
             st = self._stacks[idx[0]] = _hip.Split16Stack([(self.wino[i].s16, self.fast[i][1], self.fast[i][2]) for i in idx], device)
         return st
 
+    def _wstack_for(self, idx, device):
+        """The Wino16Stack of the run of layers idx (built by prepare(), never inside a hipGraph capture)."""
+        st = self._wstacks.get(idx[0])
+        if st is None or st.n_layers != len(idx) or st.table.device != torch.device(device):
+            st = self._wstacks[idx[0]] = _hip.Wino16Stack([(self.wino[i].w16, self.fast[i][1], self.fast[i][2]) for i in idx], device)
+        return st
+
     def _middle_run(self):
         """Indices of the run of 64->64 layers between the edge layers, when the whole run can take the split-fp16 kernel."""
         if self.fast is None or self.wino is None or len(self.fast) < 4 or self.conv64 not in ("fast", "s16"):
@@ -219,7 +234,7 @@ class _Denoiser:
 
     def stack_timed_out(self):
         """(host sync) whether a wait inside a stack launch gave up since the last call: its results are invalid."""
-        return any(st.timed_out() for st in self._stacks.values())
+        return any([st.timed_out() for st in list(self._stacks.values()) + list(self._wstacks.values())])    # (every stack: the words are rearmed)
 
     def _run_layers(self, h, idx, fused):
         if (self.stack and isinstance(h, _hip.Sp16) and len(idx) >= self.STACK_MIN_LAYERS and self._native_out and not self._calibrating
@@ -281,6 +296,8 @@ class _Denoiser:
         run = self._middle_run() if (self.stack and torch.device(device).type == "cuda") else None
         if run is not None and len(run) >= self.STACK_MIN_LAYERS and self.wino[run[0]].s16.packed.is_cuda:
             self._stack_for(run, device)
+            if self.stack_kernel == "w16" and self.tag == "ffdnet" and self.head_w16 is not None and self.tail_w16 is not None:
+                self._wstack_for(run, device)
         if self.tag == "ffdnet":
             t = self.sigma_table
             if t is None or t.numel() < n_calls or t.device != torch.device(device):
@@ -303,10 +320,11 @@ class _Denoiser:
         if cal:
             self.ranges.zero_()
         try:
-            return self._run(z1, x, call, cal)
-        finally:
-            if self._measured:
+            out = self._run(z1, x, call, cal)
+            if self._measured:                                      # (only a call that ran to its end has measured every layer)
                 self._stale = False
+            return out
+        finally:
             self._calibrating = False
 
     def _run(self, z1, x, call, cal):
@@ -322,19 +340,28 @@ class _Denoiser:
                         and run[0] in self._stacks and self._stacks[run[0]].n_layers == len(run)):
                     # slice by slice: first layer -> the run of 64->64 layers as one stack launch -> last layer, each handing its output to the
                     # next through the Infinity Cache (a slice's activation is at most 128 MiB: _hip.split16_stack_per_launch)
-                    n, st, sg = bsz * B, self._stacks[run[0]], self.sigma_table[call:call + 1]
+                    n, sg = bsz * B, self.sigma_table[call:call + 1]
+                    w16 = self.stack_kernel == "w16" and run[0] in self._wstacks and self._wstacks[run[0]].n_layers == len(run)
+                    st = self._wstacks[run[0]] if w16 else self._stacks[run[0]]
                     per = self.stack_per_launch or _hip.split16_stack_per_launch(n, H // 2, W // 2,
-                                                                                  cus=torch.cuda.get_device_properties(x.device).multi_processor_count)
+                                                                                  cus=torch.cuda.get_device_properties(x.device).multi_processor_count,
+                                                                                  tile=st.TILE)
                     bufs, hbuf = st.state(min(per, n), H // 2, W // 2), st.head_buffer(min(per, n), H // 2, W // 2)
                     rows = None if self.ranges is None else self.ranges[run[0]:run[-1] + 2]
                     out = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)
                     for a in range(0, n, per):
                         m = min(per, n - a)
-                        hin = hbuf if m == hbuf.n else _hip.Sp16(hbuf.t[:m], m, hbuf.H, hbuf.W)
-                        hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=None if self.ranges is None else self._slot(0)[a:a + m],
-                                                      out_rng=None if self.ranges is None else self._slot(1)[a:a + m])
-                        ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
-                        _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
+                        hin = hbuf if m == hbuf.n else st.act(hbuf.t[:m], m, hbuf.H, hbuf.W)
+                        in_rng = None if self.ranges is None else self._slot(0)[a:a + m]
+                        out_rng = None if self.ranges is None else self._slot(1)[a:a + m]
+                        if w16:
+                            hs = _hip.ffdnet_head_p32(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
+                            ys = _hip.conv3x3_c64_wino16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
+                            _hip.ffdnet_tail_p32(ys, self.tail_w16, out=out[a:a + m])
+                        else:
+                            hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
+                            ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
+                            _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
                     self.stack_launches += 1
                     return out.reshape(bsz, B, H, W), True
                 if self.head_w is not None and x.is_cuda:
@@ -388,13 +415,18 @@ class _Denoiser:
         return self.net(x5).reshape(bsz, B, H, W), self.tag == "3d_denoiser"
 
 
+class _StackTimeout(Exception):
+    """A wait inside a stack launch gave up (seen behind the first stack f-call of an eager reconstruction)."""
+
+
 class DEQSCIEngine:
     GRAPH_AUTO_PIXELS = 4 * 256 * 256
+    STACK_RETRY_CALLS = 16        # reconstructions on per-layer launches after a stack launch timed out, before the stack launch is tried again
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
                  fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64",
-                 stack=True):
+                 stack=True, stack_kernel="w16"):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if anderson_arith not in ("float64", "reference"):
@@ -427,7 +459,8 @@ class DEQSCIEngine:
         # the first f-call of every reconstruction (fp32, the reference's arithmetic at equilibrium_solvers_yaping.py:397-420, is
         # scale-free; fp16 pieces are not); "fixed" = 2^8 throughout, the round-3 behaviour (activations of a few units).
         self.den = _Denoiser(denoiser, fold_bn=fold_bn, channels_last=channels_last, fused_epilogue=fused_epilogue,
-                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack)
+                             fused_edges=fused_edges, winograd=winograd, conv64=self.conv64_policy, act_range=act_range, blk32=blk32, stack=stack,
+                             stack_kernel=stack_kernel)
         self.den.f22_calls = self.conv64_f22_calls
         self.iterator = iterator
         self.m, self.beta, self.lam = int(m), float(beta), float(lam)
@@ -437,6 +470,8 @@ class DEQSCIEngine:
         # True / False / "auto": replay a captured hipGraph when one reconstruction is at most GRAPH_AUTO_PIXELS
         # measurement-pixels (4 measurements of 256x256), i.e. when launch gaps are a visible share of the run
         self.use_graph = use_graph
+        self._eager = True                # (False while a hipGraph capture records the launches: no host sync then)
+        self._stack_wanted, self._stack_off_for, self.stack_timeouts_total = bool(stack), 0, 0
         self._ws = {}
         self._graph = None
         self.last_info = None
@@ -458,6 +493,10 @@ class DEQSCIEngine:
     # ------------------------------------------------------------------ one f-call = GAP -> denoise -> store -> solve
     def _store_solve(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
         out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
+        if call == 1 and self._eager and self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
+            # the FIRST stack launch of the reconstruction: a wait that gave up (its workgroups were not all resident: somebody else holds CUs)
+            # is seen here, one f-call in - not after 180 f-calls on invalid data.  One host sync per reconstruction (~0.1 ms of queue refill).
+            raise _StackTimeout()
         out = _hip.f32c(out)
         if is_noise:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
@@ -483,18 +522,32 @@ class DEQSCIEngine:
         if not (isinstance(y, torch.Tensor) and y.is_cuda):
             raise _hip.DeqsciHipError("DEQSCIEngine.reconstruct needs GPU tensors; there is no CPU path")
         with torch.cuda.device(y.device):          # events, stream sync and launches all on y's device
-            rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
-            if self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
+            if self._stack_off_for > 0:            # (a stack launch timed out a while ago: per-layer launches for STACK_RETRY_CALLS calls, then try again)
+                self._stack_off_for -= 1
+                if self._stack_off_for == 0 and self._stack_wanted:
+                    self.den.stack, self._graph = True, None
+            timed_out = 0
+            try:
+                rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
+                if self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
+                    raise _StackTimeout()          # (a replayed hipGraph, or a wait that gave up later than the first stack f-call)
+            except _StackTimeout:
                 # a stack launch waits for its own workgroups only - all resident when the device is ours.  A wait that gave up means it is
-                # not (another process holds CUs): that result is invalid; redo it with a launch per layer, and stay there
+                # not (another process holds CUs): that result is invalid; redo it with a launch per layer, and stay there for a while
                 import warnings
                 warnings.warn("deqsci_amd: a wait inside a split-fp16 stack launch timed out (the device's CUs are shared with other work); "
-                              "redoing this call with one launch per layer and keeping that (stack=False) for this engine", RuntimeWarning)
+                              f"redoing this call with one launch per layer and keeping that for the next {self.STACK_RETRY_CALLS} calls of this engine",
+                              RuntimeWarning)
+                self.den.stack_timed_out()         # (rearm every stack's words)
                 self.den.stack = False
                 self.den.stack_launches = 0
                 self._graph = None
+                self._stack_off_for = self.STACK_RETRY_CALLS
+                self.stack_timeouts_total += 1
+                timed_out = 1
                 rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
             self.last_info["stack_launches"], self.den.stack_launches = self.den.stack_launches, 0
+            self.last_info["stack_timeouts"] = timed_out     # 1: a stack launch of THIS call timed out (the result below is the per-layer redo)
             fallback = None
             if self.conv64 == "auto" and not math.isfinite(self.last_info["res"]) and bool(torch.isfinite(y).all()):
                 # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
@@ -559,6 +612,7 @@ class DEQSCIEngine:
     def _enqueue(self, ws, y, Phi4, Phi_sum, initial_point, poll):
         """Every launch of one reconstruction on the current stream.  poll: True = lagged residual read-back with early stop,
         False = one read-back at the end, None = no host traffic at all (what a hipGraph capture records)."""
+        self._eager = poll is not None
         phi = _hip.transpose(Phi4, LAYOUT_BHW)
         ps = Phi_sum if Phi_sum is not None else _hip.phi_sum(phi, LAYOUT_BHW)
         if initial_point is None:

@@ -285,6 +285,16 @@ int deqsci_ffdnet_head_split16(const float* x, const void* w_packed, const float
                                int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp,
                                const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);
 
+/* FFDNet's first and last layer in front of / behind a run of deqsci_conv3x3_c64_wino16 layers: the entry points above writing / reading
+ *     "p32" instead of sp16 (the same planes and ranges, 2^e x unsplit as fp32, the columns of every block of 64 with the parities apart:
+ *     see deqsci_conv3x3_c64_wino16).  Same weights (w_packed of deqsci_ffdnet_head_split16 / deqsci_ffdnet_tail_split16), same
+ *     arithmetic; the tail splits its operand into hi + lo on the fly.  networks/ffdnet/models.py:46-64, functions.py:16-81. */
+int deqsci_ffdnet_head_p32(const float* x, const void* w_packed, const float* sigma, int64_t sigma_stride, void* h_p32,
+                           int64_t n, int64_t H, int64_t W, int w_exp, const float* in_amax, int in_exp,
+                           const float* out_amax, int out_exp, deqsci_stream_t stream);
+int deqsci_ffdnet_tail_p32(const void* x_p32, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                           int w_exp, const float* in_amax, int in_exp, deqsci_stream_t stream);
+
 /* ---- measurement only (bench.py): the same launch with the dispatch's own begin/end timestamps
  * written to two raw hipEvent_t handles (hipExtLaunchKernelGGL), i.e. the duration rocprofv3 reports,
  * without the marker-packet overhead of events recorded around a launch. */

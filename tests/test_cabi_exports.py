@@ -189,8 +189,27 @@ def test_split16_kernels_have_no_spills(tmp_path):
     moving the tile bookkeeping into the MFMA stream: 2-8 spilled registers, tile_done reloading in the middle of the last stage)."""
     report, text = _compile_with_resource_report("conv_s16.hip", tmp_path)
     kernels = re.findall(_RESOURCES % "(?:conv_s16_kernel|tail_s16_kernel|head_s16_kernel)", report, flags=re.S)
-    assert len(kernels) == 8, report[-2000:]       # conv <0,0,0>, <1,0,0>, <0,1,0> (measuring), <0,0,1> (a run of layers); tail <4>, <1>; head <0>, <1> (measuring)
+    # conv <0,0,0>, <1,0,0>, <0,1,0> (measuring), <0,0,1> (a run of layers); tail <4,0>, <4,1> (p32 in), <1,0>; head <0,0>, <1,0> (measuring), <0,1>, <1,1> (p32 out)
+    assert len(kernels) == 11, report[-2000:]
     for name, vgprs, scratch, sspill, vspill in kernels:
         assert int(vgprs) <= 256 and (int(scratch), int(sspill), int(vspill)) == (0, 0, 0), (name, vgprs, scratch, sspill, vspill)
     assert text.count("v_mfma_f32_32x32x16_f16") > 800
     assert "scratch_" not in text and "v_writelane" not in text
+
+
+def test_wino16_kernels_have_no_spills(tmp_path):
+    """The same guard for csrc/conv_w16.hip ("zero-spill guard extended"): the split-fp16 Winograd F(2,3) x direct kernel runs two
+    waves per SIMD on 128 accumulators + a ring of two transformed halo rows + eight weight fragments + the tile's deferred outputs; a
+    spill inside a half-stage is a scratch access and a vmcnt wait behind every LDS-DMA instruction in flight.  Both instantiations
+    (single layer, stack launch) within 256 registers, no scratch; and the stream is what the design says: 8 half-stages x 36 MFMAs per
+    instantiation, the transform's subtractions as single v_sub_f32 (hipcc pairs them into v_pk_add_f32 when left alone: 19 cycles beside
+    an MFMA, profiles/r05_mfma_f16_fillers.jsonl)."""
+    report, text = _compile_with_resource_report("conv_w16.hip", tmp_path)
+    kernels = re.findall(_RESOURCES % "conv_w16_kernel", report, flags=re.S)
+    assert len(kernels) == 2, report[-2000:]
+    for name, vgprs, scratch, sspill, vspill in kernels:
+        # (the stack launch's tile bookkeeping holds more scalars than the 102 scalar registers: a dozen of them live in lanes of a vector
+        # register between tiles - v_writelane / v_readlane at tile boundaries, never memory)
+        assert int(vgprs) <= 256 and (int(scratch), int(vspill)) == (0, 0) and int(sspill) <= (16 if "ILi1E" in name else 0), (name, vgprs, scratch, sspill, vspill)
+    assert text.count("v_mfma_f32_32x32x16_f16") == 2 * 8 * 36
+    assert "scratch_" not in text and "v_pk_add_f32" not in text
