@@ -192,6 +192,9 @@ def parse_args(argv=None):
     ap.add_argument("--conv64-f22-calls", type=int, default=None, help="run the first K f-calls on F(2x2,3x3) whatever the policy")
     ap.add_argument("--no-other-kernel", action="store_true", help="skip the extra steps under the other conv64 policies")
     ap.add_argument("--other-steps", type=int, default=5, help="timed steps per other conv64 policy (behind one warm-up step)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other BASELINE configurations and variants (reference f-call count, the other stack kernel, the "
+                         "reference's Anderson arithmetic, SimpleCNN, 512x512x16)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the oracle spot check of the timed configuration (2 measurements, 10 iterations)")
     ap.add_argument("--iters", type=int, default=180)
     ap.add_argument("--denoiser", default="ffdnet", choices=["ffdnet", "SimpleCNN"])
@@ -219,15 +222,16 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
-def build_engine(args, dev, conv64=None, f22_calls="args"):
+def build_engine(args, dev, conv64=None, f22_calls="args", denoiser=None, **over):
     from deqsci_amd import checkpoint
     from deqsci_amd.cli import build_denoiser
     from deqsci_amd.engine import DEQSCIEngine
     # MIOpen find mode (cudnn.benchmark) is deliberately left off: on this conv it picks a slower igemm tile
     # (642 us vs 579 us) and writes that choice into the user find-db (measured, tools/gpu_12.sh).
-    net = build_denoiser(args.denoiser).eval()
+    denoiser = denoiser or args.denoiser
+    net = build_denoiser(denoiser).eval()
     net.load_state_dict({k.replace("nonlinear_op.", ""): v for k, v in
-                         checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if args.denoiser == "ffdnet" else "cnn"))[0].items()})
+                         checkpoint.read_state_dict(checkpoint.shipped("ffdnet_gray" if denoiser == "ffdnet" else "cnn"))[0].items()})
     net = net.to(dev)
     kw = {}
     if args.no_graph:
@@ -240,6 +244,7 @@ def build_engine(args, dev, conv64=None, f22_calls="args"):
         kw["stack"] = False
     if args.stack_kernel != "w16":
         kw["stack_kernel"] = args.stack_kernel
+    kw.update(over)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
                        fused_edges=not args.no_fused_edges, winograd=not args.no_winograd,
@@ -518,6 +523,42 @@ def run_rank(args):
                     out["other_conv64_policies"][name] = {"value": M * B / dt2, "unit": "frames/s", "ms_per_step": 1e3 * dt2, "steps": args.other_steps,
                                                           "warmup": 1}
                     del eng2, step2
+            if not args.no_other_configs and args.denoiser == "ffdnet" and args.size == "256x256x8":
+                # short runs OUTSIDE the timed region, same box, each behind a warm-up step: (a) the reference's f-call count measured, not
+                # scaled (extra_call = the dead f(z) of new_equilibrium_utils_yaping.py:271-272: 182 calls); (b) the other stack kernel; (c) the
+                # reference's Anderson arithmetic (fp32 Gram: anderson_arith="reference"); (d) BASELINE config 5 (SimpleCNN) and (e) config 4
+                # (512x512x16, one step): driver-run numbers for the configurations the headline is not quoted on
+                def short(eng_, y_, Phi_, M_, steps):
+                    st_ = make_step(eng_, y_, Phi_, M_, distributed.GatherTimer())
+                    st_()
+                    torch.cuda.synchronize()
+                    t1_ = time.perf_counter()
+                    for _ in range(steps):
+                        st_()
+                    torch.cuda.synchronize()
+                    dt_ = (time.perf_counter() - t1_) / steps
+                    return {"value": M_ * Phi_.shape[-1] / dt_, "unit": "frames/s", "ms_per_step": 1e3 * dt_, "steps": steps, "warmup": 1,
+                            "f_calls_per_step": (eng_.last_info or {}).get("f_calls")}
+                oc = {}
+                e_ = build_engine(args, dev, extra_call=True)
+                oc["value_at_reference_f_calls"] = dict(short(e_, y, Phi, M, 3), what="the same step with the reference's dead extra f-call (extra_call=True): max_iter + 2 calls")
+                del e_
+                other_sk = "s16" if eng.den.stack_kernel == "w16" else "w16"
+                e_ = build_engine(args, dev, stack_kernel=other_sk)
+                oc["other_stack_kernel"] = dict(short(e_, y, Phi, M, 3), stack_kernel=other_sk)
+                del e_
+                other_aa = "reference" if eng.anderson_arith == "float64" else "float64"
+                e_ = build_engine(args, dev, anderson_arith=other_aa)
+                oc["other_anderson_arith"] = dict(short(e_, y, Phi, M, 3), anderson_arith=other_aa)
+                del e_
+                e_ = build_engine(args, dev, denoiser="SimpleCNN")
+                oc["config5_simplecnn"] = dict(short(e_, y, Phi, M, 2), what="BASELINE configs[4]: DE-GAP-CNN denoiser (models/cnn.ckpt), same batch, 180 iterations")
+                del e_
+                y4, Phi4, _ = make_batch(0, 2, 512, 512, 16, args.seed if hasattr(args, "seed") else 1234, dev)
+                e_ = build_engine(args, dev)
+                oc["config4_512x512x16"] = dict(short(e_, y4, Phi4, 2, 1), what="BASELINE configs[3]: 2 measurements of 512x512x16, FFDNet, 180 iterations")
+                del e_, y4, Phi4
+                out["other_configs"] = oc
             if not args.no_hbm_stream:
                 del y, Phi
                 out["hbm_stream_roofline"] = hbm_stream_roofline(H, W, B, eng.m, dev)

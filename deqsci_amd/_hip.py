@@ -32,6 +32,8 @@ SIGNATURES = {
     "deqsci_residual_store_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
     "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_solve_gram_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr, _ptr],
+    "deqsci_residual_store_fine_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
+    "deqsci_anderson_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                     _i64, _i64, _i64, _i64, _int, _int, _ptr],
@@ -64,7 +66,7 @@ SIGNATURES = {
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
 }
 OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
-                 "deqsci_partials_bytes", "deqsci_gram_bytes")
+                 "deqsci_partials_bytes", "deqsci_gram_bytes", "deqsci_gram_fine_bytes")
 
 
 class DeqsciHipError(RuntimeError):
@@ -98,6 +100,8 @@ def load():
     lib.deqsci_partials_bytes.argtypes = [_i64, _i64]
     lib.deqsci_gram_bytes.restype = ctypes.c_size_t
     lib.deqsci_gram_bytes.argtypes = [_i64]
+    lib.deqsci_gram_fine_bytes.restype = ctypes.c_size_t
+    lib.deqsci_gram_fine_bytes.argtypes = [_i64, _i64]
     _lib = lib
     return lib
 
@@ -262,17 +266,36 @@ class AndersonWorkspace:
         self.gram = torch.zeros(lib.deqsci_gram_bytes(bsz) // 8, device=device, dtype=torch.float64)
         self.alpha = torch.zeros((bsz, MAX_M), device=device, dtype=torch.float32)
         self.res = torch.zeros((res_rows, 1 + bsz), device=device, dtype=torch.float32)
+        self.fine = None                  # (anderson_arith = "reference": the fine partials + the persistent fp32 Gram, see fine_buffer)
+
+    def fine_buffer(self):
+        """The `fine` buffer of deqsci_residual_store_fine_f32 / deqsci_anderson_solve_ref_f32 (allocated on first use, zeroed once)."""
+        if self.fine is None:
+            self.fine = torch.zeros(load().deqsci_gram_fine_bytes(self.bsz, self.N) // 4, device=self.F.device, dtype=torch.float32)
+        return self.fine
 
 
-def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
+def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None, fine=False):
+    """fine: additionally write the fine partials of the new Gram row (the reference's fp32 Gram: anderson_solve(..., ref=True))."""
     with _dev(z1):
-        _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
-                                                _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
-                                                n_filled, _stream()), "residual_store")
+        if fine:
+            _check(load().deqsci_residual_store_fine_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
+                                                         _p(x_next, "x_next", True), _p(ws.partials), _p(ws.fine_buffer()), ws.bsz, ws.N, ws.m, slot,
+                                                         n_filled, _stream()), "residual_store_fine")
+        else:
+            _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
+                                                    _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
+                                                    n_filled, _stream()), "residual_store")
 
 
-def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None):
-    """gram32: (bsz, n, n) fp32 - alpha from THAT Gram block with an fp32 LU (the reference's arithmetic, :177-180) instead of the float64 sums."""
+def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None, ref=False):
+    """gram32: (bsz, n, n) fp32 - alpha from THAT Gram block with an fp32 LU (the reference's arithmetic, :177-180) instead of the float64 sums.
+    ref: the same arithmetic from the kernels' own fp32 Gram (the fine partials of residual_store(..., fine=True), a flat fp32 chain along K)."""
+    if ref:
+        with _dev(ws.F):
+            _check(load().deqsci_anderson_solve_ref_f32(_p(ws.partials), _p(ws.fine_buffer()), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
+                                                        ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()), "anderson_solve_ref")
+        return
     if gram32 is not None and (tuple(gram32.shape) != (ws.bsz, n, n) or gram32.dtype != torch.float32 or not gram32.is_contiguous() or not gram32.is_cuda):
         raise DeqsciHipError(f"anderson_solve: gram32 must be a contiguous fp32 GPU tensor of shape {(ws.bsz, n, n)}")
     with _dev(ws.F):

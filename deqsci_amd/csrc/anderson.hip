@@ -21,6 +21,10 @@
 
 namespace deqsci {
 
+// "fine" buffer of anderson_arith = "reference" (per sample): FINE_HDR floats of persistent fp32 Gram matrix, then MAXM columns of
+// `rows` fine partials (rows = K4 blocks x 32)
+constexpr int FINE_HDR = MAXM * MAXM;
+
 // ------------------------------------------------------------------------------------------------
 // K4
 // ------------------------------------------------------------------------------------------------
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
                                                             const float* x_cur, float* __restrict__ F_hist,
                                                             float* __restrict__ G_hist, float* x_next,
                                                             float* __restrict__ partials, int64_t N, int m, int slot,
-                                                            int64_t chunk, int vec) {
+                                                            int64_t chunk, int vec, float* __restrict__ fine) {
     const int64_t s = blockIdx.y;
     const int64_t beg = (int64_t)blockIdx.x * chunk;
     const int64_t end = (beg + chunk < N) ? beg + chunk : N;
@@ -97,6 +101,20 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
 
     __shared__ float red[TB / WAVE][PART_STRIDE];
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    if (fine) {
+        // (anderson_arith = "reference") the FINE partials of the new Gram row: <G_slot, G_j> over the ~64 elements of each group of eight
+        // lanes, column-major [j][row], row = 32 block + group - what deqsci_anderson_solve_ref_f32 adds up ONE AFTER THE OTHER in fp32
+        const int64_t rows = (int64_t)gridDim.x * (TB / 8);
+        float* fs = fine + s * (FINE_HDR + MAXM * rows) + FINE_HDR + (int64_t)blockIdx.x * (TB / 8) + (threadIdx.x >> 3);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            float v = acc[j];
+            v += __shfl_xor(v, 1, WAVE);
+            v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 4, WAVE);
+            if ((lane & 7) == 0) fs[(int64_t)j * rows] = v;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const float v = wave_sum(acc[j]);
@@ -190,7 +208,7 @@ __device__ __forceinline__ void bordered_solve(const double* Gl, double (*M)[MAX
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
                                                               int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32,
-                                                              const float* __restrict__ gram32
+                                                              const float* __restrict__ gram32, float* fine
 #ifdef DEQSCI_DIAG
                                                               , float gram_noise
 #endif
@@ -243,7 +261,42 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
         gs[MAXM * MAXM + 1] = gg;                               // |G_k|^2
         res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
     }
-    if (n > 0) {
+    if (fine) {
+        // ---- anderson_arith = "reference" without a GEMM library: the reference forms G G^T with ONE fp32 torch.bmm over the N = H W B elements
+        // (solvers/new_equilibrium_utils_yaping.py:177-178) - an fp32 accumulation along K whose rounding error (~1e-6 of an entry at N = 2^19,
+        // up to 4e-6: measured on torch 2.10 / MKL, tools/gram_f32_error.py) steers the chaotic FFDNet runs ("Config 2").
+        // The same KIND of sum here: the new row's entries <G_slot, G_j> from K4's fine partials (64 elements each), added ONE AFTER THE OTHER
+        // in fp32 along K - a flat chain of N / 64 additions per entry (1.2e-6 mean, 3e-6 worst against float64 on the same data), one lane
+        // per entry; the other rows persist from the iterations that wrote them, as a deterministic GEMM would recompute them bit for bit.
+        __shared__ float row32[MAXM];
+        const int64_t rows = (int64_t)nchunks * (TB / 8);
+        float* g32 = fine + (int64_t)s * (FINE_HDR + MAXM * rows);
+        if (lane < n_filled) {
+            const float* col = g32 + FINE_HDR + (int64_t)lane * rows;
+            float acc = 0.0f;
+            int64_t r = 0;
+            for (; r + 16 <= rows; r += 16) {
+                const float4 a0 = ld4(col + r), a1 = ld4(col + r + 4), a2 = ld4(col + r + 8), a3 = ld4(col + r + 12);
+                acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
+                acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
+                acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;
+                acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
+            }
+            for (; r < rows; ++r) acc += col[r];
+            row32[lane] = acc;
+            g32[slot * MAXM + lane] = acc;
+            g32[lane * MAXM + slot] = acc;
+        }
+        __syncthreads();
+        if (n > 0) {
+            for (int i = lane; i < n * n; i += WAVE) {
+                const int a = i / n, b = i % n;
+                Gl[a * MAXM + b] = (double)((a == slot) ? row32[b] : (b == slot) ? row32[a] : g32[a * MAXM + b]);
+            }
+            __syncthreads();
+            bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
+        }
+    } else if (n > 0) {
         if (gram32) {
             // the REFERENCE's arithmetic for alpha (new_equilibrium_utils_yaping.py:177-180): the n x n Gram block as the caller's fp32
             // torch.bmm produced it (rows in slot order), the system formed and factorised in fp32 like torch.solve = sgesv.  The residual
@@ -431,9 +484,23 @@ size_t deqsci_partials_bytes(int64_t bsz, int64_t N) {
 
 size_t deqsci_gram_bytes(int64_t bsz) { return (size_t)(bsz * GRAM_STRIDE + 2) * sizeof(double); }   // + arrival ticket
 
+size_t deqsci_gram_fine_bytes(int64_t bsz, int64_t N) {
+    return (size_t)bsz * (size_t)(FINE_HDR + MAXM * deqsci_anderson_chunks(bsz, N) * (TB / 8)) * sizeof(float);
+}
+
+int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
+                                   float* x_next, float* partials, float* fine, int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                                   deqsci_stream_t stream);
+
 int deqsci_residual_store_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
                               float* x_next, float* partials, int64_t bsz, int64_t N, int m, int slot, int n_filled,
                               deqsci_stream_t stream) {
+    return deqsci_residual_store_fine_f32(z1, noise, x_cur, F_hist, G_hist, x_next, partials, nullptr, bsz, N, m, slot, n_filled, stream);
+}
+
+int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
+                                   float* x_next, float* partials, float* fine, int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                                   deqsci_stream_t stream) {
     if (!z1 || !x_cur || !F_hist || !G_hist || !partials) return DEQSCI_ERR_NULL;
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || slot >= n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
@@ -445,7 +512,7 @@ int deqsci_residual_store_f32(const float* z1, const float* noise, const float* 
     const dim3 grid(ceil_div(N, chunk), bsz);
     const int vec = (N % 4 == 0) ? 1 : 0;
     const int pol = pick_policy(bsz * N * 4 * (n_filled + 4), POL_NTLS);
-#define RS_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec)); break;
+#define RS_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec, fine)); break;
     switch (n_filled) {
         RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
         default: return DEQSCI_ERR_UNSUPPORTED;
@@ -462,8 +529,23 @@ int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, f
     return deqsci_anderson_solve_gram_f32(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, nullptr, stream);
 }
 
+static int solve_impl(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                      int slot, int n_filled, int n, float lam, float eps, const float* gram32, float* fine, deqsci_stream_t stream);
+
 int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
                                    int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream) {
+    return solve_impl(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, gram32, nullptr, stream);
+}
+
+int deqsci_anderson_solve_ref_f32(const float* partials, float* fine, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                                  int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    if (!fine) return DEQSCI_ERR_NULL;
+    if (!aligned16(fine)) return DEQSCI_ERR_ALIGN;
+    return solve_impl(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, nullptr, fine, stream);
+}
+
+static int solve_impl(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
+                      int slot, int n_filled, int n, float lam, float eps, const float* gram32, float* fine, deqsci_stream_t stream) {
     if (!partials || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
     if (gram32 && n <= 0) return DEQSCI_ERR_SHAPE;
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
@@ -472,10 +554,10 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
 #ifdef DEQSCI_DIAG
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, fine, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
 #else
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32);
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32, fine);
 #endif
     return launch_status();
 }

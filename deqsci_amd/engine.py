@@ -429,8 +429,8 @@ class DEQSCIEngine:
                  stack=True, stack_kernel="w16"):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
-        if anderson_arith not in ("float64", "reference"):
-            raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'float64' or 'reference'")
+        if anderson_arith not in ("float64", "reference", "reference-bmm"):
+            raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'float64', 'reference' or 'reference-bmm'")
         # How alpha is computed.  "float64" (default): the Gram row accumulated in float64 from the fp32 block partials of K4, the bordered
         # system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference": the reference's own arithmetic for that step,
         # solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over the N = H W B elements (rocBLAS here, MKL there:
@@ -498,15 +498,16 @@ class DEQSCIEngine:
             # is seen here, one f-call in - not after 180 f-calls on invalid data.  One host sync per reconstruction (~0.1 ms of queue refill).
             raise _StackTimeout()
         out = _hip.f32c(out)
+        ref = self.anderson_arith == "reference"               # the reference's fp32 Gram formed by K4 + K5 themselves (no GEMM library)
         if is_noise:
-            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
+            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next, fine=ref)
         else:
-            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
+            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next, fine=ref)
         gram32 = None
-        if self.anderson_arith == "reference" and n_solve > 0:
+        if self.anderson_arith == "reference-bmm" and n_solve > 0:
             G = ws.G[:, :n_solve]                                                               # rows in the reference's slot order k % m
-            gram32 = torch.bmm(G, G.transpose(1, 2))                                            # :178, ONE fp32 GEMM over N elements (rocBLAS)
-        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, gram32=gram32)    # (+ lam I and the fp32 LU of :178-180 in K6)
+            gram32 = torch.bmm(G, G.transpose(1, 2))                                            # :178, ONE fp32 GEMM over N elements (rocBLAS: ~200 us)
+        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, gram32=gram32, ref=ref)    # (+ lam I and the fp32 LU of :178-180 in K6)
 
     def _poll(self, ws, row):
         ws.host_res[row].copy_(ws.res[row], non_blocking=True)

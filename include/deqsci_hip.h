@@ -119,6 +119,22 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
                                    int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                                    float lam, float eps, const float* gram32, deqsci_stream_t stream);
 
+/* The same WITHOUT a GEMM library (anderson_arith = "reference" of the engine): the kernels form the reference's fp32 Gram themselves.
+ *     deqsci_residual_store_fine_f32 = K4 that additionally writes the FINE partials of the new Gram row - <G_slot, G_j> over each
+ *     group of eight lanes' ~64 elements - into `fine` (deqsci_gram_fine_bytes(bsz, N) bytes, caller-owned, ZEROED once: it also holds the
+ *     persistent fp32 Gram matrix); deqsci_anderson_solve_ref_f32 adds them up ONE AFTER THE OTHER in fp32 along K - a flat chain of
+ *     N / 64 additions per entry, the kind of sum one fp32 torch.bmm over N elements is (:177-178; rounding ~1e-6 of an entry at N = 2^19,
+ *     tools/gram_f32_error.py) -, refreshes row / column `slot` of the fp32 Gram, forms the bordered system in fp32 and factorises it in
+ *     fp32 (:180, sgesv).  Residuals and the float64 Gram of `gram` are kept exactly as by the entry points above. */
+size_t deqsci_gram_fine_bytes(int64_t bsz, int64_t N);
+int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur,
+                                   float* F_hist, float* G_hist, float* x_next, float* partials, float* fine,
+                                   int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                                   deqsci_stream_t stream);
+int deqsci_anderson_solve_ref_f32(const float* partials, float* fine, void* gram, float* alpha, float* res,
+                                  int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
+                                  float lam, float eps, deqsci_stream_t stream);
+
 /* K7  x_out = beta * sum_i alpha_i F_i + (1-beta) * sum_i alpha_i X_i,  X_i = F_i - G_i   (:182) */
 int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha,
                             float* x_out, float beta, int n, int64_t bsz, int64_t N, int m,

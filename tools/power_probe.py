@@ -69,7 +69,7 @@ def main():
     x = torch.randn(NI, 64, 128, 128, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
     if zero:
         x.zero_(); w.zero_()
-    kind = os.environ.get("PROBE_KERNEL", "s16")               # s16 | f44 (Winograd F(4x4,3x3), blk32 -> blk32) | f22 (Winograd F(2x2,3x3))
+    kind = os.environ.get("PROBE_KERNEL", "s16")               # s16 | stack | w16 | w16stack | f44 (Winograd F(4x4,3x3), blk32 -> blk32) | f22 (Winograd F(2x2,3x3))
     if kind == "s16":
         xs = _hip.to_split16(x); out = _hip.Sp16.empty(NI, 128, 128, "cuda"); Wsp = _hip.Split16Weights(w)
         launch = lambda: _hip.conv3x3_c64_split16(xs, Wsp, b, True, out=out)  # noqa: E731
@@ -77,6 +77,13 @@ def main():
         xs = _hip.to_split16(x)
         stack = _hip.Split16Stack([(_hip.Split16Weights(w), b, True)] * 13, "cuda")
         launch = lambda: _hip.conv3x3_c64_split16_stack(xs, stack)  # noqa: E731
+    elif kind == "w16stack":                                   # ... on the Winograd kernel (csrc/conv_w16.hip)
+        xp = _hip.P32.from_nchw(x)
+        stack = _hip.Wino16Stack([(_hip.Wino16Weights(w), b, True)] * 13, "cuda")
+        launch = lambda: _hip.conv3x3_c64_wino16_stack(xp, stack)  # noqa: E731
+    elif kind == "w16":
+        xp = _hip.P32.from_nchw(x); op = _hip.P32.empty(NI, 128, 128, "cuda"); Ww = _hip.Wino16Weights(w)
+        launch = lambda: _hip.conv3x3_c64_wino16(xp, Ww, b, True, out=op)  # noqa: E731
     elif kind == "f44":
         xb = _hip.Blk32.from_nchw(x); ob = _hip.Blk32.empty(NI, 128, 128, "cuda"); U = _hip.pack_winograd44_weights(w)
         launch = lambda: _hip.conv3x3_c64_winograd44(xb, U, b, True, out=ob, out_blk=True)  # noqa: E731
@@ -90,7 +97,7 @@ def main():
     idle = {k: int(open(f).read().strip()) for k, f in files.items() if k != "power1_cap"} if files else {}
     s = Sampler({k: f for k, f in files.items() if k != "power1_cap"})
     s.start()
-    n = (12000 if kind == "s16" else 8000) * max(1, 64 // NI) // (1 if NI == 64 else 2) // (13 if kind == "stack" else 1)
+    n = (12000 if kind == "s16" else 8000) * max(1, 64 // NI) // (1 if NI == 64 else 2) // (13 if kind in ("stack", "w16stack") else 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
