@@ -211,6 +211,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-slice-edges", action="store_true", help="FFDNet's first and last layer over the whole batch instead of slice by slice around the stack launches (A/B)")
     ap.add_argument("--stack-kernel", default="w16", choices=["w16", "s16"],
                     help="kernel of FFDNet's stack launches: w16 = split-fp16 under Winograd F(2,3) x direct (csrc/conv_w16.hip), s16 = split-fp16 direct (A/B)")
+    ap.add_argument("--anderson-arith", default="reference", choices=["reference", "float64", "reference-bmm"],
+                    help="arithmetic of Anderson's alpha: reference = fp32 Gram + fp32 LU as solvers/new_equilibrium_utils_yaping.py:177-180 (what the drop-in "
+                         "DEQFixedPoint runs); float64 = exactly accumulated Gram; reference-bmm = round 4's torch.bmm form (A/B)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -244,6 +247,7 @@ def build_engine(args, dev, conv64=None, f22_calls="args", denoiser=None, **over
         kw["stack"] = False
     if args.stack_kernel != "w16":
         kw["stack_kernel"] = args.stack_kernel
+    kw["anderson_arith"] = args.anderson_arith
     kw.update(over)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,

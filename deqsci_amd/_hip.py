@@ -32,8 +32,7 @@ SIGNATURES = {
     "deqsci_residual_store_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
     "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_solve_gram_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr, _ptr],
-    "deqsci_residual_store_fine_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
-    "deqsci_anderson_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_anderson_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                     _i64, _i64, _i64, _i64, _int, _int, _ptr],
@@ -66,7 +65,7 @@ SIGNATURES = {
     "deqsci_event_elapsed_ms": [_ptr, _ptr, ctypes.POINTER(_f32)],
 }
 OTHER_EXPORTS = ("deqsci_version", "deqsci_error_string", "deqsci_anderson_chunks",
-                 "deqsci_partials_bytes", "deqsci_gram_bytes", "deqsci_gram_fine_bytes")
+                 "deqsci_partials_bytes", "deqsci_gram_bytes", "deqsci_gram_ref_bytes")
 
 
 class DeqsciHipError(RuntimeError):
@@ -100,8 +99,8 @@ def load():
     lib.deqsci_partials_bytes.argtypes = [_i64, _i64]
     lib.deqsci_gram_bytes.restype = ctypes.c_size_t
     lib.deqsci_gram_bytes.argtypes = [_i64]
-    lib.deqsci_gram_fine_bytes.restype = ctypes.c_size_t
-    lib.deqsci_gram_fine_bytes.argtypes = [_i64, _i64]
+    lib.deqsci_gram_ref_bytes.restype = ctypes.c_size_t
+    lib.deqsci_gram_ref_bytes.argtypes = [_i64]
     _lib = lib
     return lib
 
@@ -266,35 +265,32 @@ class AndersonWorkspace:
         self.gram = torch.zeros(lib.deqsci_gram_bytes(bsz) // 8, device=device, dtype=torch.float64)
         self.alpha = torch.zeros((bsz, MAX_M), device=device, dtype=torch.float32)
         self.res = torch.zeros((res_rows, 1 + bsz), device=device, dtype=torch.float32)
-        self.fine = None                  # (anderson_arith = "reference": the fine partials + the persistent fp32 Gram, see fine_buffer)
+        self.gram32 = None                # (anderson_arith = "reference": the persistent fp32 Gram of deqsci_anderson_solve_ref_f32, see gram32_state)
 
-    def fine_buffer(self):
-        """The `fine` buffer of deqsci_residual_store_fine_f32 / deqsci_anderson_solve_ref_f32 (allocated on first use, zeroed once)."""
-        if self.fine is None:
-            self.fine = torch.zeros(load().deqsci_gram_fine_bytes(self.bsz, self.N) // 4, device=self.F.device, dtype=torch.float32)
-        return self.fine
+    def gram32_state(self):
+        """(bsz, MAX_M, MAX_M) fp32: the Gram matrix deqsci_anderson_solve_ref_f32 keeps between calls (allocated on first use)."""
+        if self.gram32 is None:
+            self.gram32 = torch.zeros(self.bsz, load().deqsci_gram_ref_bytes(self.bsz) // (4 * self.bsz), device=self.F.device, dtype=torch.float32)
+            self.gram32 = self.gram32.view(self.bsz, MAX_M, MAX_M)
+        return self.gram32
 
 
-def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None, fine=False):
-    """fine: additionally write the fine partials of the new Gram row (the reference's fp32 Gram: anderson_solve(..., ref=True))."""
+def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
     with _dev(z1):
-        if fine:
-            _check(load().deqsci_residual_store_fine_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
-                                                         _p(x_next, "x_next", True), _p(ws.partials), _p(ws.fine_buffer()), ws.bsz, ws.N, ws.m, slot,
-                                                         n_filled, _stream()), "residual_store_fine")
-        else:
-            _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
-                                                    _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
-                                                    n_filled, _stream()), "residual_store")
+        _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
+                                                _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
+                                                n_filled, _stream()), "residual_store")
 
 
 def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None, ref=False):
     """gram32: (bsz, n, n) fp32 - alpha from THAT Gram block with an fp32 LU (the reference's arithmetic, :177-180) instead of the float64 sums.
-    ref: the same arithmetic from the kernels' own fp32 Gram (the fine partials of residual_store(..., fine=True), a flat fp32 chain along K)."""
+    ref: the same arithmetic without a GEMM library - the new Gram row summed by the build's own kernel in the order of the reference's torch.bmm
+    (sixteen interleaved FMA chains per entry, csrc/anderson.hip gram_row_chain16_kernel) from the history residual_store just wrote."""
     if ref:
         with _dev(ws.F):
-            _check(load().deqsci_anderson_solve_ref_f32(_p(ws.partials), _p(ws.fine_buffer()), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
-                                                        ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()), "anderson_solve_ref")
+            _check(load().deqsci_anderson_solve_ref_f32(_p(ws.G), _p(ws.partials), _p(ws.gram32_state()), ws.gram.data_ptr(), _p(ws.alpha),
+                                                        _p(ws.res[res_row]), ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()),
+                   "anderson_solve_ref")
         return
     if gram32 is not None and (tuple(gram32.shape) != (ws.bsz, n, n) or gram32.dtype != torch.float32 or not gram32.is_contiguous() or not gram32.is_cuda):
         raise DeqsciHipError(f"anderson_solve: gram32 must be a contiguous fp32 GPU tensor of shape {(ws.bsz, n, n)}")

@@ -21,10 +21,6 @@
 
 namespace deqsci {
 
-// "fine" buffer of anderson_arith = "reference" (per sample): FINE_HDR floats of persistent fp32 Gram matrix, then MAXM columns of
-// `rows` fine partials (rows = K4 blocks x 32)
-constexpr int FINE_HDR = MAXM * MAXM;
-
 // ------------------------------------------------------------------------------------------------
 // K4
 // ------------------------------------------------------------------------------------------------
@@ -33,7 +29,7 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
                                                             const float* x_cur, float* __restrict__ F_hist,
                                                             float* __restrict__ G_hist, float* x_next,
                                                             float* __restrict__ partials, int64_t N, int m, int slot,
-                                                            int64_t chunk, int vec, float* __restrict__ fine) {
+                                                            int64_t chunk, int vec) {
     const int64_t s = blockIdx.y;
     const int64_t beg = (int64_t)blockIdx.x * chunk;
     const int64_t end = (beg + chunk < N) ? beg + chunk : N;
@@ -101,20 +97,6 @@ __global__ __launch_bounds__(TB) void residual_store_kernel(const float* __restr
 
     __shared__ float red[TB / WAVE][PART_STRIDE];
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    if (fine) {
-        // (anderson_arith = "reference") the FINE partials of the new Gram row: <G_slot, G_j> over the ~64 elements of each group of eight
-        // lanes, column-major [j][row], row = 32 block + group - what deqsci_anderson_solve_ref_f32 adds up ONE AFTER THE OTHER in fp32
-        const int64_t rows = (int64_t)gridDim.x * (TB / 8);
-        float* fs = fine + s * (FINE_HDR + MAXM * rows) + FINE_HDR + (int64_t)blockIdx.x * (TB / 8) + (threadIdx.x >> 3);
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            float v = acc[j];
-            v += __shfl_xor(v, 1, WAVE);
-            v += __shfl_xor(v, 2, WAVE);
-            v += __shfl_xor(v, 4, WAVE);
-            if ((lane & 7) == 0) fs[(int64_t)j * rows] = v;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const float v = wave_sum(acc[j]);
@@ -205,10 +187,116 @@ __device__ __forceinline__ void bordered_solve(const double* Gl, double (*M)[MAX
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// anderson_arith = "reference": the new row of G G^T in the SUMMATION ORDER of the reference's fp32 torch.bmm
+// ------------------------------------------------------------------------------------------------
+// The reference forms G G^T with one fp32 torch.bmm over the N = H W B elements (solvers/new_equilibrium_utils_yaping.py:177-178); on the
+// CPU that produced tests/golden that is MKL's sgemm, and for 5 x N times N x 5 its K loop is SIXTEEN interleaved FMA chains per entry -
+// chain c takes k = c, c + 16, c + 32, ... one fused multiply-add after the other - summed pairwise at the end (tools/gram_on_real_history.py:
+// an emulation of exactly that lands within one ulp of torch.bmm on every entry, bit-equal on most).  What this order does to the loop's own
+// residuals (heavy-tailed: a few moving objects carry the energy) is not noise: in a chain of 2^15 steps most products are smaller than half
+// an ulp of the running sum and are ABSORBED, so the diagonal <G_k, G_k> - all terms positive - comes out 3-7e-6 too small, the off-diagonal
+// entries, whose small products have either sign, only ~1e-6 off.  That bias, not the size of the error, is what moves the config-2
+// ensembles: a flat fp32 chain over 64-element partials (round 5's first form of this kernel: as large an error, no bias)
+// sits with the exactly accumulated Gram (profiles/r05_config2_reference_arithmetic_chain64.json).  So the order itself is reproduced: one
+// lane per (entry, chain), 2^15 dependent FMAs at N = 2^19 - that dependency chain IS the arithmetic; nothing shortens it without changing
+// what it rounds - with the operands staged through LDS two tiles ahead so that the chain waits for nothing else.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int C16 = 16;                                     // chains per entry
+constexpr int C16_TILE = 1024;                              // elements of a row per LDS tile: 64 steps of every chain
+constexpr int C16_PITCH = C16_TILE + 16;                    // (the four entries of a wavefront read different rows: 16 banks apart)
+constexpr int C16_ROWS = 5;                                 // the new row + up to four others per workgroup
+constexpr int C16_RING = 7;                                 // tiles in LDS (7 x 5 x 4160 B = 142 KiB)
+constexpr int C16_AHEAD = 5;                                // a tile is asked for five chain-tiles (~2 us) before it is read: HBM latency
+constexpr int C16_LOADERS = 3;                              // wavefronts 1..3 only move data (LDS-DMA, 20 KiB per tile); wavefront 0 only adds
+constexpr int C16_TB = WAVE * (1 + C16_LOADERS);
+
+__global__ __launch_bounds__(C16_TB) void gram_row_chain16_kernel(const float* __restrict__ G_hist, float* __restrict__ gram32, int64_t N, int m, int slot,
+                                                                  int n_filled, int vec) {
+    const int64_t s = blockIdx.y;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+    const int lane = threadIdx.x % WAVE, c = lane & (C16 - 1), jj = lane >> 4;
+    const int j0 = 4 * blockIdx.x, j = j0 + jj;
+    const bool live = j < n_filled;
+    const float* Gs = G_hist + s * m * N;
+    const float* ga = Gs + (int64_t)slot * N;
+    float acc = 0.0f;
+    if (vec) {
+        __shared__ __attribute__((aligned(16))) float ring[C16_RING][C16_ROWS][C16_PITCH];
+        const int tiles = (int)((N + C16_TILE - 1) / C16_TILE);
+        // one buffer descriptor per staged row: reads past the row's N floats return 0, and fma(0, 0, x) = x
+        i32x4 rsrc[C16_ROWS];
+#pragma unroll
+        for (int r = 0; r < C16_ROWS; ++r) {
+            const int jr = (r == 0) ? slot : ((j0 + r - 1 < n_filled) ? j0 + r - 1 : slot);
+            const uint64_t base = (uint64_t)(Gs + (int64_t)jr * N);
+            rsrc[r].x = (int)__builtin_amdgcn_readfirstlane((uint32_t)base);
+            rsrc[r].y = (int)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+            rsrc[r].z = (int)__builtin_amdgcn_readfirstlane((uint32_t)(N * 4));
+            rsrc[r].w = 0x00020000;
+        }
+        const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)&ring[0][0][0];
+        auto ask = [&](int t) __attribute__((always_inline)) {   // tile t -> ring slot t % C16_RING: 20 asynchronous 1 KiB copies, no registers
+            const uint32_t slot_lds = ring_lds + (uint32_t)((t % C16_RING) * C16_ROWS * C16_PITCH * 4);
+            const uint32_t voff = (uint32_t)lane * 16u;
+#pragma unroll
+            for (int r = 0; r < C16_ROWS; ++r)
+#pragma unroll
+                for (int h = 0; h < C16_TILE / 256; ++h) {
+                    const uint32_t m0v = __builtin_amdgcn_readfirstlane(slot_lds + (uint32_t)((r * C16_PITCH + 256 * h) * 4));
+                    const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)t * (uint32_t)(C16_TILE * 4) + (uint32_t)(h * 1024));
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc[r]), "s"(soff) : "m0", "memory");
+                }
+        };
+        if (wave > 0)
+            for (int t = wave - 1; t < C16_AHEAD && t < tiles; t += C16_LOADERS) ask(t);
+        for (int t = 0; t < tiles; ++t) {
+            if (wave > 0) {
+                if (t % C16_LOADERS == wave - 1) {              // my tile: landed?  (behind it I have asked for tile t + 3 at most)
+                    if (t + C16_LOADERS < tiles) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if ((t + C16_AHEAD) % C16_LOADERS == wave - 1 && t + C16_AHEAD < tiles) ask(t + C16_AHEAD);   // (into the slot of tile t - 2: read and done)
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const float* a = &ring[t % C16_RING][0][c];
+                const float* b = &ring[t % C16_RING][1 + jj][c];
+                // 64 dependent FMAs; their 128 operands come 12 steps ahead (an LDS read takes ~64 cycles, a dependent FMA ~5)
+                float av[C16_TILE / C16], bv[C16_TILE / C16];
+#pragma unroll
+                for (int i = 0; i < C16_TILE / C16; ++i) { av[i] = a[C16 * i]; bv[i] = b[C16 * i]; }
+#pragma unroll
+                for (int i = 0; i < C16_TILE / C16; ++i) acc = fmaf(av[i], bv[i], acc);
+                __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+                for (int i = 0; i < C16_TILE / C16 - 14; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+        }
+        if (wave > 0) return;
+    } else {
+        if (wave > 0) return;
+        const float* gb = Gs + (int64_t)(live ? j : slot) * N;
+        for (int64_t k = c; k < N; k += C16) acc = fmaf(ga[k], gb[k], acc);
+    }
+    acc += __shfl_xor(acc, 8, WAVE);                            // 16 -> 8 -> 4 -> 2 -> 1, halves onto halves
+    acc += __shfl_xor(acc, 4, WAVE);
+    acc += __shfl_xor(acc, 2, WAVE);
+    acc += __shfl_xor(acc, 1, WAVE);
+    if (live && c == 0) {
+        float* g = gram32 + s * (MAXM * MAXM);
+        g[slot * MAXM + j] = acc;
+        g[j * MAXM + slot] = acc;
+    }
+}
+
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
                                                               int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32,
-                                                              const float* __restrict__ gram32, float* fine
+                                                              const float* __restrict__ gram32, int gram32_pitch
 #ifdef DEQSCI_DIAG
                                                               , float gram_noise
 #endif
@@ -261,48 +349,14 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
         gs[MAXM * MAXM + 1] = gg;                               // |G_k|^2
         res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
     }
-    if (fine) {
-        // ---- anderson_arith = "reference" without a GEMM library: the reference forms G G^T with ONE fp32 torch.bmm over the N = H W B elements
-        // (solvers/new_equilibrium_utils_yaping.py:177-178) - an fp32 accumulation along K whose rounding error (~1e-6 of an entry at N = 2^19,
-        // up to 4e-6: measured on torch 2.10 / MKL, tools/gram_f32_error.py) steers the chaotic FFDNet runs ("Config 2").
-        // The same KIND of sum here: the new row's entries <G_slot, G_j> from K4's fine partials (64 elements each), added ONE AFTER THE OTHER
-        // in fp32 along K - a flat chain of N / 64 additions per entry (1.2e-6 mean, 3e-6 worst against float64 on the same data), one lane
-        // per entry; the other rows persist from the iterations that wrote them, as a deterministic GEMM would recompute them bit for bit.
-        __shared__ float row32[MAXM];
-        const int64_t rows = (int64_t)nchunks * (TB / 8);
-        float* g32 = fine + (int64_t)s * (FINE_HDR + MAXM * rows);
-        if (lane < n_filled) {
-            const float* col = g32 + FINE_HDR + (int64_t)lane * rows;
-            float acc = 0.0f;
-            int64_t r = 0;
-            for (; r + 16 <= rows; r += 16) {
-                const float4 a0 = ld4(col + r), a1 = ld4(col + r + 4), a2 = ld4(col + r + 8), a3 = ld4(col + r + 12);
-                acc += a0.x; acc += a0.y; acc += a0.z; acc += a0.w;
-                acc += a1.x; acc += a1.y; acc += a1.z; acc += a1.w;
-                acc += a2.x; acc += a2.y; acc += a2.z; acc += a2.w;
-                acc += a3.x; acc += a3.y; acc += a3.z; acc += a3.w;
-            }
-            for (; r < rows; ++r) acc += col[r];
-            row32[lane] = acc;
-            g32[slot * MAXM + lane] = acc;
-            g32[lane * MAXM + slot] = acc;
-        }
-        __syncthreads();
-        if (n > 0) {
-            for (int i = lane; i < n * n; i += WAVE) {
-                const int a = i / n, b = i % n;
-                Gl[a * MAXM + b] = (double)((a == slot) ? row32[b] : (b == slot) ? row32[a] : g32[a * MAXM + b]);
-            }
-            __syncthreads();
-            bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
-        }
-    } else if (n > 0) {
+    if (n > 0) {
         if (gram32) {
             // the REFERENCE's arithmetic for alpha (new_equilibrium_utils_yaping.py:177-180): the n x n Gram block as the caller's fp32
             // torch.bmm produced it (rows in slot order), the system formed and factorised in fp32 like torch.solve = sgesv.  The residual
             // above and the persistent float64 Gram keep their own, exact, sums.
             __syncthreads();
-            for (int i = lane; i < n * n; i += WAVE) Gl[(i / n) * MAXM + (i % n)] = (double)gram32[(int64_t)s * n * n + i];
+            const int pitch = gram32_pitch ? gram32_pitch : n;                                  // (MAXM: the persistent Gram of gram_row_chain16_kernel)
+            for (int i = lane; i < n * n; i += WAVE) Gl[(i / n) * MAXM + (i % n)] = (double)gram32[(int64_t)s * pitch * pitch + (i / n) * pitch + (i % n)];
             __syncthreads();
             bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
         } else if (solve_f32) bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
@@ -484,23 +538,9 @@ size_t deqsci_partials_bytes(int64_t bsz, int64_t N) {
 
 size_t deqsci_gram_bytes(int64_t bsz) { return (size_t)(bsz * GRAM_STRIDE + 2) * sizeof(double); }   // + arrival ticket
 
-size_t deqsci_gram_fine_bytes(int64_t bsz, int64_t N) {
-    return (size_t)bsz * (size_t)(FINE_HDR + MAXM * deqsci_anderson_chunks(bsz, N) * (TB / 8)) * sizeof(float);
-}
-
-int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
-                                   float* x_next, float* partials, float* fine, int64_t bsz, int64_t N, int m, int slot, int n_filled,
-                                   deqsci_stream_t stream);
-
 int deqsci_residual_store_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
                               float* x_next, float* partials, int64_t bsz, int64_t N, int m, int slot, int n_filled,
                               deqsci_stream_t stream) {
-    return deqsci_residual_store_fine_f32(z1, noise, x_cur, F_hist, G_hist, x_next, partials, nullptr, bsz, N, m, slot, n_filled, stream);
-}
-
-int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist,
-                                   float* x_next, float* partials, float* fine, int64_t bsz, int64_t N, int m, int slot, int n_filled,
-                                   deqsci_stream_t stream) {
     if (!z1 || !x_cur || !F_hist || !G_hist || !partials) return DEQSCI_ERR_NULL;
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || slot >= n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
@@ -512,7 +552,7 @@ int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const fl
     const dim3 grid(ceil_div(N, chunk), bsz);
     const int vec = (N % 4 == 0) ? 1 : 0;
     const int pol = pick_policy(bsz * N * 4 * (n_filled + 4), POL_NTLS);
-#define RS_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec, fine)); break;
+#define RS_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, N, m, slot, chunk, vec)); break;
     switch (n_filled) {
         RS_CASE(1) RS_CASE(2) RS_CASE(3) RS_CASE(4) RS_CASE(5) RS_CASE(6) RS_CASE(7) RS_CASE(8)
         default: return DEQSCI_ERR_UNSUPPORTED;
@@ -524,42 +564,47 @@ int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const fl
 int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
                                    int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream);
 
+static int solve_launch(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int slot, int n_filled, int n, float lam,
+                        float eps, const float* gram32, int pitch, hipStream_t st) {
+    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+#ifdef DEQSCI_DIAG
+    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, pitch, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+#else
+    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32, pitch);
+#endif
+    return launch_status();
+}
+
 int deqsci_anderson_solve_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
                               int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
     return deqsci_anderson_solve_gram_f32(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, nullptr, stream);
 }
 
-static int solve_impl(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
-                      int slot, int n_filled, int n, float lam, float eps, const float* gram32, float* fine, deqsci_stream_t stream);
-
 int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
                                    int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream) {
-    return solve_impl(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, gram32, nullptr, stream);
-}
-
-int deqsci_anderson_solve_ref_f32(const float* partials, float* fine, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
-                                  int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
-    if (!fine) return DEQSCI_ERR_NULL;
-    if (!aligned16(fine)) return DEQSCI_ERR_ALIGN;
-    return solve_impl(partials, gram, alpha, res, bsz, N, m, slot, n_filled, n, lam, eps, nullptr, fine, stream);
-}
-
-static int solve_impl(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int m,
-                      int slot, int n_filled, int n, float lam, float eps, const float* gram32, float* fine, deqsci_stream_t stream) {
     if (!partials || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
     if (gram32 && n <= 0) return DEQSCI_ERR_SHAPE;
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
-#ifdef DEQSCI_DIAG
-    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, fine, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
-#else
-    hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32, fine);
-#endif
-    return launch_status();
+    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, gram32, 0, st);
+}
+
+size_t deqsci_gram_ref_bytes(int64_t bsz) { return (size_t)(bsz > 0 ? bsz : 0) * MAXM * MAXM * sizeof(float); }
+
+int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* gram32, void* gram, float* alpha, float* res, int64_t bsz,
+                                  int64_t N, int m, int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    if (!G_hist || !partials || !gram32 || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(G_hist)) return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gram_row_chain16_kernel, dim3((unsigned)ceil_div(n_filled, 4), (unsigned)bsz), dim3(C16_TB), 0, st, G_hist, gram32, N, m, slot, n_filled,
+                       (N % 4 == 0) ? 1 : 0);
+    if (int rc = launch_status()) return rc;
+    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, gram32, MAXM, st);
 }
 
 int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha, float* x_out, float beta, int n,

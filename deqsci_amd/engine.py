@@ -500,9 +500,9 @@ class DEQSCIEngine:
         out = _hip.f32c(out)
         ref = self.anderson_arith == "reference"               # the reference's fp32 Gram formed by K4 + K5 themselves (no GEMM library)
         if is_noise:
-            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next, fine=ref)
+            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
         else:
-            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next, fine=ref)
+            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
         gram32 = None
         if self.anderson_arith == "reference-bmm" and n_solve > 0:
             G = ws.G[:, :n_solve]                                                               # rows in the reference's slot order k % m

@@ -110,8 +110,13 @@ class EquilibriumProxGradSCI(nn.Module):
         return _hip.residual_out(z1, _hip.f32c(noise.reshape(bsz, c, w, h)), LAYOUT_HWB)
 
 
-def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
-    """Anderson acceleration for fixed point iteration (generic f)."""
+def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, *, anderson_arith="reference"):
+    """Anderson acceleration for fixed point iteration (generic f).
+    anderson_arith (this build's keyword): "reference" - G G^T accumulated in fp32 along N and an fp32 LU, the arithmetic of the reference's
+    torch.bmm + torch.solve (solvers/new_equilibrium_utils_yaping.py:177-180); "float64" - the exactly accumulated Gram."""
+    if anderson_arith not in ("reference", "float64"):
+        raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'reference' or 'float64'")
+    ref = anderson_arith == "reference"
     bsz = x0.shape[0]
     shape = x0.shape
     xa = _hip.f32c(x0).reshape(bsz, -1)
@@ -122,9 +127,9 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
     xb = torch.empty_like(xa)
     flat = lambda t: _hip.f32c(t).reshape(bsz, N)
     _hip.residual_store(ws, flat(f(xa.view(shape))), None, xa, 0, 1, xb)       # X1 = F0
-    _hip.anderson_solve(ws, 0, 1, 0, lam, 1e-5)
+    _hip.anderson_solve(ws, 0, 1, 0, lam, 1e-5, ref=ref)
     _hip.residual_store(ws, flat(f(xb.view(shape))), None, xb, 1, 2, None)
-    _hip.anderson_solve(ws, 1, 2, 2, lam, 1e-5)
+    _hip.anderson_solve(ws, 1, 2, 2, lam, 1e-5, ref=ref)
     bufs = [xa.clone(), xb]
     cur = bufs[0]                                                              # X[:, 0] = x0 if the loop is skipped
     res = None
@@ -134,7 +139,7 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0):
         _hip.anderson_mix(ws, cur, beta, n)
         nf = min(k + 1, m)
         _hip.residual_store(ws, flat(f(cur.view(shape))), None, cur, k % m, nf, None)
-        _hip.anderson_solve(ws, k % m, nf, nf, lam, 1e-5)
+        _hip.anderson_solve(ws, k % m, nf, nf, lam, 1e-5, ref=ref)
         res = ws.res[0, 0].item()
         if res < tol:
             break
@@ -180,8 +185,9 @@ class DEQFixedPoint(nn.Module):
             return None
         kw = dict(self.kwargs)
         if self.solver is andersonexp:
+            # (the reference's API gets the reference's arithmetic for alpha - an fp32 Gram - unless told otherwise: DESIGN section 5, "Config 2")
             cfg = dict(iterator="anderson", m=kw.pop("m", 5), lam=kw.pop("lam", 1e-4), max_iter=kw.pop("max_iter", 50),
-                       tol=kw.pop("tol", 1e-5), beta=kw.pop("beta", 1.0))
+                       tol=kw.pop("tol", 1e-5), beta=kw.pop("beta", 1.0), anderson_arith=kw.pop("anderson_arith", "reference"))
         elif self.solver is forward_iteration:
             cfg = dict(iterator="picard", max_iter=kw.pop("max_iter", 50), tol=kw.pop("tol", 1e-5))
         else:
@@ -190,7 +196,7 @@ class DEQFixedPoint(nn.Module):
             raise TypeError(f"{self.solver.__name__}() got an unexpected keyword argument '{next(iter(kw))}'")
         key = (id(f.nonlinear_op), f.nonlinear_op.training, tuple(sorted(cfg.items())), tuple(sorted(self.engine_options.items())))
         if self._engine is None or self._engine[0] != key:
-            self._engine = (key, DEQSCIEngine(f.nonlinear_op, **cfg, **self.engine_options))
+            self._engine = (key, DEQSCIEngine(f.nonlinear_op, **{**cfg, **self.engine_options}))
         return self._engine[1]
 
     def forward(self, x, Phi, Phi_sum, initial_point=None, train_flag=True):

@@ -119,19 +119,17 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
                                    int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                                    float lam, float eps, const float* gram32, deqsci_stream_t stream);
 
-/* The same WITHOUT a GEMM library (anderson_arith = "reference" of the engine): the kernels form the reference's fp32 Gram themselves.
- *     deqsci_residual_store_fine_f32 = K4 that additionally writes the FINE partials of the new Gram row - <G_slot, G_j> over each
- *     group of eight lanes' ~64 elements - into `fine` (deqsci_gram_fine_bytes(bsz, N) bytes, caller-owned, ZEROED once: it also holds the
- *     persistent fp32 Gram matrix); deqsci_anderson_solve_ref_f32 adds them up ONE AFTER THE OTHER in fp32 along K - a flat chain of
- *     N / 64 additions per entry, the kind of sum one fp32 torch.bmm over N elements is (:177-178; rounding ~1e-6 of an entry at N = 2^19,
- *     tools/gram_f32_error.py) -, refreshes row / column `slot` of the fp32 Gram, forms the bordered system in fp32 and factorises it in
- *     fp32 (:180, sgesv).  Residuals and the float64 Gram of `gram` are kept exactly as by the entry points above. */
-size_t deqsci_gram_fine_bytes(int64_t bsz, int64_t N);
-int deqsci_residual_store_fine_f32(const float* z1, const float* noise, const float* x_cur,
-                                   float* F_hist, float* G_hist, float* x_next, float* partials, float* fine,
-                                   int64_t bsz, int64_t N, int m, int slot, int n_filled,
-                                   deqsci_stream_t stream);
-int deqsci_anderson_solve_ref_f32(const float* partials, float* fine, void* gram, float* alpha, float* res,
+/* The same WITHOUT a GEMM library (anderson_arith = "reference" of the engine and of the drop-in DEQFixedPoint): the new row of G G^T in the
+ *     summation order of the fp32 torch.bmm behind tests/golden (MKL sgemm for 5 x N times N x 5: sixteen interleaved fused-multiply-add
+ *     chains per entry, chain c over k = c, c + 16, ..., summed pairwise at the end; within one ulp of torch.bmm, tools/gram_on_real_history.py).
+ *     On the loop's heavy-tailed residuals that order ABSORBS the small products of a 2^15-step chain: the diagonal comes out 3-7e-6 too small -
+ *     a bias, and the thing that moves the reference's chaotic FFDNet ensembles (an unbiased fp32 sum of the same error size
+ *     does not).  G_hist = the history K4 wrote (bsz, m, N); gram32 = deqsci_gram_ref_bytes(bsz) bytes, caller-owned, persistent between calls
+ *     (row / column `slot` of the MAX_M x MAX_M fp32 Gram of each sample is refreshed per call; the other rows are what a deterministic GEMM
+ *     would recompute bit for bit).  The bordered system is then formed and factorised in fp32 (:180, sgesv); residuals and the float64 Gram
+ *     of `gram` are kept exactly as by the entry points above.  Cost: N / 16 dependent FMAs (~70 us at N = 2^19, any batch size). */
+size_t deqsci_gram_ref_bytes(int64_t bsz);
+int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* gram32, void* gram, float* alpha, float* res,
                                   int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                                   float lam, float eps, deqsci_stream_t stream);
 

@@ -148,9 +148,12 @@ def test_anderson_generic_vs_reference_golden(bsz):
     g = np.load(os.path.join(GOLDEN, "anderson_toy.npz"))
     a, c, x0 = G(g[f"b{bsz}_a"]), G(g[f"b{bsz}_c"]), G(g[f"b{bsz}_x0"])
     for it in (3, 7, 12, 40):
-        z, res = deqsci_amd.andersonexp(_toy(a, c), x0, m=5, lam=1e-2, max_iter=it, tol=1e-5, beta=1.0)
-        assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_it{it}_z"]) < 2e-5, it
-        assert abs(res - float(g[f"b{bsz}_it{it}_res"])) <= 2e-3 * float(g[f"b{bsz}_it{it}_res"]) + 1e-7
+        for aa in ("reference", "float64"):                  # (the default: the reference's fp32 Gram + fp32 LU; the exactly accumulated Gram)
+            z, res = deqsci_amd.andersonexp(_toy(a, c), x0, m=5, lam=1e-2, max_iter=it, tol=1e-5, beta=1.0, anderson_arith=aa)
+            assert rel_l2(z.cpu().numpy(), g[f"b{bsz}_it{it}_z"]) < 2e-5, (it, aa)
+            assert abs(res - float(g[f"b{bsz}_it{it}_res"])) <= 2e-3 * float(g[f"b{bsz}_it{it}_res"]) + 1e-7
+    with pytest.raises(ValueError):
+        deqsci_amd.andersonexp(_toy(a, c), x0, anderson_arith="fp16")
     n = [0]
 
     def f2(z):
