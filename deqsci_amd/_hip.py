@@ -33,6 +33,7 @@ SIGNATURES = {
     "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_solve_gram_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr, _ptr],
     "deqsci_anderson_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_gram_row_chain16_f32": [_ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _ptr],
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
                                     _i64, _i64, _i64, _i64, _int, _int, _ptr],
@@ -100,7 +101,7 @@ def load():
     lib.deqsci_gram_bytes.restype = ctypes.c_size_t
     lib.deqsci_gram_bytes.argtypes = [_i64]
     lib.deqsci_gram_ref_bytes.restype = ctypes.c_size_t
-    lib.deqsci_gram_ref_bytes.argtypes = [_i64]
+    lib.deqsci_gram_ref_bytes.argtypes = [_i64, _i64]
     _lib = lib
     return lib
 
@@ -267,12 +268,27 @@ class AndersonWorkspace:
         self.res = torch.zeros((res_rows, 1 + bsz), device=device, dtype=torch.float32)
         self.gram32 = None                # (anderson_arith = "reference": the persistent fp32 Gram of deqsci_anderson_solve_ref_f32, see gram32_state)
 
-    def gram32_state(self):
-        """(bsz, MAX_M, MAX_M) fp32: the Gram matrix deqsci_anderson_solve_ref_f32 keeps between calls (allocated on first use)."""
+    def ref_state(self):
+        """The caller-owned state of deqsci_anderson_solve_ref_f32 (allocated and zeroed on first use): per sample the persistent fp32 Gram
+        (MAX_M x MAX_M), the 16 chain sums per entry of the last call, and the block records of the two-pass form."""
         if self.gram32 is None:
-            self.gram32 = torch.zeros(self.bsz, load().deqsci_gram_ref_bytes(self.bsz) // (4 * self.bsz), device=self.F.device, dtype=torch.float32)
-            self.gram32 = self.gram32.view(self.bsz, MAX_M, MAX_M)
+            self.gram32 = torch.zeros(load().deqsci_gram_ref_bytes(self.bsz, self.N) // 4, device=self.F.device, dtype=torch.float32)
         return self.gram32
+
+    def gram32_state(self):
+        """(bsz, MAX_M, MAX_M) view of the persistent fp32 Gram in ref_state()."""
+        st = self.ref_state().view(self.bsz, -1)
+        return st[:, :MAX_M * MAX_M].view(self.bsz, MAX_M, MAX_M)
+
+    def chain_sums(self):
+        """(bsz, MAX_M, 16) view of the chain sums of the last deqsci_gram_row_chain16_f32 / deqsci_anderson_solve_ref_f32 call."""
+        st = self.ref_state().view(self.bsz, -1)
+        return st[:, MAX_M * MAX_M:MAX_M * MAX_M + 16 * MAX_M].view(self.bsz, MAX_M, 16)
+
+    def chains_walked(self):
+        """(bsz, MAX_M, 16) int32 view (diagnostic): the blocks each chain was walked through term by term in the last two-pass call (-1: serial form)."""
+        st = self.ref_state().view(self.bsz, -1)
+        return st[:, MAX_M * MAX_M + 16 * MAX_M:MAX_M * MAX_M + 32 * MAX_M].view(torch.int32).view(self.bsz, MAX_M, 16)
 
 
 def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
@@ -288,7 +304,7 @@ def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None, ref=
     (sixteen interleaved FMA chains per entry, csrc/anderson.hip gram_row_chain16_kernel) from the history residual_store just wrote."""
     if ref:
         with _dev(ws.F):
-            _check(load().deqsci_anderson_solve_ref_f32(_p(ws.G), _p(ws.partials), _p(ws.gram32_state()), ws.gram.data_ptr(), _p(ws.alpha),
+            _check(load().deqsci_anderson_solve_ref_f32(_p(ws.G), _p(ws.partials), _p(ws.ref_state()), ws.gram.data_ptr(), _p(ws.alpha),
                                                         _p(ws.res[res_row]), ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()),
                    "anderson_solve_ref")
         return
@@ -298,6 +314,15 @@ def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None, ref=
         _check(load().deqsci_anderson_solve_gram_f32(_p(ws.partials), ws.gram.data_ptr(), _p(ws.alpha), _p(ws.res[res_row]),
                                                      ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps),
                                                      None if gram32 is None else gram32.data_ptr(), _stream()), "anderson_solve")
+
+
+def gram_row_chain16(ws, slot, n_filled, serial=False):
+    """The 16 chain sums of every entry of the new Gram row (ws.chain_sums()) from the history and block sums residual_store just wrote:
+    serial=True as the chains are written, False in the two-pass form (the same bits; tests hold them equal)."""
+    with _dev(ws.F):
+        _check(load().deqsci_gram_row_chain16_f32(_p(ws.G), _p(ws.partials), _p(ws.ref_state()), ws.bsz, ws.N, ws.m, slot, n_filled, int(bool(serial)),
+                                                  _stream()), "gram_row_chain16")
+    return ws.chain_sums()
 
 
 def anderson_mix(ws, x_out, beta, n):

@@ -210,9 +210,25 @@ constexpr int C16_RING = 7;                                 // tiles in LDS (7 x
 constexpr int C16_AHEAD = 5;                                // a tile is asked for five chain-tiles (~2 us) before it is read: HBM latency
 constexpr int C16_LOADERS = 3;                              // wavefronts 1..3 only move data (LDS-DMA, 20 KiB per tile); wavefront 0 only adds
 constexpr int C16_TB = WAVE * (1 + C16_LOADERS);
+// the caller's state of this arithmetic, per sample, in 4-byte words: the persistent fp32 Gram, the chain sums of this call, and the records of the
+// two-pass form (gram_round_kernel -> gram_chain_apply_kernel): per K4 block the binade the block was rounded for, and per (block, entry, chain,
+// candidate binade) the pair {sum of the rounded terms, sum of their magnitudes} in units of that binade's ulp
+constexpr int REF_CSUM = MAXM * MAXM;
+constexpr int REF_WALKED = REF_CSUM + MAXM * C16;            // (diagnostic) blocks each chain was walked through in the last call
+constexpr int REF_TAKEN = REF_WALKED + MAXM * C16;           // per entry: term slots handed out in this call (zeroed again by gram_chain_apply_kernel)
+constexpr int REF_EP = REF_TAKEN + MAXM;
+constexpr int REF_NONE = -100000;                           // no prediction for this block (first block, zero or non-finite sums)
+__host__ __device__ constexpr int ref_lo(int code) { return (code >> 1) - 1 + (code & 1); }     // the lower of the two candidate binades
+constexpr int REF_CAND = 2;                                 // binades a block is rounded for: the predicted one and its nearer neighbour
+constexpr int PF_TERMS = 128;                               // terms per chain of a block of 2048 elements (the chunk K4 uses up to N = 2^25 / bsz)
+constexpr int TSLOTS = 96;                                  // blocks per entry whose terms gram_round_kernel also stores chain by chain (see there)
+__host__ __device__ constexpr int64_t ref_rec(int64_t nchunks) { return REF_EP + nchunks * MAXM; }
+__host__ __device__ constexpr int64_t ref_slot(int64_t nchunks) { return ref_rec(nchunks) + nchunks * MAXM * C16 * REF_CAND * 2; }
+__host__ __device__ constexpr int64_t ref_terms(int64_t nchunks) { return (ref_slot(nchunks) + nchunks * MAXM + 3) / 4 * 4; }
+__host__ __device__ constexpr int64_t ref_words(int64_t nchunks) { return ref_terms(nchunks) + (int64_t)MAXM * TSLOTS * C16 * PF_TERMS * 2; }
 
-__global__ __launch_bounds__(C16_TB) void gram_row_chain16_kernel(const float* __restrict__ G_hist, float* __restrict__ gram32, int64_t N, int m, int slot,
-                                                                  int n_filled, int vec) {
+__global__ __launch_bounds__(C16_TB) void gram_row_chain16_kernel(const float* __restrict__ G_hist, float* __restrict__ ref_state, int64_t ref_stride,
+                                                                  int64_t N, int m, int slot, int n_filled, int vec) {
     const int64_t s = blockIdx.y;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
     const int lane = threadIdx.x % WAVE, c = lane & (C16 - 1), jj = lane >> 4;
@@ -282,21 +298,444 @@ __global__ __launch_bounds__(C16_TB) void gram_row_chain16_kernel(const float* _
         const float* gb = Gs + (int64_t)(live ? j : slot) * N;
         for (int64_t k = c; k < N; k += C16) acc = fmaf(ga[k], gb[k], acc);
     }
-    acc += __shfl_xor(acc, 8, WAVE);                            // 16 -> 8 -> 4 -> 2 -> 1, halves onto halves
-    acc += __shfl_xor(acc, 4, WAVE);
-    acc += __shfl_xor(acc, 2, WAVE);
-    acc += __shfl_xor(acc, 1, WAVE);
-    if (live && c == 0) {
-        float* g = gram32 + s * (MAXM * MAXM);
-        g[slot * MAXM + j] = acc;
-        g[j * MAXM + slot] = acc;
+    if (live) {
+        ref_state[s * ref_stride + REF_CSUM + j * C16 + c] = acc;       // (folded by anderson_solve_kernel)
+        reinterpret_cast<int*>(ref_state + s * ref_stride)[REF_WALKED + j * C16 + c] = -1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same sums, bit for bit, WITHOUT the 2^15-step dependency chain
+// ------------------------------------------------------------------------------------------------
+// While the running sum S of a chain stays inside one binade [2^e, 2^(e+1)) it is a multiple of u = 2^(e-23), and then
+//     RN(S + p) = S + RN_u(p)                    (RN_u: to the nearest multiple of u; no tie)
+// - the rounded step does not depend on S.  Inside a binade the chain is an INTEGER sum (in units of u) of individually rounded products, exact
+// in any order, so every K4 block can round and add its 128 terms per chain on its own (gram_round_kernel, the whole machine, one pass over the
+// history) - for the binade the chain is predicted to be in there (from K4's block partials: prefix / 16) and its two neighbours -, and only
+// the bookkeeping stays serial (gram_chain_apply_kernel, one wavefront per chain): take the blocks 64 at a time, accept the run of blocks whose
+// record is for the binade S is in and that cannot leave it (|S| -+ the block's sum of magnitudes stays inside, two ulps to spare), and walk
+// through a block that fails - a crossing into the next binade, a term on a rounding tie (then S's parity decides), a term too large for the
+// trick, the first blocks where S is still small - term by term with the FMA itself.  tools/gram_chain_prototype.py: ~16 of 256 blocks per
+// chain are walked on the loop's own residuals; tests/test_gpu_parity.py holds the two forms bit-equal on those and on random data.
+constexpr int RND_TILE = 1024;                              // elements per staged tile: 64 terms of every chain
+constexpr int RND_PITCH = RND_TILE + RND_TILE / C16;        // (skewed by one word per 16: a chain's terms fall in different banks)
+
+template <int NF>
+__global__ __launch_bounds__(TB) void gram_round_kernel(const float* __restrict__ G_hist, const float* __restrict__ partials, float* __restrict__ ref_state,
+                                                        int64_t ref_stride, int64_t N, int m, int slot, int64_t chunk) {
+    const int64_t s = blockIdx.y;
+    const int b = blockIdx.x, nchunks = gridDim.x;
+    const int t = threadIdx.x, wave = t / WAVE, lane = t % WAVE;
+    const int64_t beg = (int64_t)b * chunk;
+    const float* Gs = G_hist + s * m * N;
+    __shared__ float red[TB / WAVE][MAXM];
+    __shared__ int ep_s[MAXM], slot_s[MAXM];
+    __shared__ __attribute__((aligned(16))) float tile[NF][RND_PITCH];
+    // ---- where each chain of each entry is when it gets here: (K4's sums of the blocks before this one) / 16
+    const float* ps = partials + s * nchunks * PART_STRIDE;
+    {
+        float x[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) x[j] = 0.0f;
+        for (int bb = t; bb < b; bb += TB)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) x[j] += ps[(int64_t)bb * PART_STRIDE + j];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float v = wave_sum(x[j]);
+            if (lane == 0) red[wave][j] = v;
+        }
+        __syncthreads();
+        if (t < NF) {
+            float v = 0.0f;
+            for (int w = 0; w < TB / WAVE; ++w) v += red[w][t];
+            v = fabsf(v) * (1.0f / C16);
+            int code = REF_NONE;                                // 2 x (predicted binade) + (upper half of it, on the log scale: the neighbour above is the second candidate)
+            if (v > 0.0f && v < 3.0e38f) {
+                const int e = ilogbf(v);
+                if (e >= -90 && e <= 90) code = 2 * e + (ldexpf(v, -e) >= 1.41421356f ? 1 : 0);
+            }
+            ep_s[t] = code;
+            int* sti = reinterpret_cast<int*>(ref_state + s * ref_stride);
+            sti[REF_EP + (int64_t)b * MAXM + t] = code;
+            // a block that gram_chain_apply_kernel is likely to WALK - the first ones, where the block is a large part of the sum so far, where
+            // the chains (each within ~10 % of their mean) change binade - also leaves its terms chain by chain: a chain's 128 terms of a block
+            // are 64 bytes apart in the history (8 KB of cache lines per row), 1 KB in a row there
+            int sl = -1;
+            if (chunk <= (int64_t)PF_TERMS * C16) {
+                const float here = fabsf(ps[(int64_t)b * PART_STRIDE + t]) * (1.0f / C16);
+                const float lo = v < v + here ? v : v + here, hi = v + here;
+                bool mark = code == REF_NONE || b < 24 || !(here < 0.2f * v);
+                if (!mark) mark = ilogbf(0.88f * lo) != ilogbf(1.12f * hi);
+                if (mark) {
+                    sl = atomicAdd(&sti[REF_TAKEN + t], 1);
+                    if (sl >= TSLOTS) sl = -1;
+                }
+            }
+            slot_s[t] = sl;
+            sti[ref_slot(nchunks) + (int64_t)b * MAXM + t] = sl;
+        }
+        __syncthreads();
+    }
+    float cM[NF][REF_CAND], cH[NF][REF_CAND];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) {
+            const int e = ep_s[j] == REF_NONE ? 0 : ref_lo(ep_s[j]) + q;
+            cM[j][q] = ldexpf(1.5f, e);                         // S + p rounds on the grid of [2^e, 2^(e+1)) <=> 1.5 2^e + p does (|p| < 2^(e-1))
+            cH[j][q] = ldexpf(1.0f, e - 24);                    // u / 2: the distance of a tie
+        }
+    // per (entry, candidate): the sum of the bit patterns of t = RN(1.5 2^e + a b) - inside the binade they are linear in t, so that
+    // bits(t) - bits(1.5 2^e) IS the rounded term in ulps -, the sum of the magnitudes, their OR (any term out of the binade shows up as >= 2^22)
+    unsigned Ns[NF][REF_CAND], As[NF][REF_CAND], Os[NF][REF_CAND];
+    bool tie[NF][REF_CAND];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) { Ns[j][q] = 0; As[j][q] = 0; Os[j][q] = 0; tie[j][q] = ep_s[j] == REF_NONE; }
+    const int c = t >> 4, g = t & 15;                          // my chain, and which of its terms: i = g, g + 16, ...
+    float* terms = ref_state + s * ref_stride + ref_terms(nchunks);
+    const int tiles = (int)(chunk / RND_TILE);
+    float4 pre[NF];
+    auto fetch = [&](int tl) {
+        const int64_t k = beg + (int64_t)tl * RND_TILE + 4 * t;
+        const bool in = k < N;                                  // (N % 4 == 0 on this path)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float4 v = ld4(Gs + (int64_t)j * N + (in ? k : 0));
+            pre[j] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+        }
+    };
+    fetch(0);
+    for (int tl = 0; tl < tiles; ++tl) {
+        const int w0 = 4 * t + (t >> 2);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { tile[j][w0] = pre[j].x; tile[j][w0 + 1] = pre[j].y; tile[j][w0 + 2] = pre[j].z; tile[j][w0 + 3] = pre[j].w; }
+        __syncthreads();
+        if (tl + 1 < tiles) fetch(tl + 1);
+#pragma unroll
+        for (int ii = 0; ii < RND_TILE / C16 / 16; ++ii) {
+            const int i = g + 16 * ii, w = 17 * i + c;
+            const float a = tile[slot][w];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float bb = tile[j][w];
+                if (slot_s[j] >= 0)                             // (uniform)
+                    *reinterpret_cast<float2*>(terms + ((((int64_t)j * TSLOTS + slot_s[j]) * C16 + c) * PF_TERMS + (tl * (RND_TILE / C16) + i)) * 2) = make_float2(a, bb);
+#pragma unroll
+                for (int q = 0; q < REF_CAND; ++q) {
+                    const float tt = fmaf(a, bb, cM[j][q]);
+                    const unsigned ti = __float_as_uint(tt), mi = __float_as_uint(cM[j][q]);
+                    const unsigned dl = ti > mi ? ti - mi : mi - ti;        // |RN_u(a b)| / u
+                    Ns[j][q] += ti - mi;
+                    As[j][q] += dl;
+                    Os[j][q] |= dl;
+                    const float d = fmaf(a, bb, -(tt - cM[j][q]));          // a b - RN_u(a b): +- u / 2 on a tie (then S's parity decides: walked)
+                    tie[j][q] |= fabsf(d) == cH[j][q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    int* rec = reinterpret_cast<int*>(ref_state + s * ref_stride) + ref_rec(nchunks);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) {
+            unsigned nn = Ns[j][q], aa = As[j][q], oo = Os[j][q] | (tie[j][q] ? 0x80000000u : 0u);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, WAVE); aa += __shfl_xor(aa, o, WAVE); oo |= __shfl_xor(oo, o, WAVE); }
+            if (g == 0) {
+                int* r2 = rec + ((((int64_t)b * MAXM + j) * C16 + c) * REF_CAND + q) * 2;
+                r2[0] = (int)nn;
+                r2[1] = (oo >> 22) ? -1 : (int)aa;              // (a term of 2^22 ulps or more, a tie: not for the fast path)
+            }
+        }
+}
+
+// inclusive prefix sum over the 64 lanes: shifts inside the rows of 16 (DPP), then the three row totals
+__device__ __forceinline__ int wave_scan_incl(int v, int lane) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);    // row_shr:8
+    const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+    const int row = lane >> 4;
+    return v + (row >= 1 ? t0 : 0) + (row >= 2 ? t1 : 0) + (row >= 3 ? t2 : 0);
+}
+
+constexpr int PF_BLOCKS = 32;                               // blocks whose terms are fetched before the chain starts
+constexpr int WIN = 256;                                    // blocks whose records are held in LDS at a time
+
+__global__ __launch_bounds__(WAVE) void gram_chain_apply_kernel(const float* __restrict__ G_hist, const float* __restrict__ partials, float* __restrict__ ref_state,
+                                                                int64_t ref_stride, int64_t N, int m, int slot, int64_t chunk, int nchunks) {
+    const int64_t s = blockIdx.y;
+    const int j = blockIdx.x / C16, c = blockIdx.x % C16, lane = threadIdx.x;
+    const float* ga = G_hist + (s * m + slot) * N;
+    const float* gb = G_hist + (s * m + j) * N;
+    float* st = ref_state + s * ref_stride;
+    const int* ep = reinterpret_cast<const int*>(st + REF_EP);
+    const int* rec = reinterpret_cast<const int*>(st) + ref_rec(nchunks);
+    const int* tslot = reinterpret_cast<const int*>(st) + ref_slot(nchunks);
+    const float* terms = st + ref_terms(nchunks);
+    const bool small = chunk <= (int64_t)PF_TERMS * C16;        // blocks of <= 128 terms per chain: the prefetches below apply
+    __shared__ __attribute__((aligned(16))) float wa[1024], wb[1024];                        // the terms of a block that is walked (chunk <= 16384: <= 1024 per chain)
+    __shared__ __attribute__((aligned(16))) float pfa[PF_BLOCKS][PF_TERMS], pfb[PF_BLOCKS][PF_TERMS];
+    __shared__ int pf_list[PF_BLOCKS];
+    __shared__ int code_s[WIN], tslot_s[WIN];
+    __shared__ int rec_s[WIN][REF_CAND][2];
+    int win0 = -1;                                              // first block of the record window in LDS
+    auto load_window = [&](int b0) {                            // (uniform)
+        __syncthreads();
+        for (int x = lane; x < WIN; x += WAVE) {
+            const int bl = b0 + x;
+            const bool in = bl < nchunks;
+            code_s[x] = in ? ep[(int64_t)bl * MAXM + j] : REF_NONE;
+            tslot_s[x] = in ? tslot[(int64_t)bl * MAXM + j] : -1;
+            const int4 r4 = in ? *reinterpret_cast<const int4*>(rec + (((int64_t)bl * MAXM + j) * C16 + c) * REF_CAND * 2) : make_int4(0, -1, 0, -1);
+            rec_s[x][0][0] = r4.x; rec_s[x][0][1] = r4.y; rec_s[x][1][0] = r4.z; rec_s[x][1][1] = r4.w;
+        }
+        win0 = b0;
+        __syncthreads();
+    };
+#ifdef DEQSCI_DIAG
+    long long stamp0 = __builtin_readcyclecounter(), c_group = 0, c_walk = 0;
+    long long stampA = 0, stampB = 0;
+    int n_group = 0, n_hit = 0, n_noslot = 0, n_miss = 0;
+#endif
+    load_window(0);
+#ifdef DEQSCI_DIAG
+    const long long stamp1 = __builtin_readcyclecounter();
+#endif
+    // ---- the blocks that will be walked can be told beforehand: THIS chain's way through the binades, to a few ulps, is the running sum of its
+    // own block records (K4's block sums / 16 where a record is flagged) - the blocks where that sum changes binade or comes within the block's
+    // magnitude of a boundary, the flagged ones, the first ones.  Their terms are asked for before the chain starts, all at once (a walk that has
+    // to fetch its own terms waits a round trip to memory, ~2 us).  (All of the loads in flight before the first is parked: one round trip in all.)
+    int n_pf = 0;
+    auto ask_terms = [&](int bl, float (&da)[PF_TERMS / WAVE], float (&db)[PF_TERMS / WAVE]) {
+        const int64_t beg = (int64_t)bl * chunk;
+#pragma unroll
+        for (int h = 0; h < PF_TERMS / WAVE; ++h) {
+            const int i = lane + WAVE * h;
+            const int64_t k = beg + c + (int64_t)C16 * i;
+            const bool in = k < N && (int64_t)C16 * i + c < chunk;
+            const float va = ga[in ? k : 0], vb = gb[in ? k : 0];
+            da[h] = in ? va : 0.0f;                             // (past the block: fma(0, 0, S) = S)
+            db[h] = in ? vb : 0.0f;
+        }
+    };
+    if (small && nchunks <= WIN) {
+        constexpr int PER = WIN / WAVE;                         // blocks per lane: 4 lane + r
+        const float* ps = partials + s * nchunks * PART_STRIDE;
+        float contrib[PER], mag[PER];
+        float mine = 0.0f;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int bl = PER * lane + r;
+            contrib[r] = 0.0f;
+            mag[r] = 0.0f;
+            if (bl < nchunks) {
+                const int code = code_s[bl];
+                const int q = code == REF_NONE ? 0 : (code >> 1) - ref_lo(code);
+                const int aa = rec_s[bl][q][1];
+                const float avg = ps[(int64_t)bl * PART_STRIDE + j] * (1.0f / C16);
+                if (code != REF_NONE && aa >= 0) {
+                    const float u = ldexpf(1.0f, (code >> 1) - 23);
+                    contrib[r] = (float)rec_s[bl][q][0] * u;
+                    mag[r] = (float)aa * u;
+                } else {
+                    contrib[r] = avg;
+                    mag[r] = 3.0e38f;                           // (flagged: walked whatever the sum does)
+                }
+            }
+            mine += contrib[r];
+        }
+        float run = mine;                                       // exclusive prefix of the lanes' sums (a prediction: float order does not matter)
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const float v = __shfl_up(run, o, WAVE);
+            if (lane >= o) run += v;
+        }
+        run -= mine;
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+            const int bl = PER * lane + r;
+            const float s0 = run, s1 = run + contrib[r];
+            run = s1;
+            bool mark = false;
+            if (bl < nchunks) {
+                const float lo = fminf(fabsf(s0), fabsf(s1)), hi = fmaxf(fabsf(s0), fabsf(s1));
+                const float m2 = mag[r] < 1.0e38f ? 1.5f * mag[r] + 1.0e-3f * hi : 3.0e38f;
+                mark = !(lo - m2 > 0.0f) || (s0 < 0.0f) != (s1 < 0.0f) || ilogbf(lo - m2) != ilogbf(hi + m2);
+                if (!mark) {                                    // is there a record for the binade the chain will be in?
+                    const int code = code_s[bl];
+                    const int q = ilogbf(lo) - ref_lo(code);
+                    mark = q < 0 || q >= REF_CAND || rec_s[bl][q][1] < 0;
+                }
+                mark = mark && tslot_s[bl] >= 0;                // (gram_round_kernel left its terms in a row; a block it did not is gathered if and when it is walked)
+            }
+            const unsigned long long mk = __ballot(mark);
+            const int pos = n_pf + __popcll(mk & ((1ull << lane) - 1ull));
+            if (mark && pos < PF_BLOCKS) pf_list[pos] = bl;
+            n_pf += __popcll(mk);
+        }
+        if (n_pf > PF_BLOCKS) n_pf = PF_BLOCKS;
+        __syncthreads();
+#ifdef DEQSCI_DIAG
+        stampA = __builtin_readcyclecounter();
+#endif
+        // (all of them in flight before the first is parked: one round trip in all.  A block with a slot in `terms` is 1 KB in a row -
+        //  two terms per lane; one without is gathered from the history, 64 bytes apart)
+        float4 tq[PF_BLOCKS];
+#pragma unroll
+        for (int x = 0; x < PF_BLOCKS; ++x) {
+            const int sl = x < n_pf ? tslot_s[pf_list[x]] : 0;
+            tq[x] = ld4(terms + ((((int64_t)j * TSLOTS + sl) * C16 + c) * PF_TERMS + 2 * lane) * 2);
+        }
+#pragma unroll
+        for (int x = 0; x < PF_BLOCKS; ++x) {
+            pfa[x][2 * lane] = tq[x].x; pfb[x][2 * lane] = tq[x].y; pfa[x][2 * lane + 1] = tq[x].z; pfb[x][2 * lane + 1] = tq[x].w;
+        }
+#ifdef DEQSCI_DIAG
+        stampB = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+    }
+#ifdef DEQSCI_DIAG
+    const long long stamp2 = __builtin_readcyclecounter();
+#endif
+    float S = 0.0f;
+    int b = 0, walked = 0;
+    while (b < nchunks) {
+        if (b >= win0 + WIN) load_window(b);
+#ifdef DEQSCI_DIAG
+        const long long g0 = __builtin_readcyclecounter();
+#endif
+        // ---- the next 64 blocks at once: which of them does S pass through without leaving its binade?
+        const int bl = b + lane;
+        const bool valid = bl < nchunks && bl < win0 + WIN;
+        const float aS = fabsf(S);
+        const int e = (aS > 0.0f && aS < 3.0e38f) ? ilogbf(aS) : -2000;
+        const int code = valid ? code_s[bl - win0] : REF_NONE;
+        const int q = code == REF_NONE ? -1 : e - ref_lo(code);
+        int nn = 0, aa = -1;
+        if (q >= 0 && q < REF_CAND) {
+            nn = rec_s[bl - win0][q][0];
+            aa = rec_s[bl - win0][q][1];
+        }
+        bool ok = aa >= 0 && aa < (1 << 22);
+        if (!ok) nn = 0;
+        const int pre = wave_scan_incl(nn, lane);               // inclusive prefix over the lanes (integers: exact)
+        const int si = (e > -200 && e < 100) ? (int)(S * ldexpf(1.0f, 23 - e)) : 0;      // S / u: +-[2^23, 2^24), exact
+        const int v0 = si + pre - nn;                           // where the chain stands when it reaches my block, if all before it were passed
+        const int av = v0 < 0 ? -v0 : v0;
+        ok = ok && ((v0 < 0) == (si < 0)) && av - aa >= (1 << 23) + 2 && av + aa <= (1 << 24) - 2;
+        const unsigned long long pass = __ballot(ok);
+        int f = pass == ~0ull ? WAVE : __builtin_ctzll(~pass);  // the first block that is not passed
+        if (b + f > win0 + WIN) f = win0 + WIN - b;             // (the window's end is not a failure: the next round reloads)
+        if (f > 0) {
+            const int tot = __builtin_amdgcn_readlane(pre, __builtin_amdgcn_readfirstlane(f - 1));
+            S = (float)(si + tot) * ldexpf(1.0f, e - 23);       // (|si + tot| < 2^24: exact)
+            b += f;
+        }
+#ifdef DEQSCI_DIAG
+        const long long g1 = __builtin_readcyclecounter();
+        c_group += g1 - g0;
+        n_group += 1;
+#endif
+        if (f < WAVE && b < nchunks && b < win0 + WIN) {
+            // ---- walk block b: its terms k = beg + c + 16 i, one FMA after the other
+            const int64_t beg = (int64_t)b * chunk;
+            const int64_t end = beg + chunk < N ? beg + chunk : N;
+            int T = (int)((end - beg - c + C16 - 1) / C16);
+            if (T < 0) T = 0;
+            const float *xa = wa, *xb = wb;
+            const unsigned long long hit = __ballot(lane < n_pf && pf_list[lane < PF_BLOCKS ? lane : 0] == b);
+            bool have = false;
+            if (hit) {
+                const int x = __builtin_ctzll(hit);
+                xa = pfa[x];
+                xb = pfb[x];
+                have = true;
+            }
+            if (!have) {
+                if (small && b - win0 < WIN && tslot_s[b - win0] >= 0) {
+                    const float4 v = ld4(terms + ((((int64_t)j * TSLOTS + tslot_s[b - win0]) * C16 + c) * PF_TERMS + 2 * lane) * 2);
+                    wa[2 * lane] = v.x; wb[2 * lane] = v.y; wa[2 * lane + 1] = v.z; wb[2 * lane + 1] = v.w;
+                } else if (small) {
+                    float da[PF_TERMS / WAVE], db[PF_TERMS / WAVE];
+                    ask_terms(b, da, db);
+#pragma unroll
+                    for (int h = 0; h < PF_TERMS / WAVE; ++h) { wa[lane + WAVE * h] = da[h]; wb[lane + WAVE * h] = db[h]; }
+                } else {
+                    for (int i = lane; i < T; i += WAVE) { wa[i] = ga[beg + c + (int64_t)C16 * i]; wb[i] = gb[beg + c + (int64_t)C16 * i]; }
+                }
+            }
+            __syncthreads();
+            if (small) {
+                // 128 dependent FMAs (terms past the block are zeros); the operands come 32 terms ahead of the chain
+                const float4* xa4 = reinterpret_cast<const float4*>(xa);
+                const float4* xb4 = reinterpret_cast<const float4*>(xb);
+                float4 A4[2][8], B4[2][8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { A4[0][k] = xa4[k]; B4[0][k] = xb4[k]; }
+#pragma unroll
+                for (int ch = 0; ch < PF_TERMS / 32; ++ch) {
+                    if (ch + 1 < PF_TERMS / 32) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { A4[(ch + 1) & 1][k] = xa4[8 * (ch + 1) + k]; B4[(ch + 1) & 1][k] = xb4[8 * (ch + 1) + k]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float4 va = A4[ch & 1][k], vb = B4[ch & 1][k];
+                        S = fmaf(va.x, vb.x, S); S = fmaf(va.y, vb.y, S); S = fmaf(va.z, vb.z, S); S = fmaf(va.w, vb.w, S);
+                    }
+                }
+            } else {
+                int i = 0;
+                for (; i + 16 <= T; i += 16) {
+                    float av2[16], bv2[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { av2[u] = xa[i + u]; bv2[u] = xb[i + u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) S = fmaf(av2[u], bv2[u], S);
+                }
+                for (; i < T; ++i) S = fmaf(xa[i], xb[i], S);
+            }
+            __syncthreads();
+            b += 1;
+            walked += 1;
+#ifdef DEQSCI_DIAG
+            c_walk += __builtin_readcyclecounter() - g1;
+            if (lane == 0 && j == 0 && c == 0 && walked <= 24) {
+                int* dg = reinterpret_cast<int*>(st) + REF_WALKED + 7 * C16;
+                dg[walked - 1] = (b - 1) | (hit ? 0x1000 : 0) | ((b - 1 - win0 < WIN && tslot_s[b - 1 - win0] >= 0) ? 0x2000 : 0);      // walked block | was prefetched | has a slot
+            }
+            n_hit += hit ? 1 : 0;
+            n_miss += have ? 0 : 1;
+#endif
+        }
+    }
+#ifdef DEQSCI_DIAG
+    if (lane == 0 && j == 0 && c == 0) {                        // (the unused rows of the counters: one chain's account of its time, in cycles)
+        int* dg = reinterpret_cast<int*>(st) + REF_WALKED + 6 * C16;
+        dg[0] = (int)(stamp1 - stamp0); dg[1] = (int)(stamp2 - stamp1); dg[2] = (int)c_group; dg[3] = (int)c_walk;
+        dg[4] = n_group; dg[5] = walked; dg[6] = n_hit; dg[7] = n_noslot; dg[8] = n_miss; dg[9] = (int)(__builtin_readcyclecounter() - stamp0);
+        dg[10] = (int)(stampA - stamp1); dg[11] = (int)(stampB - stampA); dg[12] = n_pf;
+    }
+#endif
+    if (lane == 0) {
+        st[REF_CSUM + j * C16 + c] = S;
+        reinterpret_cast<int*>(st)[REF_WALKED + j * C16 + c] = walked;
+        if (c == 0) reinterpret_cast<int*>(st)[REF_TAKEN + j] = 0;              // (gram_round_kernel's term slots: free again for the next call)
     }
 }
 
 __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __restrict__ partials, double* gram,
                                                               float* __restrict__ alpha, float* res, int bsz,
                                                               int nchunks, int slot, int n_filled, int n, float lam, float eps, int solve_f32,
-                                                              const float* __restrict__ gram32, int gram32_pitch
+                                                              const float* __restrict__ gram32, float* ref_state, int64_t ref_stride
 #ifdef DEQSCI_DIAG
                                                               , float gram_noise
 #endif
@@ -349,14 +788,42 @@ __global__ __launch_bounds__(WAVE) void anderson_solve_kernel(const float* __res
         gs[MAXM * MAXM + 1] = gg;                               // |G_k|^2
         res[1 + s] = (float)(sqrt(gg) / ((double)eps + sqrt(ff)));
     }
-    if (n > 0) {
+    if (ref_state) {
+        // anderson_arith = "reference": the sixteen chain sums of each entry of the new row (gram_row_chain16_kernel or the two-pass form of the
+        // same sums below) folded halves onto halves, row / column `slot` of the persistent fp32 Gram refreshed, the system solved in fp32
+        __shared__ float row32[MAXM];
+        float* g32 = ref_state + (int64_t)s * ref_stride;
+        const float* csum = g32 + REF_CSUM;
+#pragma unroll
+        for (int jb = 0; jb < MAXM / 4; ++jb) {
+            const int j = 4 * jb + (lane >> 4);
+            float v = (j < n_filled) ? csum[j * C16 + (lane & (C16 - 1))] : 0.0f;
+            v += __shfl_xor(v, 8, WAVE);                        // 16 -> 8 -> 4 -> 2 -> 1
+            v += __shfl_xor(v, 4, WAVE);
+            v += __shfl_xor(v, 2, WAVE);
+            v += __shfl_xor(v, 1, WAVE);
+            if (j < n_filled && (lane & (C16 - 1)) == 0) {
+                row32[j] = v;
+                g32[slot * MAXM + j] = v;
+                g32[j * MAXM + slot] = v;
+            }
+        }
+        __syncthreads();
+        if (n > 0) {
+            for (int i = lane; i < n * n; i += WAVE) {
+                const int a = i / n, b = i % n;
+                Gl[a * MAXM + b] = (double)((a == slot) ? row32[b] : (b == slot) ? row32[a] : g32[a * MAXM + b]);
+            }
+            __syncthreads();
+            bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
+        }
+    } else if (n > 0) {
         if (gram32) {
             // the REFERENCE's arithmetic for alpha (new_equilibrium_utils_yaping.py:177-180): the n x n Gram block as the caller's fp32
             // torch.bmm produced it (rows in slot order), the system formed and factorised in fp32 like torch.solve = sgesv.  The residual
             // above and the persistent float64 Gram keep their own, exact, sums.
             __syncthreads();
-            const int pitch = gram32_pitch ? gram32_pitch : n;                                  // (MAXM: the persistent Gram of gram_row_chain16_kernel)
-            for (int i = lane; i < n * n; i += WAVE) Gl[(i / n) * MAXM + (i % n)] = (double)gram32[(int64_t)s * pitch * pitch + (i / n) * pitch + (i % n)];
+            for (int i = lane; i < n * n; i += WAVE) Gl[(i / n) * MAXM + (i % n)] = (double)gram32[(int64_t)s * n * n + i];
             __syncthreads();
             bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
         } else if (solve_f32) bordered_solve<float>(Gl, M, alpha, s, lane, n, lam);
@@ -565,14 +1032,16 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
                                    int slot, int n_filled, int n, float lam, float eps, const float* gram32, deqsci_stream_t stream);
 
 static int solve_launch(const float* partials, void* gram, float* alpha, float* res, int64_t bsz, int64_t N, int slot, int n_filled, int n, float lam,
-                        float eps, const float* gram32, int pitch, hipStream_t st) {
+                        float eps, const float* gram32, float* ref_state, hipStream_t st) {
     const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+    const int64_t ref_stride = ref_words(nchunks);
 #ifdef DEQSCI_DIAG
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, pitch, (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, diag_env_int("DEQSCI_SOLVE_F32", 0), gram32, ref_state, ref_stride,
+                       (float)diag_env_f64("DEQSCI_GRAM_NOISE", 0.0));
 #else
     hipLaunchKernelGGL(anderson_solve_kernel, dim3((unsigned)bsz), dim3(WAVE), 0, st, partials, static_cast<double*>(gram), alpha, res,
-                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32, pitch);
+                       (int)bsz, nchunks, slot, n_filled, n, lam, eps, 0, gram32, ref_state, ref_stride);
 #endif
     return launch_status();
 }
@@ -589,22 +1058,53 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
     if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, gram32, 0, st);
+    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, gram32, nullptr, st);
 }
 
-size_t deqsci_gram_ref_bytes(int64_t bsz) { return (size_t)(bsz > 0 ? bsz : 0) * MAXM * MAXM * sizeof(float); }
+size_t deqsci_gram_ref_bytes(int64_t bsz, int64_t N) {
+    if (bsz <= 0 || N <= 0) return 0;
+    return (size_t)bsz * (size_t)ref_words(deqsci_anderson_chunks(bsz, N)) * sizeof(float);
+}
 
-int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* gram32, void* gram, float* alpha, float* res, int64_t bsz,
-                                  int64_t N, int m, int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
-    if (!G_hist || !partials || !gram32 || !gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
-    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
+static int ref_check(const float* G_hist, const float* partials, float* ref_state, int64_t bsz, int64_t N, int m, int slot, int n_filled) {
+    if (!G_hist || !partials || !ref_state) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || slot >= n_filled) return DEQSCI_ERR_SHAPE;
     if (m > MAXM || bsz > 65535) return DEQSCI_ERR_UNSUPPORTED;
-    if (!aligned16(G_hist)) return DEQSCI_ERR_ALIGN;
+    if (!aligned16(G_hist) || !aligned16(ref_state)) return DEQSCI_ERR_ALIGN;
+    return 0;
+}
+
+int deqsci_gram_row_chain16_f32(const float* G_hist, const float* partials, float* ref_state, int64_t bsz, int64_t N, int m, int slot, int n_filled,
+                                int serial, deqsci_stream_t stream) {
+    if (int rc = ref_check(G_hist, partials, ref_state, bsz, N, m, slot, n_filled)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gram_row_chain16_kernel, dim3((unsigned)ceil_div(n_filled, 4), (unsigned)bsz), dim3(C16_TB), 0, st, G_hist, gram32, N, m, slot, n_filled,
-                       (N % 4 == 0) ? 1 : 0);
+    const int64_t chunk = chunk_elems(bsz, N);
+    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+    const int64_t ref_stride = ref_words(nchunks);
+    if (serial || N % 4 != 0 || chunk > 16384) {                // (the two-pass form wants float4 rows and <= 1024 terms per chain and block)
+        hipLaunchKernelGGL(gram_row_chain16_kernel, dim3((unsigned)ceil_div(n_filled, 4), (unsigned)bsz), dim3(C16_TB), 0, st, G_hist, ref_state, ref_stride, N, m,
+                           slot, n_filled, (N % 4 == 0) ? 1 : 0);
+        return launch_status();
+    }
+    const dim3 grid((unsigned)nchunks, (unsigned)bsz);
+#define RND_CASE(NF) case NF: hipLaunchKernelGGL(gram_round_kernel<NF>, grid, dim3(TB), 0, st, G_hist, partials, ref_state, ref_stride, N, m, slot, chunk); break;
+    switch (n_filled) {
+        RND_CASE(1) RND_CASE(2) RND_CASE(3) RND_CASE(4) RND_CASE(5) RND_CASE(6) RND_CASE(7) RND_CASE(8)
+        default: return DEQSCI_ERR_UNSUPPORTED;
+    }
+#undef RND_CASE
     if (int rc = launch_status()) return rc;
-    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, gram32, MAXM, st);
+    hipLaunchKernelGGL(gram_chain_apply_kernel, dim3((unsigned)(n_filled * C16), (unsigned)bsz), dim3(WAVE), 0, st, G_hist, partials, ref_state, ref_stride, N, m, slot, chunk,
+                       nchunks);
+    return launch_status();
+}
+
+int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* ref_state, void* gram, float* alpha, float* res, int64_t bsz,
+                                  int64_t N, int m, int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    if (!gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
+    if (n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
+    if (int rc = deqsci_gram_row_chain16_f32(G_hist, partials, ref_state, bsz, N, m, slot, n_filled, 0, stream)) return rc;
+    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, nullptr, ref_state, static_cast<hipStream_t>(stream));
 }
 
 int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha, float* x_out, float beta, int n,

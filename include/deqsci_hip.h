@@ -124,12 +124,19 @@ int deqsci_anderson_solve_gram_f32(const float* partials, void* gram, float* alp
  *     chains per entry, chain c over k = c, c + 16, ..., summed pairwise at the end; within one ulp of torch.bmm, tools/gram_on_real_history.py).
  *     On the loop's heavy-tailed residuals that order ABSORBS the small products of a 2^15-step chain: the diagonal comes out 3-7e-6 too small -
  *     a bias, and the thing that moves the reference's chaotic FFDNet ensembles (an unbiased fp32 sum of the same error size
- *     does not).  G_hist = the history K4 wrote (bsz, m, N); gram32 = deqsci_gram_ref_bytes(bsz) bytes, caller-owned, persistent between calls
- *     (row / column `slot` of the MAX_M x MAX_M fp32 Gram of each sample is refreshed per call; the other rows are what a deterministic GEMM
- *     would recompute bit for bit).  The bordered system is then formed and factorised in fp32 (:180, sgesv); residuals and the float64 Gram
- *     of `gram` are kept exactly as by the entry points above.  Cost: N / 16 dependent FMAs (~70 us at N = 2^19, any batch size). */
-size_t deqsci_gram_ref_bytes(int64_t bsz);
-int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* gram32, void* gram, float* alpha, float* res,
+ *     does not).  G_hist = the history K4 wrote (bsz, m, N), partials = K4's block sums of the same call; ref_state = deqsci_gram_ref_bytes(bsz, N)
+ *     bytes, caller-owned, 16-byte aligned, ZEROED once and then left alone between calls (it carries the MAX_M x MAX_M fp32 Gram of each sample:
+ *     row / column `slot` is refreshed per call, the other rows are what a deterministic GEMM would recompute bit for bit).
+ *     deqsci_gram_row_chain16_f32 computes the 16 chain sums of every entry <G_slot, G_j>, j < n_filled, into ref_state: serial = 1 runs the chains
+ *     as they are written (N / 16 dependent FMAs, ~220 us at N = 2^19); serial = 0 produces THE SAME BITS in two passes - inside one binade of the
+ *     running sum a chain step is S + RN_ulp(p), an integer sum that any number of workgroups can form in any order; only the binade crossings are
+ *     walked term by term (csrc/anderson.hip) - and falls back to serial = 1 where N % 4 != 0.  deqsci_anderson_solve_ref_f32 = that (serial = 0),
+ *     then the bordered system formed and factorised in fp32 (:180, sgesv); residuals and the float64 Gram of `gram` as by the entry points above. */
+size_t deqsci_gram_ref_bytes(int64_t bsz, int64_t N);
+int deqsci_gram_row_chain16_f32(const float* G_hist, const float* partials, float* ref_state,
+                                int64_t bsz, int64_t N, int m, int slot, int n_filled, int serial,
+                                deqsci_stream_t stream);
+int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* ref_state, void* gram, float* alpha, float* res,
                                   int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                                   float lam, float eps, deqsci_stream_t stream);
 

@@ -225,6 +225,33 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, gram_dtyp
     return X[:, last % m].view_as(x0), res
 
 
+def gram_chain16(G):
+    """The fp32 `torch.bmm(G, G^T)` of solvers/new_equilibrium_utils_yaping.py:177-178 as the CPU that produced tests/golden sums it (MKL sgemm,
+    n x N times N x n with n <= 5, AVX-512): per entry SIXTEEN interleaved fused-multiply-add chains - chain c over k = c, c + 16, c + 32, ... -
+    and the sixteen sums folded halves onto halves.  G (n, N) fp32 numpy, N % 16 == 0 -> (n, n) fp32, and the (n, n, 16) chain sums.
+    Pinned by tests/test_oracle_golden.py against torch.bmm itself (within one ulp on every entry - the last bit is MKL's order of folding the
+    sixteen - and with the same bias of the diagonal on heavy-tailed rows); csrc/anderson.hip's kernels are held bit-equal to the chain sums."""
+    n, N = G.shape
+    A = np.ascontiguousarray(G, dtype=np.float32).reshape(n, -1, 16).astype(np.longdouble)
+    S = np.zeros((n, n, 16), np.float32)
+    for k in range(A.shape[1]):
+        a = A[:, k, :]
+        S = (S.astype(np.longdouble) + a[:, None, :] * a[None, :, :]).astype(np.float32)      # one rounding per step: an FMA
+    chains = S.copy()
+    while S.shape[-1] > 1:
+        h = S.shape[-1] // 2
+        S = (S[..., :h] + S[..., h:]).astype(np.float32)
+    return S[..., 0], chains
+
+
+def heavy_tailed_rows(seed=7, n=5, N=2 ** 19):
+    """Five correlated rows with heavy tails - a few elements carry the energy, as in Anderson's residual history in the FFDNet loop - from a
+    seed (numpy RandomState: frozen streams).  The input of tests/golden/gram_bmm_cpu.npz (tools/make_gram_golden.py)."""
+    rs = np.random.RandomState(seed)
+    base = rs.standard_normal(N) ** 3
+    return np.stack([(base * (1 + 0.05 * k) + 0.3 * rs.standard_normal(N) ** 3) * 1e-3 for k in range(n)]).astype(np.float32)
+
+
 def forward_iteration(f, x0, max_iter=50, tol=1e-5):
     """Picard iteration, solvers/new_equilibrium_utils_yaping.py:213-222: returns the last
     OUTPUT of f and the list of residuals."""

@@ -186,6 +186,88 @@ def test_anderson_kernels_vs_oracle_odd_sizes():
         assert abs(gres - wres) < 5e-2 * wres + 1e-7
 
 
+def _history(ws, rows):
+    """rows (bsz, m, N) -> the workspace's residual history G (x = 0: G = f), slot by slot as the loop stores it; returns the last slot."""
+    bsz, m, N = rows.shape
+    zero = torch.zeros(bsz, N, device=DEV)
+    for k in range(m):
+        _hip.residual_store(ws, rows[:, k].contiguous(), None, zero, k, k + 1, None)
+    return m - 1
+
+
+def _gram_rows(kind, bsz, m, N, gen):
+    r = lambda *sh: torch.randn(*sh, device=DEV, generator=gen)
+    if kind == "correlated":                                   # what the loop's history looks like late in the iteration
+        return (r(bsz, 1, N) * (1 + 0.05 * torch.arange(m, device=DEV).view(1, m, 1)) + 0.3 * r(bsz, m, N)) * 1e-2
+    if kind == "heavy":                                        # ... with its heavy tails: most products are absorbed by the running sum
+        return (r(bsz, 1, N) ** 3 + 0.3 * r(bsz, m, N) ** 3) * 1e-3
+    if kind == "orthogonal":                                   # off-diagonal sums wander around zero: nearly every block is walked
+        return r(bsz, m, N)
+    if kind == "negative":                                     # negative running sums
+        sign = torch.tensor([1.0, -1.0] * m, device=DEV)[:m].view(1, m, 1)
+        return sign * (r(bsz, 1, N) + 0.2 * r(bsz, m, N))
+    if kind == "tiny":
+        return (r(bsz, 1, N) + 0.3 * r(bsz, m, N)) * 1e-17
+    if kind == "huge":
+        return (r(bsz, 1, N) + 0.3 * r(bsz, m, N)) * 1e14
+    if kind == "few_bits":                                     # small integers / 1024: every product lands on a grid point or a TIE
+        return torch.randint(-40, 41, (bsz, m, N), device=DEV, generator=gen).float() / 1024
+    if kind == "zero_row":
+        x = r(bsz, m, N)
+        x[:, m - 1] = 0
+        return x
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["correlated", "heavy", "orthogonal", "negative", "tiny", "huge", "few_bits", "zero_row"])
+@pytest.mark.parametrize("bsz,N,m", [(1, 1 << 19, 5), (3, 1 << 17, 5), (2, 20480, 3), (1, (1 << 19) + 28, 8), (2, 105, 5), (1, 2048, 2)])
+def test_reference_gram_two_pass_form_is_bit_equal_to_the_serial_chains(kind, bsz, N, m):
+    """anderson_arith = "reference": the 16 FMA chains per Gram entry (csrc/anderson.hip) as they are written - N / 16 dependent FMAs,
+    gram_row_chain16_kernel - and in the two-pass form that ships (gram_round_kernel + gram_chain_apply_kernel: inside a binade of the running sum
+    a chain step is S + RN_ulp(p), an integer sum in any order; crossings, ties and oversized terms are walked) give THE SAME BITS, on every kind
+    of history: the loop's (correlated, heavy-tailed), sums that wander around zero or run negative, scales near the ends of fp32, operands with
+    few bits (ties), an all-zero row; ragged N, N % 4 != 0 (both forms fall back to the serial kernel), m = 8."""
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    rows = _gram_rows(kind, bsz, m, N, gen).float().contiguous()
+    ws = _hip.AndersonWorkspace(bsz, N, m, DEV)
+    slot = _history(ws, rows)
+    two = _hip.gram_row_chain16(ws, slot, m, serial=False)[:, :m].clone()
+    walked = ws.chains_walked()[:, :m].clone()
+    ser = _hip.gram_row_chain16(ws, slot, m, serial=True)[:, :m].clone()
+    assert torch.isfinite(ser).all()
+    assert torch.equal(two, ser), (kind, int((two != ser).sum()))
+    if N % 4 == 0:
+        assert (walked >= 0).all()                             # (the two-pass form did run)
+        if kind in ("correlated", "heavy") and N >= 1 << 17:
+            assert walked.float().mean() < 0.25 * (N // 2048)  # ... and passed most blocks without walking them
+    # a second call on another slot of the same workspace (records, term slots and counters are reused)
+    two2 = _hip.gram_row_chain16(ws, 0, m, serial=False)[:, :m].clone()
+    ser2 = _hip.gram_row_chain16(ws, 0, m, serial=True)[:, :m].clone()
+    assert torch.equal(two2, ser2)
+
+
+def test_reference_gram_kernels_vs_oracle_and_the_references_bmm():
+    """The chain sums of the kernels against the CPU restatement of the reference's summation order (oracle.gram_chain16: bit-equal), and the
+    folded Gram entries the engine solves with against what torch.bmm itself returned for the same rows on the CPU behind tests/golden
+    (gram_bmm_cpu.npz: within one ulp, and the same bias of the diagonal)."""
+    g = np.load(os.path.join(GOLDEN, "gram_bmm_cpu.npz"))
+    rows = orc.heavy_tailed_rows(int(g["seed"]), int(g["n"]), int(g["N"]))
+    want, chains = orc.gram_chain16(rows)
+    m, N = rows.shape
+    ws = _hip.AndersonWorkspace(1, N, m, DEV)
+    R = G(torch.from_numpy(rows))[None]
+    zero = torch.zeros(1, N, device=DEV)
+    for k in range(m):                                         # every slot's row / column, as the loop fills them
+        _hip.residual_store(ws, R[:, k].contiguous(), None, zero, k, k + 1, None)
+        _hip.anderson_solve(ws, k, k + 1, k + 1 if k else 0, 1e-2, 1e-5, ref=True)
+        assert np.array_equal(ws.chain_sums()[0, :k + 1].cpu().numpy(), chains[k, :k + 1]), k
+    got = ws.gram32_state()[0, :m, :m].cpu().numpy()
+    assert np.array_equal(got, want)
+    assert (np.abs(got.astype(np.float64) - g["bmm"]) <= np.spacing(np.abs(g["bmm"]))).all()
+    err = np.diag((got.astype(np.float64) - g["exact"]) / g["exact"])
+    assert (err < -1e-5).all()
+
+
 # ----------------------------------------------------------------------------- f-map and the DEQ loop
 def _pipeline(kind, iters, iterator="anderson"):
     solver, deq = build_pipeline(kind, checkpoint.shipped("ffdnet_gray" if kind == "ffdnet" else "cnn"), iters)

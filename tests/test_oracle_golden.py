@@ -162,6 +162,29 @@ def test_reference_fp32_gram_loses_digits_at_large_n():
     assert rel_l2(a, b) < 1e-5
 
 
+def test_gram_chain16_is_the_summation_order_of_the_references_bmm():
+    """The Gram matrix of solvers/new_equilibrium_utils_yaping.py:177-178 is ONE fp32 torch.bmm over N = H W B elements, and on the CPU that produced
+    tests/golden (MKL, AVX-512) its K loop is sixteen interleaved FMA chains per entry.  oracle.gram_chain16 restates that order; the fixture
+    (tools/make_gram_golden.py) holds what torch.bmm itself returned here for five heavy-tailed rows of N = 2^19: every entry within ONE ulp (the
+    last bit is MKL's order of folding the sixteen sums) - and, what matters for the chaotic FFDNet runs, the same BIAS: a chain
+    of 2^15 steps absorbs the many small products, so the diagonal (all terms positive) comes out too small by far more than the off-diagonal
+    entries are off.  Where the machine running this test has the same BLAS kernel, torch.bmm is compared live as well."""
+    g = np.load(os.path.join(GOLDEN, "gram_bmm_cpu.npz"))
+    G_ = orc.heavy_tailed_rows(int(g["seed"]), int(g["n"]), int(g["N"]))
+    got, chains = orc.gram_chain16(G_)
+    bmm, exact = g["bmm"], g["exact"]
+    assert chains.shape == (5, 5, 16) and got.dtype == np.float32
+    assert (np.abs(got.astype(np.float64) - bmm) <= np.spacing(np.abs(bmm))).all()
+    assert (got == bmm).sum() >= 10
+    err = (got.astype(np.float64) - exact) / exact
+    diag, off = np.diag(err), np.abs(err[~np.eye(5, dtype=bool)])
+    assert (diag < -1e-5).all() and off.mean() < 0.5 * np.abs(diag).mean()
+    np.testing.assert_allclose(np.diag((bmm - exact) / exact), diag, atol=2e-7)
+    live = torch.bmm(T(G_)[None], T(G_)[None].transpose(1, 2))[0].numpy()
+    if np.array_equal(live, bmm):                              # (same BLAS kernel as the fixture's machine)
+        assert (np.abs(got.astype(np.float64) - live) <= np.spacing(np.abs(live))).all()
+
+
 def test_admm_variant_golden():
     g = np.load(os.path.join(GOLDEN, "admm_toy.npz"))
     Phi, y, Ps, x0, u0 = (T(g[k]) for k in ("Phi", "y", "Phi_sum", "x0", "u0"))

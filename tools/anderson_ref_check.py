@@ -60,6 +60,10 @@ def gram():
                         acc = (acc[:acc.size // 2] + acc[acc.size // 2:]).astype(np.float32)
                     emu[b, i, j] = float(acc[0])
         bit_equal = int((emu[0].double() == g32[0].cpu()).sum())
+        two = _hip.gram_row_chain16(ws, m - 1, m, serial=False)[:, :m].clone()           # the 16 chain sums per entry: two-pass form against the chains as written
+        walked = ws.chains_walked()[:, :m].clone().float()
+        ser = _hip.gram_row_chain16(ws, m - 1, m, serial=True)[:, :m].clone()
+        chains_equal = "%d / %d" % (int((two == ser).sum()), two.numel())
         a_ref = ws.alpha.clone().view(bsz, -1)[:, :m]
         ws2 = _hip.AndersonWorkspace(bsz, N, m, DEV)
         fill(ws2, f, x, False)
@@ -72,7 +76,7 @@ def gram():
             return {"mean": float(r.mean()), "max": float(r.max())}
         print(json.dumps({"what": "fp32 Gram against float64, relative error of an entry", "bsz": bsz, "N": N,
                           "kernel (16 interleaved FMA chains per entry)": err(g32), "entries bit-equal to a numpy emulation of that order (sample 0)": "%d / %d" % (bit_equal, m * m),
-                          "signed error of the diagonal x 1e6 (sample 0)": [round(float(v) * 1e6, 2) for v in ((g32 - exact) / exact)[0].diagonal()], "one fp32 torch.bmm (rocBLAS)": err(bmm.double()),
+                          "chain sums, two-pass form bit-equal to the serial chains": chains_equal, "blocks walked per chain (of %d): mean, max" % (N // 2048): [float(walked.mean()), float(walked.max())], "signed error of the diagonal x 1e6 (sample 0)": [round(float(v) * 1e6, 2) for v in ((g32 - exact) / exact)[0].diagonal()], "one fp32 torch.bmm (rocBLAS)": err(bmm.double()),
                           "alpha kernels vs exact": float((a_ref - a_exact).abs().max()), "alpha bmm vs exact": float((a_bmm - a_exact).abs().max()),
                           "alpha": a_ref[0].tolist(), "alpha exact": a_exact[0].tolist()}), flush=True)
 
@@ -99,7 +103,10 @@ def time_():
                     _hip.anderson_solve(ws, 2, m, m, 1e-2, 1e-5, gram32=torch.bmm(Gh, Gh.transpose(1, 2)))
                 else:
                     _hip.anderson_solve(ws, 2, m, m, 1e-2, 1e-5, ref=fine)
-            for label, fn in (("K4 residual_store", k4), ("K5 solve", k5)):
+            extra = ()
+            if fine:
+                extra = (("the 16 x n chains, serial", lambda: _hip.gram_row_chain16(ws, 2, m, serial=True)), ("the 16 x n chains, two passes", lambda: _hip.gram_row_chain16(ws, 2, m, serial=False)))
+            for label, fn in (("K4 residual_store", k4), ("K5 solve", k5)) + extra:
                 for _ in range(5):
                     fn()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
