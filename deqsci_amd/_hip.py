@@ -904,7 +904,7 @@ def split16_stack_per_launch(n, H, W, slice_bytes=STACK_SLICE_BYTES, cus=None, t
     return min(per, n)
 
 
-def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
+def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None, check=None):
     """x Sp16 -> the run of 64->64 layers `stack` (Split16Stack), each launch a whole run (csrc/conv_s16.hip, STACK: the persistent
     workgroups walk their tiles layer after layer, a tile waiting for the layer before of itself and its eight neighbours) over a slice
     of the batch - per_launch images (None: split16_stack_per_launch, slices that fit the Infinity Cache), one launch after the other;
@@ -944,6 +944,11 @@ def conv3x3_c64_split16_stack(x, stack, ranges=None, events=None, per_launch=Non
     if out.n != n:
         out = Sp16(out.t[:n], n, H, W)
     out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers][rng_offset:rng_offset + n]), SP16_DEFAULT_EXP
+    if check is None:
+        check = not torch.cuda.is_current_stream_capturing()
+    if check and stack.timed_out():                             # (one host sync; DEQSCIEngine passes check=False and looks once per reconstruction)
+        raise DeqsciHipError("a wait inside the stack launch timed out - its workgroups were not all resident (the device's CUs are shared with "
+                             "other work): the output of this call is invalid; use one launch per layer")
     return out
 
 
@@ -1092,7 +1097,7 @@ class Wino16Stack(Split16Stack):
         return Wino16Weights
 
 
-def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None):
+def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None, rng_offset=0, out_bufs=None, check=None):
     """conv3x3_c64_split16_stack on the Winograd kernel: x P32 -> the run of 64->64 layers `stack` (Wino16Stack), each launch a whole run
     over a slice of the batch; same arguments, same time-out contract."""
     _act_check(x, "conv3x3_c64_wino16_stack")
@@ -1127,6 +1132,11 @@ def conv3x3_c64_wino16_stack(x, stack, ranges=None, events=None, per_launch=None
     if out.n != n:
         out = stack.act(out.t[:n], n, H, W)
     out.rng, out.exp = (None if ranges is None else ranges[stack.n_layers][rng_offset:rng_offset + n]), SP16_DEFAULT_EXP
+    if check is None:
+        check = not torch.cuda.is_current_stream_capturing()
+    if check and stack.timed_out():                             # (one host sync; DEQSCIEngine passes check=False and looks once per reconstruction)
+        raise DeqsciHipError("a wait inside the stack launch timed out - its workgroups were not all resident (the device's CUs are shared with "
+                             "other work): the output of this call is invalid; use one launch per layer")
     return out
 
 

@@ -157,6 +157,24 @@ inline int num_cus() {
     return cached[dev];
 }
 
+// Workgroups of `kernel` the device can hold AT ONCE (occupancy query x CUs; cached per device): what a launch whose workgroups wait for one
+// another - the stack launches of conv_s16.hip / conv_w16.hip - may ask for at most.  0: the kernel cannot be resident as built (the caller
+// reports DEQSCI_ERR_UNSUPPORTED instead of launching something that would sit in its waits until they time out).
+template <typename Kernel> inline int64_t resident_workgroups(Kernel kernel, int threads, int* cache /* [64], zero-initialised */) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu <= 0) {
+            (void)hipGetLastError();
+            cache[dev] = -1;
+        } else {
+            cache[dev] = per_cu;
+        }
+    }
+    return cache[dev] > 0 ? (int64_t)cache[dev] * num_cus() : 0;
+}
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : static_cast<int>(e);

@@ -610,6 +610,9 @@ __global__ __launch_bounds__(TBW, 2) void conv_s16_kernel(const char* __restrict
         // verdict through LDS behind its barrier): with several tiles per workgroup they were written a tile or more ago
         stage(2, true, [&]() __attribute__((always_inline)) {
             if (STACK && wave == 0) {
+                // (the poll's destination register is only valid behind the wait: said to the compiler too, so that it cannot copy or spill
+                //  the register between the load's issue and here - the stage's own wait has already drained the queue, this one is free)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv)::"memory");
                 const unsigned target = fbase + (unsigned)L_next;
                 const bool late = poll && lane < 9 && (int)(pv - target) < 0;
                 const uint32_t ok = (!poll || fgiveup) ? 1u : (__builtin_amdgcn_ballot_w64(late) == 0 ? 1u : 0u);
@@ -1154,7 +1157,10 @@ extern "C" int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even
     // every workgroup of the launch has to be RESIDENT (they wait for one another): one per CU - the kernel's 152 KB of LDS admit no
     // second one - so never more workgroups than CUs; each walks its tiles layer after layer
     if (n_tiles > (int64_t)INT32_MAX / (16 * 32)) return DEQSCI_ERR_UNSUPPORTED;
-    const int64_t resident = (int64_t)num_cus();
+    static int occ_cache[64] = {0};
+    const int64_t fit = resident_workgroups(s16::conv_s16_kernel<0, 0, 1>, s16::TBW, occ_cache);
+    if (fit <= 0) return DEQSCI_ERR_UNSUPPORTED;                // (the waits inside the launch need every workgroup resident: ask the runtime, do not assume)
+    const int64_t resident = fit < (int64_t)num_cus() ? fit : (int64_t)num_cus();
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t mg_img, sh_img, mg_tx, sh_tx;
     s16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);

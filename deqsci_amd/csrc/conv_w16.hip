@@ -663,7 +663,10 @@ extern "C" int deqsci_conv3x3_c64_wino16_stack(const void* x_p32, void* y_even, 
     // every workgroup of the launch has to be RESIDENT (they wait for one another): one per CU - the kernel's 148 KB of LDS admit no second
     // one - so never more workgroups than CUs; each walks its tiles layer after layer
     if (n_tiles > (int64_t)INT32_MAX / (16 * 32)) return DEQSCI_ERR_UNSUPPORTED;
-    const int64_t resident = (int64_t)num_cus();
+    static int occ_cache[64] = {0};
+    const int64_t fit = resident_workgroups(w16::conv_w16_kernel<1>, w16::TBW, occ_cache);
+    if (fit <= 0) return DEQSCI_ERR_UNSUPPORTED;                // (the waits inside the launch need every workgroup resident: ask the runtime, do not assume)
+    const int64_t resident = fit < (int64_t)num_cus() ? fit : (int64_t)num_cus();
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t mg_img, sh_img, mg_tx, sh_tx;
     w16_magic((uint32_t)(tiles_x * tiles_y), &mg_img, &sh_img);

@@ -203,6 +203,8 @@ def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
     procs, logs = [], []
     scratch = tempfile.mkdtemp(prefix="deqsci_ranks_")
     forwarded = [0]                                      # bytes of rank 0's stderr already passed through
+    import codecs
+    decoder = codecs.getincrementaldecoder("utf-8")(errors="replace")    # (a character split between two polls is completed by the next one)
 
     def forward_rank0():
         try:
@@ -213,7 +215,7 @@ def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
             return
         if chunk:
             forwarded[0] += len(chunk)
-            sys.stderr.write(chunk.decode(errors="replace"))
+            sys.stderr.write(decoder.decode(chunk))
             sys.stderr.flush()
 
     def on_term(signum, frame):
@@ -274,6 +276,8 @@ def launch_ranks(argv, n, device_ids=None, timeout=None, _attempts=2):
         finally:
             shutil.rmtree(scratch, ignore_errors=True)
     if retry:
+        sys.stderr.write(f"[launch_ranks] the rendezvous lost the race for port {port} (address already in use; rank {first_bad}'s traceback may be "
+                         "above): starting the ranks again on a new port\n")
         return launch_ranks(argv, n, device_ids=device_ids, timeout=timeout, _attempts=_attempts - 1)
     return code
 

@@ -242,7 +242,7 @@ class _Denoiser:
             # the whole run in one launch (per slice of the batch): sp16 in, sp16 out, ranges of the run = slots idx[0] .. idx[-1] + 1
             self.stack_launches += 1
             return _hip.conv3x3_c64_split16_stack(h, self._stack_for(idx, h.t.device), None if self.ranges is None else self.ranges[idx[0]:idx[-1] + 2],
-                                                  per_launch=self.stack_per_launch)
+                                                  per_launch=self.stack_per_launch, check=False)
         for pos, i in enumerate(idx):
             w, b, relu = self.fast[i]
             nxt = idx[pos + 1] if pos + 1 < len(idx) else None
@@ -356,11 +356,11 @@ class _Denoiser:
                         out_rng = None if self.ranges is None else self._slot(1)[a:a + m]
                         if w16:
                             hs = _hip.ffdnet_head_p32(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
-                            ys = _hip.conv3x3_c64_wino16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
+                            ys = _hip.conv3x3_c64_wino16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
                             _hip.ffdnet_tail_p32(ys, self.tail_w16, out=out[a:a + m])
                         else:
                             hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
-                            ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs)
+                            ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
                             _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
                     self.stack_launches += 1
                     return out.reshape(bsz, B, H, W), True

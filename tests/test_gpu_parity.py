@@ -1167,6 +1167,18 @@ def test_split16_stack_timeout_is_reported_and_the_engine_falls_back(bsz, stack_
     again = eng.reconstruct(y, Phi)
     assert eng.den.stack is True and eng.last_info["stack_launches"] == eng.last_info["f_calls"] - 1 and eng.stack_timeouts_total == 1
     assert _same(again, want, stack_kernel)
+    # the launchers' own API says so too: called directly (not from the engine, not under capture) a timed-out launch RAISES
+    n = 8 * bsz
+    x = torch.relu(torch.randn(n, 64, 128, 128, device=DEV)).contiguous(memory_format=torch.channels_last)
+    if stack_kernel == "w16":
+        xin, launch = _hip.P32.from_nchw(x), _hip.conv3x3_c64_wino16_stack
+    else:
+        xin, launch = _hip.to_split16(x), _hip.conv3x3_c64_split16_stack
+    launch(xin, stack)                                          # fine
+    stack.flags(n, 128, 128)[32 * 5] -= 1000
+    with pytest.raises(_hip.DeqsciHipError, match="timed out"):
+        launch(xin, stack)
+    launch(xin, stack)                                          # (rearmed by the check)
 
 
 @pytest.mark.parametrize("kind", ["ffdnet", "ffdnet-s16", "SimpleCNN", "SimpleCNN-128"])

@@ -34,14 +34,14 @@ _hip.CONV64_EVENT_HOOK = lambda kind, m, hh, ww, layers=1: timer.pair()
 if kernel == "s16":
     stack = _hip.Split16Stack(list(zip(Ws, bs, [True] * L)), "cuda")
     for _ in range(passes):
-        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng)
+        out = _hip.conv3x3_c64_split16_stack(h0, stack, rng, check=False)
     same = torch.equal(out.t, h.t)
 else:
     Ww = [_hip.Wino16Weights(w) for w in ws_raw]
     stack = _hip.Wino16Stack(list(zip(Ww, bs, [True] * L)), "cuda")
     p0 = _hip.P32.from_nchw(x, rng=rng[0])
     for _ in range(passes):
-        out = _hip.conv3x3_c64_wino16_stack(p0, stack, rng)
+        out = _hip.conv3x3_c64_wino16_stack(p0, stack, rng, check=False)
     d = (out.to_nchw().double() - h.to_nchw().double()).norm() / h.to_nchw().double().norm()
     same = float(d) < 3e-6                                      # (the direct kernel's chain of 13 layers: another arithmetic of the same accuracy)
 torch.cuda.synchronize()
