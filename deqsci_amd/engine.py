@@ -431,13 +431,15 @@ class DEQSCIEngine:
             raise ValueError(iterator)
         if anderson_arith not in ("float64", "reference", "reference-bmm"):
             raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'float64', 'reference' or 'reference-bmm'")
-        # How alpha is computed.  "float64" (default): the Gram row accumulated in float64 from the fp32 block partials of K4, the bordered
-        # system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference": the reference's own arithmetic for that step,
-        # solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over the N = H W B elements (rocBLAS here, MKL there:
-        # ~5e-6 relative on an entry at N = 2^19), the system formed and factorised in fp32 by K6 as sgesv does (the GEMM is capturable: the hipGraph path stays; it costs rocBLAS's
-        # ~200 us for this 5 x 2^19 x 5 shape per iteration, +50 % at one measurement per call).  It exists
-        # because that rounding error is not neutral on BASELINE config 2: it is what puts the reference's 180-iteration ensemble mean
-        # 0.02 dB above the exact-Gram result ("Config 2"; tools/config2_anderson_arith.py).
+        # How alpha is computed.  "float64" (this class's default): the Gram row accumulated in float64 from the fp32 block partials of K4, the
+        # bordered system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference" (what the drop-in DEQFixedPoint / andersonexp and bench.py
+        # pass): the reference's own arithmetic for that step, solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over
+        # the N = H W B elements, fp32 LU - by the build's own kernels: the new Gram row in the summation ORDER of that GEMM on the CPU behind
+        # tests/golden (16 interleaved FMA chains per entry, csrc/anderson.hip; no GEMM library, capturable), the system formed and factorised
+        # in fp32 by K6 as sgesv does.  It exists because that order is not neutral on BASELINE config 2: a 2^15-step chain absorbs the many
+        # small products of the heavy-tailed residuals, the diagonal of the Gram matrix comes out 3-7e-6 too small, and that bias is what
+        # puts the reference's 180-iteration ensemble means where they are ("Config 2").  Cost: +3 % of a step at eight
+        # measurements per call, +12 % at one.  "reference-bmm": round 4's form, the Gram as one rocBLAS torch.bmm (A/B only: +13 % / +65 %).
         self.anderson_arith = anderson_arith
         if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
             raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'fast32', 'f22', 'f44' or 's16'")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the profiles/r05_* files of profiles/README.md's round-5 table (run on the GPU box through gpurun).  Stages can be skipped:
-# R5_SKIP="tests pmc shapes".  The stamp file needs the profiling build first: bash tools/w16_variants.sh "stamp:-DW16_STAMP"
+# R5_SKIP="tests pmc shapes anderson".  The stamp file needs the profiling build first: bash tools/w16_variants.sh "stamp:-DW16_STAMP"
 mkdir -p gpurun_out/r05p gpurun_out/pmc_w16
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -33,6 +33,9 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 cp $(find $R/gpurun_out/prof_bench5 -name "*kernel_stats.csv" | head -1) $O/r05_bench_kernel_stats.csv
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_bsz1_5 -o b1 -- python3 $R/bench.py --batch-per-gpu 1 --steps 2 --warmup 2 --no-cpu-baseline --no-hbm-stream --no-kernel-timing --no-other-kernel --no-other-configs --no-parity-check > $R/gpurun_out/prof_bsz1_5.log 2>&1
 cp $(find $R/gpurun_out/prof_bsz1_5 -name "*kernel_stats.csv" | head -1) $O/r05_bench_bsz1_graph_kernel_stats.csv
+cd $R
+if ! skip anderson; then bash tools/gpu_round5_anderson.sh; fi
+cd /tmp
 if ! skip pmc; then
   i=0
   for SET in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
