@@ -254,7 +254,15 @@ int deqsci_conv3x3_c64_split16(const void* x_sp16, const void* w_packed, const f
  *     each), zeroed ONCE by the caller and then left alone: the progress words count on from launch to launch (launches of one shape
  *     may share them when they run one after the other; another shape needs its own).  flags[32 n_tiles] != 0 after a launch = a wait
  *     timed out - a workgroup of the launch was not resident, i.e. somebody else holds CUs of this device - and the output of that
- *     launch is invalid; the launch never hangs, and later launches on the same words do not wait at all (zero the words to rearm). */
+ *     launch is invalid; the launch never hangs, and later launches on the same words do not wait at all (zero the words to rearm).
+ *     THE RESIDENCY / TIME-OUT CONTRACT (this launch and deqsci_conv3x3_c64_wino16_stack): the workgroups of a launch wait for ONE ANOTHER, so all
+ *     of them must be resident at once.  The launcher asks for min(n_tiles, CUs) workgroups, one per CU by their LDS footprint, after an
+ *     occupancy query (DEQSCI_ERR_UNSUPPORTED if the kernel cannot be resident at all on this device) - which holds when the device's CUs
+ *     are the caller's: no CU mask, no other process, no concurrent kernel of another stream holding CUs for the length of the launch.  It
+ *     is NOT enforced by the hardware queue (no cooperative launch: those cannot be captured into a hipGraph).  A caller who cannot
+ *     promise it must read flags[32 n_tiles] after the launch (the Python launchers do, and raise; DEQSCIEngine reads it after the first
+ *     stack f-call of a reconstruction and at its end, redoes the call with one launch per layer and stays there for 16 calls) - a
+ *     waiting workgroup gives up after ~0.25 s, so a broken promise costs time and an invalid output that says so, never a hang. */
 int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_odd, const void* layers, int n_layers,
                                      int64_t n, int64_t H, int64_t W, const float* ranges, int64_t range_stride, int in_exp, int out_exp,
                                      void* flags, deqsci_stream_t stream, void* start_event, void* stop_event);
@@ -267,8 +275,11 @@ int deqsci_conv3x3_c64_split16_stack(const void* x_sp16, void* y_even, void* y_o
  *     u_packed: 2^w_exp U as [4 cin chunks][2 xi halves][2 xi'][3 dy][2 pieces: hi, lo][2 cout groups of 32][64 lanes][8 halfs]
  *     (xi = 2 half + xi', cout = 32 g + lane % 32, cin = 16 c + 8 (lane / 32) + j), w_exp the power of two that puts max |U| into [2^13, 2^14).
  *     Activations x, y in "p32": the 16 planes of 16-byte pixels of sp16 holding 2^e x as fp32 instead of hi + lo fp16 -
- *     [n][8 blocks of 8 channels][2 halves of 4][H][W][4 floats] (nothing to join in front of the transform, nothing to split behind the output
- *     transform); FFDNet's first and last layer write / read it (deqsci_ffdnet_head_p32, deqsci_ffdnet_tail_p32).  Ranges (in_amax, in_exp),
+ *     [n][8 blocks of 8 channels][2 halves of 4][H][ceil(W/64) column blocks][2 column parities][32][4 floats]: plane 2 b8 + j = channels
+ *     8 b8 + 4 j .. + 3, a row is 64 ceil(W/64) pixels long (the tail of the last block is padding nobody reads), and inside a block of 64
+ *     columns the 32 EVEN columns come first, then the 32 odd ones - an F(2,3) tile pair reads and writes whole 128-byte lines (nothing to
+ *     join in front of the transform, nothing to split behind the output transform); FFDNet's first and last layer write / read it
+ *     (deqsci_ffdnet_head_p32, deqsci_ffdnet_tail_p32).  Ranges (in_amax, in_exp),
  *     (out_amax, out_exp): as for sp16 (B^T d is at most twice max |d|: the headroom against fp16's overflow is 8 x the measured maximum
  *     instead of 16 x).  Output = relu?(conv + bias).  Block tiles of 8 x 64 output pixels, one persistent 512-thread workgroup per CU
  *     (a wave = one output row x 64 couts; 148 KB of LDS). */
