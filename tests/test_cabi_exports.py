@@ -38,11 +38,18 @@ def test_scratch_size_queries_and_error_strings():
     # argument validation happens before any launch, so it is testable without a GPU
     assert lib.deqsci_sci_forward_f32(None, None, None, 1, 4, 4, 8, 0, 0, None) == -1
     assert lib.deqsci_residual_store_f32(None, None, None, None, None, None, None, 1, 64, 5, 0, 1, None) == -1
+    # the reference's Gram arithmetic (round 5): state size = per sample the 8 x 8 Gram, chain sums, counters, block records and term slots
+    nb = lib.deqsci_gram_ref_bytes(8, 256 * 256 * 8)
+    assert nb % 16 == 0 and nb // 8 > 4 * (64 + 128 + n * 8 * 16 * 2 * 2) and lib.deqsci_gram_ref_bytes(0, 10) == 0
+    assert lib.deqsci_anderson_solve_ref_f32(None, None, None, None, None, None, 1, 64, 5, 0, 1, 0, 1e-2, 1e-5, None) == -1
+    assert lib.deqsci_gram_row_chain16_f32(None, None, None, 1, 64, 5, 0, 1, 0, None) == -1
     buf = (ctypes.c_float * 96)()
     p = ctypes.addressof(buf)
     p16 = (p + 15) // 16 * 16
     assert lib.deqsci_sci_forward_f32(p16, p16, p16, 1, 2, 2, -8, 0, 0, None) == -2
     assert lib.deqsci_sci_forward_f32(p16 + 4, p16, p16, 1, 2, 2, 8, 0, 0, None) == -3
+    assert lib.deqsci_gram_row_chain16_f32(p16, p16, p16, 1, 64, 5, 5, 5, 0, None) == -2           # slot >= m
+    assert lib.deqsci_gram_row_chain16_f32(p16, p16, p16 + 4, 1, 64, 5, 0, 1, 0, None) == -3
     assert lib.deqsci_gap_update_f32(p16, p16, p16, p16, p16, 1, 2, 2, 8, 0, 1, 0, None) == -4     # aliasing across layouts
     assert lib.deqsci_anderson_mix_f32(p16, p16, p16, p16, 1.0, 9, 1, 8, 9, None) == -4           # m > DEQSCI_MAX_M
     # Winograd conv: the kernel forms a 32-bit byte offset (pixel * 256 B), so images of 2^24 pixels or more are refused

@@ -1904,16 +1904,19 @@ def test_engine_conv_layout_and_kernel_choice():
         _hip.CONV64_EVENT_HOOK = None
 
 
-def test_engine_graph_replay_is_bit_identical_to_eager():
+@pytest.mark.parametrize("anderson_arith", ["float64", "reference"])
+def test_engine_graph_replay_is_bit_identical_to_eager(anderson_arith):
     """The hipGraph path replays the same kernels with the same arguments: first call of a shape eager, second captured,
     later ones replayed with new inputs - all bit-identical to an engine that never uses a graph; and when the tolerance
-    test would have fired inside a replayed run the call is redone eagerly and stops where the reference stops."""
+    test would have fired inside a replayed run the call is redone eagerly and stops where the reference stops.  In both Anderson
+    arithmetics: the reference's (its Gram kernels hand out their term slots with an atomic counter - the ORDER of the slots varies from
+    run to run, the sums do not) is as capturable and as deterministic as the exact one."""
     d = _clip("traffic_cacti.mat")
     Phi = d["mask"][None].to(DEV)
     ys = d["meas"].permute(2, 0, 1).contiguous().to(DEV)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 14)[0].nonlinear_op
-    eager = DEQSCIEngine(net, max_iter=14, use_graph=False)
-    graph = DEQSCIEngine(net, max_iter=14, use_graph=True)
+    eager = DEQSCIEngine(net, max_iter=14, use_graph=False, anderson_arith=anderson_arith)
+    graph = DEQSCIEngine(net, max_iter=14, use_graph=True, anderson_arith=anderson_arith)
     want = [eager.reconstruct(ys[i:i + 1], Phi).clone() for i in range(3)]
     assert eager.last_info["graph"] is False
     got0 = graph.reconstruct(ys[0:1], Phi)                   # first call of the shape: eager warm-up
