@@ -1742,12 +1742,16 @@ def test_config2_ffdnet_anderson_180_all_measurements():
 
 
 def test_config2_with_the_references_anderson_arithmetic():
-    """The other half of the config-2 account: with the reference's OWN arithmetic for alpha - `anderson_arith="reference"`: G G^T as one
-    fp32 torch.bmm over N = 2^19 elements, fp32 LU, solvers/new_equilibrium_utils_yaping.py:177-180 - the engine's 25-start ensembles of the
-    six chaotic measurements reproduce the reference AS IT IS: the six-measurement mean within 3 SE of the difference (the exact-Gram
-    default sits 0.02 below, previous test), and the reference's signature measurement - traffic m2, 21.53 +- 0.01 dB in the reference as
-    it is, 21.31-21.41 under every exact-Gram implementation incl. the float64 denoiser - above 21.45.  On a well-conditioned
-    configuration the two arithmetics agree to 1e-5 and both hold the reference's run at 1e-4."""
+    """The other half of the config-2 account: with the reference's OWN arithmetic for alpha - `anderson_arith="reference"`, what the drop-in
+    DEQFixedPoint runs: G G^T in fp32 in the summation ORDER of the reference's torch.bmm (16 interleaved FMA chains per entry, formed by
+    csrc/anderson.hip's own kernels; its 2^15-step chains absorb the small products of the heavy-tailed residuals, so the diagonal comes out
+    3-7e-6 too small), fp32 LU, solvers/new_equilibrium_utils_yaping.py:177-180 - the engine's 25-start ensembles of the six chaotic
+    measurements reproduce the reference AS IT IS: the six-measurement mean within 3 SE of the difference (the exact-Gram engine sits 0.02
+    below, previous test; 100 starts: 21.430 +- 0.003 against 21.439 +- 0.005, profiles/r05_config2_reference_arithmetic_100seeds.json), and
+    the reference's signature measurement - traffic m2, 21.53 +- 0.01 dB in the reference as it is, 21.31-21.41 under every exact-Gram
+    implementation incl. the float64 denoiser AND under an unbiased fp32 Gram of the same error size
+    (profiles/r05_config2_reference_arithmetic_chain64.json) - above 21.45.  On a well-conditioned configuration the two arithmetics agree to
+    1e-5 and both hold the reference's run at 1e-4."""
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
     eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, anderson_arith="reference")
     report, _, _ = _config2_ensembles(eng, chaotic_only=True)
