@@ -220,13 +220,14 @@ def _gram_rows(kind, bsz, m, N, gen):
 
 
 @pytest.mark.parametrize("kind", ["correlated", "heavy", "orthogonal", "negative", "tiny", "huge", "few_bits", "zero_row"])
-@pytest.mark.parametrize("bsz,N,m", [(1, 1 << 19, 5), (3, 1 << 17, 5), (2, 20480, 3), (1, (1 << 19) + 28, 8), (2, 105, 5), (1, 2048, 2)])
+@pytest.mark.parametrize("bsz,N,m", [(1, 1 << 19, 5), (3, 1 << 17, 5), (2, 20480, 3), (1, (1 << 19) + 28, 8), (2, 105, 5), (1, 2048, 2), (1, 1 << 22, 3), (9, 1 << 15, 5)])
 def test_reference_gram_two_pass_form_is_bit_equal_to_the_serial_chains(kind, bsz, N, m):
     """anderson_arith = "reference": the 16 FMA chains per Gram entry (csrc/anderson.hip) as they are written - N / 16 dependent FMAs,
     gram_row_chain16_kernel - and in the two-pass form that ships (gram_round_kernel + gram_chain_apply_kernel: inside a binade of the running sum
     a chain step is S + RN_ulp(p), an integer sum in any order; crossings, ties and oversized terms are walked) give THE SAME BITS, on every kind
     of history: the loop's (correlated, heavy-tailed), sums that wander around zero or run negative, scales near the ends of fp32, operands with
-    few bits (ties), an all-zero row; ragged N, N % 4 != 0 (both forms fall back to the serial kernel), m = 8."""
+    few bits (ties), an all-zero row; ragged N, N % 4 != 0 (both forms fall back to the serial kernel), m = 8, more blocks than the record window of
+    the apply kernel (N = 2^22: 2048 blocks, eight windows), an odd batch."""
     gen = torch.Generator(device=DEV).manual_seed(11)
     rows = _gram_rows(kind, bsz, m, N, gen).float().contiguous()
     ws = _hip.AndersonWorkspace(bsz, N, m, DEV)
