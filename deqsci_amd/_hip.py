@@ -58,6 +58,8 @@ SIGNATURES = {
     "deqsci_ffdnet_tail_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
     "deqsci_ffdnet_head_split16": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_conv3x3_c64_to_1_split16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
+    "deqsci_conv3x3_c64_to_1_p32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
+    "deqsci_conv3x3_c1_to_64_p32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _ptr],
     "deqsci_ffdnet_head_p32": [_ptr, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _int, _ptr],
     "deqsci_ffdnet_tail_p32": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr],
     "deqsci_conv3x3_c1_to_64_sp16": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _int, _ptr, _int, _ptr, _ptr],
@@ -404,12 +406,22 @@ def pack_c1_to_64_weights(w):
     return w.detach().float().reshape(16, 4, 9).permute(2, 0, 1).contiguous()
 
 
-def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False, out_rng=None, out_exp=None, track=None):
-    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True) with the
-    range (out_rng, out_exp); track: a range slot that receives max |output| (the measurement of the first f-call)."""
+def conv3x3_c1_to_64(x, w_packed, relu=True, out=None, sp16=False, out_rng=None, out_exp=None, track=None, p32=False):
+    """x (n,1,H,W) planar -> [relu](conv3x3(x, w, pad=1)) as a channels_last (n,64,H,W) activation, or as an Sp16 (sp16=True) / a P32
+    (p32=True: in front of conv3x3_c64_wino16 layers) with the range (out_rng, out_exp); track: a range slot that receives max |output|
+    (the measurement of the first f-call)."""
     n, c, H, W = x.shape
     if c != 1:
         raise DeqsciHipError(f"conv3x3_c1_to_64: (n,1,H,W) image required, got {tuple(x.shape)}")
+    if p32:
+        o = out if out is not None else P32.empty(n, H, W, x.device)
+        if not isinstance(o, P32) or (o.n, o.H, o.W) != (n, H, W):
+            raise DeqsciHipError("conv3x3_c1_to_64: out must be a P32 of the output's shape")
+        o.rng, o.exp = out_rng, SP16_DEFAULT_EXP if out_exp is None else int(out_exp)
+        with _dev(x):
+            _check(load().deqsci_conv3x3_c1_to_64_p32(_p(x, "x"), _p(w_packed, "w_packed"), o.t.data_ptr(), n, H, W, 1 if relu else 0,
+                                                      _rng(o.rng, n), o.exp, _rng(track, n), _stream()), "conv3x3_c1_to_64_p32")
+        return o
     if sp16:
         o = out if out is not None else Sp16.empty(n, H, W, x.device)
         o.rng, o.exp = out_rng, SP16_DEFAULT_EXP if out_exp is None else int(out_exp)
@@ -1070,15 +1082,17 @@ def ffdnet_head_p32(x, weights, sigma, out=None, in_rng=None, in_exp=SP16_DEFAUL
 
 
 def ffdnet_tail_p32(h, weights, out=None):
-    """tail_split16 (COUT = 4: FFDNet's last layer + pixel shuffle) reading a P32; `weights` = TailSplit16Weights(w)."""
+    """tail_split16 reading a P32: COUT = 4 (FFDNet's last layer + pixel shuffle) or 1 (a plain 64 -> 1 layer: SimpleCNN's last);
+    `weights` = TailSplit16Weights(w)."""
     _act_check(h, "ffdnet_tail_p32")
-    if not isinstance(weights, TailSplit16Weights) or weights.cout != 4:
-        raise DeqsciHipError("ffdnet_tail_p32: TailSplit16Weights of a (4,64,3,3) weight are required")
-    o = out if out is not None else torch.empty((h.n, 1, 2 * h.H, 2 * h.W), device=h.t.device, dtype=torch.float32)
+    if not isinstance(weights, TailSplit16Weights) or weights.cout not in (1, 4):
+        raise DeqsciHipError("ffdnet_tail_p32: TailSplit16Weights of a (4,64,3,3) or (1,64,3,3) weight are required")
+    shape = (h.n, 1, 2 * h.H, 2 * h.W) if weights.cout == 4 else (h.n, 1, h.H, h.W)
+    o = out if out is not None else torch.empty(shape, device=h.t.device, dtype=torch.float32)
     wp = weights.packed if weights.packed.device == h.t.device else weights.packed.to(h.t.device)
+    fn = load().deqsci_ffdnet_tail_p32 if weights.cout == 4 else load().deqsci_conv3x3_c64_to_1_p32
     with _dev(h.t):
-        _check(load().deqsci_ffdnet_tail_p32(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng, h.n), h.exp,
-                                             _stream()), "ffdnet_tail_p32")
+        _check(fn(h.t.data_ptr(), wp.data_ptr(), _p(o, "out"), h.n, h.H, h.W, weights.sw, _rng(h.rng, h.n), h.exp, _stream()), "tail_p32")
     return o
 
 

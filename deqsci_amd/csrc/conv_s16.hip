@@ -1224,6 +1224,11 @@ extern "C" int deqsci_ffdnet_tail_p32(const void* x_p32, const void* w_packed, f
     return tail_s16_impl<4, 1>(x_p32, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
 }
 
+extern "C" int deqsci_conv3x3_c64_to_1_p32(const void* x_p32, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
+                                           const float* in_amax, int in_exp, deqsci_stream_t stream) {
+    return tail_s16_impl<1, 1>(x_p32, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);
+}
+
 extern "C" int deqsci_conv3x3_c64_to_1_split16(const void* x_sp16, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W, int w_exp,
                                                const float* in_amax, int in_exp, deqsci_stream_t stream) {
     return tail_s16_impl<1>(x_sp16, w_packed, out, n, H, W, w_exp, in_amax, in_exp, stream);

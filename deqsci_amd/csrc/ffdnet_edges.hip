@@ -137,7 +137,8 @@ __global__ __launch_bounds__(TB) void edge_tail_kernel(const float* __restrict__
 // Same mapping as the FFDNet head below: 16 lanes per position x 4 output channels each, 9 x 4 weights in
 // registers, a 34 x 34 patch in LDS read by broadcast; the kernel is bound by its 256 B/position store.
 constexpr int H1_T = 32, H1_P = H1_T + 2, H1_PS = H1_P + 1;
-// OUT_SP16: the output as an sp16 activation holding 2^e y, e from the range (out_amax, out_exp) (common.hpp); `track` (may be NULL):
+// OUT_SP16: the output as an sp16 activation (1) or a p32 activation (2: the 16-byte pixels of csrc/conv_w16.hip, 2^e y unsplit, even / odd
+// columns of a 64-column block apart) holding 2^e y, e from the range (out_amax, out_exp) (common.hpp); `track` (may be NULL):
 // max |y| of the launch folded into *track - the range measurement of the first f-call
 template <int OUT_SP16>
 __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restrict__ x, const float* __restrict__ wq,
@@ -173,7 +174,13 @@ __global__ __launch_bounds__(TB) void conv_c1_to_64_kernel(const float* __restri
             if (relu) { acc.x = fmaxf(acc.x, 0.0f); acc.y = fmaxf(acc.y, 0.0f); acc.z = fmaxf(acc.z, 0.0f); acc.w = fmaxf(acc.w, 0.0f); }
             if (OUT_SP16) {
                 if (track) tmax = fmaxf(fmaxf(tmax, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));   // (uniform branch)
-                sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, acc, oscale, true);
+                if (OUT_SP16 == 2) {                            // plane cq = couts 4 cq .. 4 cq + 3
+                    const int64_t nbc = (W + 63) >> 6;
+                    st4(h + ((((((int64_t)n * 16 + cq) * H + r) * nbc + (c >> 6)) * 2 + (c & 1)) * 32 + ((c & 63) >> 1)) * 4,
+                        make_float4(acc.x * oscale, acc.y * oscale, acc.z * oscale, acc.w * oscale));
+                } else {
+                    sp16_store_quad(reinterpret_cast<char*>(h) + (int64_t)n * H * W * 256, (int64_t)H * W, (int64_t)r * W + c, cq, acc, oscale, true);
+                }
             } else st4(hn + ((int64_t)r * W + c) * 64 + 4 * cq, acc);
         }
     }
@@ -402,7 +409,8 @@ static int c1_to_64_impl(const float* x, const float* w_packed, float* h, int64_
     if (!aligned16(w_packed) || !aligned16(h)) return DEQSCI_ERR_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)ceil_div(W, H1_T), (unsigned)ceil_div(H, H1_T), (unsigned)n);
-    if (sp16) hipLaunchKernelGGL(conv_c1_to_64_kernel<1>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
+    if (sp16 == 2) hipLaunchKernelGGL(conv_c1_to_64_kernel<2>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
+    else if (sp16) hipLaunchKernelGGL(conv_c1_to_64_kernel<1>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
     else hipLaunchKernelGGL(conv_c1_to_64_kernel<0>, grid, dim3(TB), 0, st, x, w_packed, h, (int)H, (int)W, relu, out_amax, out_exp, track_amax);
     return launch_status();
 }
@@ -415,4 +423,9 @@ extern "C" int deqsci_conv3x3_c1_to_64_f32(const float* x, const float* w_packed
 extern "C" int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W,
                                             int relu, const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream) {
     return c1_to_64_impl(x, w_packed, static_cast<float*>(h_sp16), n, H, W, relu, 1, out_amax, out_exp, track_amax, stream);
+}
+
+extern "C" int deqsci_conv3x3_c1_to_64_p32(const float* x, const float* w_packed, void* h_p32, int64_t n, int64_t H, int64_t W,
+                                           int relu, const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream) {
+    return c1_to_64_impl(x, w_packed, static_cast<float*>(h_p32), n, H, W, relu, 2, out_amax, out_exp, track_amax, stream);
 }

@@ -69,7 +69,8 @@ class _Denoiser:
         self.net = net
         # stack_kernel: which kernel a stack launch of FFDNet's run runs - "w16" (default): the split-fp16 arithmetic under Winograd F(2,3) x
         # direct (csrc/conv_w16.hip: a third fewer matrix-core products, p32 activations between FFDNet's first and last layer); "s16": the
-        # split-fp16 direct convolution (csrc/conv_s16.hip).  The measuring f-call and runs shorter than STACK_MIN_LAYERS keep the direct kernel.
+        # split-fp16 direct convolution (csrc/conv_s16.hip).  The measuring f-call keeps the direct kernel; SimpleCNN's two middle layers (a run
+        # shorter than STACK_MIN_LAYERS) go out as single launches of the chosen kernel.
         if stack_kernel not in ("w16", "s16"):
             raise ValueError(f"stack_kernel={stack_kernel!r}: expected 'w16' or 's16'")
         self.stack_kernel = stack_kernel
@@ -176,6 +177,10 @@ class _Denoiser:
                 if tuple(layers[-1][0].shape) == (1, 64, 3, 3) and layers[-1][1] is None and not layers[-1][2]:
                     self.plain_tail_w = _hip.pack_c64_to_1_weights(layers[-1][0])
                     self.plain_tail_w16 = _hip.TailSplit16Weights(layers[-1][0])
+                if s16 and self.stack_kernel == "w16" and self.plain_head_w is not None and self.plain_tail_w16 is not None:
+                    for u in self.wino[1:-1]:                    # (the Winograd pack of the middle layers: here, never inside a capture)
+                        if u is not None:
+                            u.w16
             if (isinstance(net, FFDNet) and self.fused_edges and self.channels_last and layers[-1][1] is None
                     and not layers[-1][2] and tuple(layers[-1][0].shape) == (4, 64, 3, 3) and layers[-1][0].is_cuda):
                 # last layer + upsamplefeatures as one HIP stencil kernel (csrc/ffdnet_edges.hip)
@@ -399,6 +404,15 @@ class _Denoiser:
                     if first and sp and cal:
                         self._measured = True
                         _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=True, out_exp=0, track=self._slot(1))
+                    if (first and sp and not cal and self.stack_kernel == "w16" and self.plain_tail_w16 is not None
+                            and all(u is not None for u in self.wino[1:-1]) and self.ranges is not None):
+                        # the 64->64 layers on the split-fp16 Winograd kernel (csrc/conv_w16.hip: a third fewer matrix-core products), one
+                        # launch per layer (two layers: no run worth a stack launch), p32 activations from the first layer to the last; the
+                        # ranges are the ones the first f-call measured on the direct kernels below
+                        h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], p32=True, out_rng=self._slot(1))
+                        for i in range(1, len(self.fast) - 1):
+                            h = _hip.conv3x3_c64_wino16(h, self.wino[i].w16, self.fast[i][1], self.fast[i][2], out_rng=self._slot(i + 1))
+                        return _hip.ffdnet_tail_p32(h, self.plain_tail_w16).reshape(bsz, B, H, W), True
                     h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=sp, out_rng=self._slot(1) if sp else None) if first else x
                     if self.plain_tail_w is not None:
                         h = self._run_stack(h, skip_first=first, skip_last=True, native_out=sp)

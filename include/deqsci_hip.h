@@ -303,6 +303,11 @@ int deqsci_absmax_f32(const float* x, int64_t n, int64_t count, float* amax, deq
  *     instead of fp32 channels_last - no conversion pass in front of a run of split16 layers. */
 int deqsci_conv3x3_c1_to_64_sp16(const float* x, const float* w_packed, void* h_sp16, int64_t n, int64_t H, int64_t W, int relu,
                                  const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);
+/* ... and writing / reading p32 (in front of / behind a run of deqsci_conv3x3_c64_wino16 layers: SimpleCNN_models.py:43-45, 55-56). */
+int deqsci_conv3x3_c1_to_64_p32(const float* x, const float* w_packed, void* h_p32, int64_t n, int64_t H, int64_t W, int relu,
+                                const float* out_amax, int out_exp, float* track_amax, deqsci_stream_t stream);
+int deqsci_conv3x3_c64_to_1_p32(const void* x_p32, const void* w_packed, float* out, int64_t n, int64_t H, int64_t W,
+                                int w_exp, const float* in_amax, int in_exp, deqsci_stream_t stream);
 /* The denoisers' last layers (conv3x3 64 -> 4 + pixel shuffle / 64 -> 1, no bias) on the f16 matrix cores with the split-fp16 arithmetic of
  *     deqsci_conv3x3_c64_split16: the 9 taps ride in the matrix N dimension (column = COUT tap + cout), the per-tap products are summed from
  *     LDS.  w_packed: 2^w_exp w as [4 chunks][2 pieces][N tiles][64 lanes][8 halfs]; the input's range is (in_amax, in_exp); fp32 out. */
