@@ -331,6 +331,17 @@ __global__ __launch_bounds__(TB) void gram_round_kernel(const float* __restrict_
     __shared__ float red[TB / WAVE][MAXM];
     __shared__ int ep_s[MAXM], slot_s[MAXM];
     __shared__ __attribute__((aligned(16))) float tile[NF][RND_PITCH];
+    float4 pre[NF];
+    auto fetch = [&](int tl) {
+        const int64_t k = beg + (int64_t)tl * RND_TILE + 4 * t;
+        const bool in = k < N;                                  // (N % 4 == 0 on this path)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float4 v = ld4(Gs + (int64_t)j * N + (in ? k : 0));
+            pre[j] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
+        }
+    };
+    fetch(0);                                                   // (the first tile is on its way while the prediction below is formed)
     // ---- where each chain of each entry is when it gets here: (K4's sums of the blocks before this one) / 16
     const float* ps = partials + s * nchunks * PART_STRIDE;
     {
@@ -397,17 +408,6 @@ __global__ __launch_bounds__(TB) void gram_round_kernel(const float* __restrict_
     const int c = t >> 4, g = t & 15;                          // my chain, and which of its terms: i = g, g + 16, ...
     float* terms = ref_state + s * ref_stride + ref_terms(nchunks);
     const int tiles = (int)(chunk / RND_TILE);
-    float4 pre[NF];
-    auto fetch = [&](int tl) {
-        const int64_t k = beg + (int64_t)tl * RND_TILE + 4 * t;
-        const bool in = k < N;                                  // (N % 4 == 0 on this path)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const float4 v = ld4(Gs + (int64_t)j * N + (in ? k : 0));
-            pre[j] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
-        }
-    };
-    fetch(0);
     for (int tl = 0; tl < tiles; ++tl) {
         const int w0 = 4 * t + (t >> 2);
 #pragma unroll
@@ -504,6 +504,13 @@ __global__ __launch_bounds__(WAVE) void gram_chain_apply_kernel(const float* __r
     long long stampA = 0, stampB = 0;
     int n_group = 0, n_hit = 0, n_noslot = 0, n_miss = 0;
 #endif
+    // (K4's sums of this lane's four blocks - the fallback of the prediction below - are asked for together with the record window)
+    float avg4[WIN / WAVE];
+#pragma unroll
+    for (int r = 0; r < WIN / WAVE; ++r) {
+        const int bl = (WIN / WAVE) * lane + r;
+        avg4[r] = bl < nchunks ? partials[(s * nchunks + bl) * PART_STRIDE + j] * (1.0f / C16) : 0.0f;
+    }
     load_window(0);
 #ifdef DEQSCI_DIAG
     const long long stamp1 = __builtin_readcyclecounter();
@@ -527,7 +534,6 @@ __global__ __launch_bounds__(WAVE) void gram_chain_apply_kernel(const float* __r
     };
     if (small && nchunks <= WIN) {
         constexpr int PER = WIN / WAVE;                         // blocks per lane: 4 lane + r
-        const float* ps = partials + s * nchunks * PART_STRIDE;
         float contrib[PER], mag[PER];
         float mine = 0.0f;
 #pragma unroll
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(WAVE) void gram_chain_apply_kernel(const float* __r
                 const int code = code_s[bl];
                 const int q = code == REF_NONE ? 0 : (code >> 1) - ref_lo(code);
                 const int aa = rec_s[bl][q][1];
-                const float avg = ps[(int64_t)bl * PART_STRIDE + j] * (1.0f / C16);
+                const float avg = avg4[r];
                 if (code != REF_NONE && aa >= 0) {
                     const float u = ldexpf(1.0f, (code >> 1) - 23);
                     contrib[r] = (float)rec_s[bl][q][0] * u;
