@@ -6,7 +6,7 @@ once - and the x0-perturbation ensemble of tools/config2_ensemble.py is run on i
 reference's (21.434 exact Gram / 21.439 as it is) the build's -0.010 ... -0.015 dB is the denoiser's rounding noise; if it stays at the
 build's 21.42 the bias is elsewhere (GAP / mix fusion, fp64 Gram finish, BN folding) and has to be bisected.
 
-    python tools/config2_fp64_denoiser.py [seeds=50] [variants=fp64,fp64_gramf32,...]
+    python tools/config2_fp64_denoiser.py [seeds=50] [seed0=0] [variants=fp64,fp64_gramf32,...]
 
 Variants: fp64 (denoiser in float64, everything else as shipped); default (the shipped engine: for the same seeds, same box).
 Output: gpurun_out/config2_fp64_denoiser.json (per-run PSNRs, pooled mean +- SE, the reference ensembles beside them)."""
@@ -80,7 +80,7 @@ class Float64FFDNet(torch.nn.Module):
         return F.pixel_shuffle(h.permute(0, 3, 1, 2), 2).float()
 
 
-def ensemble(eng, n_seeds, log):
+def ensemble(eng, n_seeds, log, seed0=0):
     out = {}
     clip = [as_clip(c) for c in SCITestDataset(DATA) if "traffic" in as_clip(c)["file"]][0]
     Phi = clip["mask"].to("cuda")[None].contiguous()
@@ -90,7 +90,7 @@ def ensemble(eng, n_seeds, log):
         x0 = deqsci_amd.initial_point(y, Phi, None, None)
         ps = []
         t0 = time.time()
-        for seed in range(n_seeds):
+        for seed in range(seed0, seed0 + n_seeds):
             xs = x0 if seed == 0 else x0 * (1 + 1e-7 * torch.randn(x0.shape, generator=torch.Generator().manual_seed(seed))).to("cuda")
             ps.append(float(psnr(eng.reconstruct(y, Phi, initial_point=xs).clamp(0, 1).cpu().numpy()[0], gt)))
         out[f"traffic_cacti.mat:{fi}"] = ps
@@ -112,6 +112,7 @@ def reference(path):
 def main():
     args = dict(a.split("=", 1) for a in sys.argv[1:])
     n_seeds = int(args.get("seeds", 50))
+    seed0 = int(args.get("seed0", 0))                          # seeds seed0 .. seed0 + seeds - 1 (seed 0 = the unperturbed x0)
     variants = args.get("variants", "fp64,default").split(",")
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
     kw = dict(iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
@@ -121,6 +122,10 @@ def main():
             eng = DEQSCIEngine(Float64FFDNet(net), use_graph=False, **kw)
         elif v == "default":
             eng = DEQSCIEngine(net, **kw)
+        elif v == "default_s16":                               # round 4's denoiser kernels (the direct split-fp16 stack), exact Gram
+            eng = DEQSCIEngine(net, stack_kernel="s16", **kw)
+        elif v == "refarith_s16":                              # ... with the reference's Anderson arithmetic
+            eng = DEQSCIEngine(net, stack_kernel="s16", anderson_arith="reference", **kw)
         elif v == "fixed":                                     # the round-3 arithmetic: activation scales pinned at 2^8
             eng = DEQSCIEngine(net, act_range="fixed", **kw)
         elif v == "refarith":                                  # the reference's Anderson arithmetic (fp32 bmm Gram, fp32 LU) around the shipped denoiser
@@ -134,7 +139,7 @@ def main():
             eng = DEQSCIEngine(net, conv64=pol, conv64_f22_calls=int(k), **kw)
         else:
             eng = DEQSCIEngine(net, conv64=v, **kw)            # fast32 / f22 / f44 / s16
-        runs[v] = ensemble(eng, n_seeds, v)
+        runs[v] = ensemble(eng, n_seeds, v, seed0)
     refs = {"reference as it is (fp32 bmm Gram)": reference(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread.json")),
             "reference, exact Gram": reference(os.path.join(GOLDEN, "e2e_ffdnet_anderson_180_spread_gram64.json"))}
     summary = {}
