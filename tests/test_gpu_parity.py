@@ -1699,7 +1699,9 @@ def test_config2_ffdnet_anderson_180_all_measurements():
       * it DOES move with the precision of the Gram matrix: the reference's Anderson step emulated on the GPU around the same f - fp32
         torch.bmm Gram, fp32 LU - gives 21.430 +- 0.004 and the reference's per-measurement pattern (m2 at 21.53), the same code with a
         float64 Gram 21.408 / 21.412.  The reference's fp32 Gram error (~5e-6 at N = 2^19) is worth +0.02 dB at 180 iterations.
-    The build's default keeps the exact Gram (deviation 3), so its pooled mean is EXPECTED CONFIG2_GRAM_SHIFT below the reference's; the
+    DEQSCIEngine's own default keeps the exact Gram (deviation 3): around round 4's direct split-fp16 kernels its pooled mean sat CONFIG2_GRAM_SHIFT
+    below the reference's (21.417), around round 5's Winograd kernels it is 21.434 - the allowance stays, it is no longer used up
+    (DESIGN section 5, item 6); the
     engine's `anderson_arith="reference"` (the next test) reproduces the reference's.  Criteria, all computed from the ensembles:
       * six-measurement mean: no more than 3 SE above the reference's (either variant), no more than CONFIG2_GRAM_SHIFT + 3 SE below;
       * per chaotic measurement: median PSNR / residual inside the hull of both reference ensembles widened by 1.5 (+ 0.01 dB / 1 %), no run
