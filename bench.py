@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py - headline metric of BASELINE.json on MI355X: reconstructed frames/s at 256x256x8,
 180 DEQ (Anderson) iterations, FFDNet denoiser, plus the MFMA roofline of the dominant kernel (the
-denoiser's 64->64 layers: the split-fp16 direct convolution on the f16 matrix cores under the default policy - as the STACK launch,
-one launch of deqsci::s16::conv_s16_kernel<0, 0, 1> per 13 layers and slice of 32 images; --no-stack: one launch per layer), the HBM
-roofline of the fused Phi/Phi^T + GAP-update kernel, a parity spot check of the very configuration that is timed against
-the CPU oracle, and the reference algorithm timed on the host CPU.
+denoiser's 64->64 layers: split-fp16 arithmetic on the f16 matrix cores under Winograd F(2,3) along x nested in the direct sum along y - as
+the STACK launch, one launch of deqsci::w16::conv_w16_kernel<1> per 13 layers and slice of 32 images, csrc/conv_w16.hip; --stack-kernel s16:
+round 4's direct form, deqsci::s16::conv_s16_kernel<0, 0, 1>; --no-stack: one launch per layer), the HBM roofline of the fused
+Phi/Phi^T + GAP-update kernel, a parity spot check of the very configuration that is timed against the CPU oracle, the other
+configurations a reader asks about (one measurement per call, the shipped clips of BASELINE config 2 with their PSNR, the fp32-only policy,
+the exact-Gram arithmetic, one stream instead of two: `summary`, the LAST key of the line), and the reference algorithm timed on the host CPU.
 
     python bench.py --gpus N --steps K --warmup W          # N > 1: starts N rank processes itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -178,6 +180,41 @@ def hbm_stream_roofline(H, W, B, m, dev, bsz=64, sets=3, budget_s=1.5):
     return {"workload": f"bsz {bsz} at {H}x{W}x{B}, {sets} rotating buffer sets (working set >> 256 MiB Infinity Cache)", "kernels": out}
 
 
+def config2_shipped_clips(args, dev):
+    """BASELINE configs[1] on the data it names: the 3 shipped clips = 8 measurements through the build's evaluation harness
+    (deqsci_amd.harness.evaluate: upload, reconstruction, PSNR; file reading excluded) - one measurement per call (the reference's
+    schedule, training/sci_equilibrium_training.py:171-181) and a clip's measurements as one batch - with the average PSNR next to the
+    reference's own run and its perturbation band (tests/golden/e2e_ffdnet_anderson_180*.json; FFDNet + Anderson at 180 iterations is
+    chaotic on the traffic clip: the band, not the digit, is the comparison - DESIGN section 5)."""
+    from deqsci_amd import checkpoint
+    from deqsci_amd.cli import build_pipeline
+    from deqsci_amd.harness import SCITestDataset, evaluate
+    clips = list(SCITestDataset(os.path.join(ROOT, "data", "test_gray")))
+    _, deq = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), args.iters)
+    out = {"what": "the 8 shipped measurements (drop8 1, runner8 1, traffic 6) through harness.evaluate, FFDNet (net_gray.pth), Anderson, "
+                   f"and_maxiters={args.iters}; wall time of upload + reconstruction + PSNR"}
+    for name, batch in (("one_by_one", False), ("clip_batched", True)):
+        for _ in range(2):                                     # eager warm-up of every shape, then its hipGraph capture
+            evaluate(deq, clips, batch=batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        avg, _ = evaluate(deq, clips, batch=batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": 64 / dt, "unit": "frames/s", "avg_psnr_db": avg}
+    if args.iters == 180:
+        g = os.path.join(ROOT, "tests", "golden")
+        with open(os.path.join(g, "e2e_ffdnet_anderson_180.json")) as fh:
+            out["reference_avg_psnr_db"] = json.load(fh)["avg_psnr"]
+        bands = []
+        for f in ("e2e_ffdnet_anderson_180_spread.json", "e2e_ffdnet_anderson_180_spread_gram64.json"):
+            with open(os.path.join(g, f)) as fh:
+                d = json.load(fh)
+            bands += [d["avg_psnr_min"], d["avg_psnr_max"]]
+        out["reference_avg_psnr_band_db"] = [min(bands), max(bands)]     # 25 runs each: as it is and with an exact Gram, x0 (1 + 1e-7 randn)
+    return out
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,9 +248,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-slice-edges", action="store_true", help="FFDNet's first and last layer over the whole batch instead of slice by slice around the stack launches (A/B)")
     ap.add_argument("--stack-kernel", default="w16", choices=["w16", "s16"],
                     help="kernel of FFDNet's stack launches: w16 = split-fp16 under Winograd F(2,3) x direct (csrc/conv_w16.hip), s16 = split-fp16 direct (A/B)")
-    ap.add_argument("--anderson-arith", default="reference", choices=["reference", "float64", "reference-bmm"],
-                    help="arithmetic of Anderson's alpha: reference = fp32 Gram + fp32 LU as solvers/new_equilibrium_utils_yaping.py:177-180 (what the drop-in "
-                         "DEQFixedPoint runs); float64 = exactly accumulated Gram; reference-bmm = round 4's torch.bmm form (A/B)")
+    ap.add_argument("--anderson-arith", default="reference", choices=["reference", "float64"],
+                    help="arithmetic of Anderson's alpha: reference = fp32 Gram + fp32 LU as solvers/new_equilibrium_utils_yaping.py:177-180 (the default of "
+                         "every entry point); float64 = exactly accumulated Gram")
+    ap.add_argument("--groups", default="auto", choices=["auto", "1", "2"],
+                    help="auto / 2: a batch of at least two stack slices runs as two half batches on two streams, their f-calls issued alternately "
+                         "(DEQSCIEngine groups; bit-identical results); 1: one stream (A/B)")
     ap.add_argument("--no-stack", action="store_true", help="one launch per 64->64 layer even where a run of layers fits one launch (A/B at small batches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -248,6 +288,8 @@ def build_engine(args, dev, conv64=None, f22_calls="args", denoiser=None, **over
     if args.stack_kernel != "w16":
         kw["stack_kernel"] = args.stack_kernel
     kw["anderson_arith"] = args.anderson_arith
+    if args.groups != "auto":
+        kw["groups"] = int(args.groups)
     kw.update(over)
     eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=args.iters, tol=1e-5,
                        channels_last=False if args.no_channels_last else None, fused_epilogue=not args.no_fused_epilogue,
@@ -309,9 +351,12 @@ def run_rank(args):
         timing_on = [False]
         orig = _hip.anderson_mix_gap
 
+        mix_gap_bsz = [bsz]
+
         def timed_mix_gap(ws, beta, n, *a):
             if not timing_on[0] or n != eng.m:
                 return orig(ws, beta, n, *a)
+            mix_gap_bsz[0] = ws.bsz                            # (a grouped reconstruction launches it per half batch)
             return timer.mix_gap(ws, beta, n, *a)
         _hip.anderson_mix_gap = timed_mix_gap
 
@@ -389,7 +434,9 @@ def run_rank(args):
                    # reconstructions (warm-up included) whose stack launch timed out and were redone with a launch per layer: foreign work on the
                    # device's CUs (two ranks on one GPU provoke it); 0 on a device of one's own
                    "stack_timeouts": None if selftest else getattr(eng, "stack_timeouts_total", None),
-                   "anderson_arith": None if selftest else getattr(eng, "anderson_arith", None)},
+                   "anderson_arith": None if selftest else getattr(eng, "anderson_arith", None),
+                   # [lo, hi) measurements of the half batches a grouped step runs on two streams (None: one stream)
+                   "groups": info.get("groups")},
         "arithmetic": ("fp32 tensors, fp32 accumulation everywhere.  64->64 conv layers under conv64 policy 'fast' (default): products on the f16 matrix "
                        "cores from hi + lo fp16 pairs of the fp32 operands (22 significant bits each, three MFMAs per product, fp32 accumulation; the "
                        "power-of-two scale of every activation follows max |activation| measured on the device at the first f-call, so the path is "
@@ -414,7 +461,7 @@ def run_rank(args):
         ms = timer.durations_ms() if timing else []
         if ms:
             avg_s = 1e-3 * sum(ms) / len(ms)
-            nbytes = mix_gap_bytes(bsz, H, W, B, eng.m)
+            nbytes = mix_gap_bytes(mix_gap_bsz[0], H, W, B, eng.m)
             traffic = None
             for tname in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):   # rocprofv3 --pmc passes, tools/pmc_traffic.sh
                 tfile = os.path.join(ROOT, "profiles", tname)
@@ -422,14 +469,15 @@ def run_rank(args):
                     with open(tfile) as fh:
                         for rec in json.load(fh):
                             k = rec["kernels"].get(f"mix_gap_bhw_kernel<{B}>")
-                            if rec["bsz"] == bsz and rec["size"] == args.size and k:
+                            if rec["bsz"] == mix_gap_bsz[0] and rec["size"] == args.size and k:
                                 traffic = k["hbm_bytes_per_launch"]
             out["hbm_roofline"] = {"kernel": f"deqsci::mix_gap_bhw_kernel<{B}> (K7+K3: Anderson mix fused with the Phi/Phi^T GAP update), in the DEQ loop",
                                    "bound": "hbm", "achieved": nbytes / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": nbytes / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                                    "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e6 * avg_s, "launches_timed": len(ms),
-                                   "note": f"in-loop figure at bsz {bsz}: the kernel's {nbytes / 2**20:.0f} MiB working set sits partly in the "
-                                           "256 MiB Infinity Cache; hbm_stream_roofline is the same kernel on a working set far beyond it"}
+                                   "note": f"in-loop figure at bsz {mix_gap_bsz[0]} per launch: the kernel's {nbytes / 2**20:.0f} MiB working set sits partly in the "
+                                           "256 MiB Infinity Cache" + (", and in a grouped step the other half batch's kernels run beside it" if mix_gap_bsz[0] != bsz else "")
+                                           + "; hbm_stream_roofline is the same kernel alone on a working set far beyond the cache"}
         # "roofline" = the DOMINANT kernel of the step: the denoiser's 64->64 conv layers (13 launches per f-call), on the kernel that takes
         # the largest share of the step; any other 64->64 kernel that ran is reported under "roofline_other_kernels".
         # Algorithmic flops per launch = the MFMA flops the kernel's algorithm executes: split-fp16 direct
@@ -562,6 +610,19 @@ def run_rank(args):
                 e_ = build_engine(args, dev)
                 oc["config4_512x512x16"] = dict(short(e_, y4, Phi4, 2, 1), what="BASELINE configs[3]: 2 measurements of 512x512x16, FFDNet, 180 iterations")
                 del e_, y4, Phi4
+                if info.get("groups"):
+                    e_ = build_engine(args, dev, groups=1)
+                    oc["one_stream"] = dict(short(e_, y, Phi, M, 3), what="the same step with groups=1: the whole batch on one stream (rounds 1-5)")
+                    del e_
+                # the reference's schedule (training/sci_equilibrium_training.py:171-181): ONE measurement per call - a hipGraph replay of the
+                # whole reconstruction (the eager warm-up and the capture are the two calls in front of the warm-up step)
+                e_ = build_engine(args, dev)
+                st1 = make_step(e_, y[:1], Phi[:1], 1, distributed.GatherTimer())
+                st1()
+                st1()
+                oc["one_measurement_per_call"] = dict(short(e_, y[:1], Phi[:1], 1, 3), launch_mode="hipGraph replay" if (e_.last_info or {}).get("graph") else "eager")
+                del e_, st1
+                oc["config2_shipped_clips"] = config2_shipped_clips(args, dev)
                 out["other_configs"] = oc
             if not args.no_hbm_stream:
                 del y, Phi
@@ -570,6 +631,32 @@ def run_rank(args):
                 out["parity_spot_check"] = parity_spot_check(args, dev, H, W, B)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_iters, f_calls, H, W, B, args.denoiser)
+            # the numbers a reader asks for next to the headline, as scalars: in `config` (which record keepers parse whole) and once more as
+            # the LAST key of the line (which survives a tail cut).  frames/s unless named otherwise; all on this box, outside the timed region
+            oc, op = out.get("other_configs", {}), out.get("other_conv64_policies", {})
+            c2 = oc.get("config2_shipped_clips", {})
+            summary = {
+                "headline_frames_per_s": round(value, 2),
+                "one_stream_groups_1": round(oc["one_stream"]["value"], 2) if "one_stream" in oc else None,
+                "exact_gram_float64" if eng.anderson_arith == "reference" else "reference_gram": round(oc["other_anderson_arith"]["value"], 2) if "other_anderson_arith" in oc else None,
+                "with_the_references_dead_182nd_f_call": round(oc["value_at_reference_f_calls"]["value"], 2) if "value_at_reference_f_calls" in oc else None,
+                "fp32_mfma_only_policy_fast32": round(op["fast32"]["value"], 2) if "fast32" in op else None,
+                "one_measurement_per_call": round(oc["one_measurement_per_call"]["value"], 2) if "one_measurement_per_call" in oc else None,
+                "config2_shipped_clips_one_by_one": round(c2["one_by_one"]["value"], 2) if c2 else None,
+                "config2_shipped_clips_clip_batched": round(c2["clip_batched"]["value"], 2) if c2 else None,
+                "config2_avg_psnr_db": round(c2["one_by_one"]["avg_psnr_db"], 4) if c2 else None,
+                "config2_reference_avg_psnr_db": round(c2["reference_avg_psnr_db"], 4) if c2.get("reference_avg_psnr_db") else None,
+                "config2_reference_avg_psnr_band_db": [round(v, 4) for v in c2["reference_avg_psnr_band_db"]] if c2.get("reference_avg_psnr_band_db") else None,
+                "config5_simplecnn": round(oc["config5_simplecnn"]["value"], 2) if "config5_simplecnn" in oc else None,
+                "config4_512x512x16": round(oc["config4_512x512x16"]["value"], 2) if "config4_512x512x16" in oc else None,
+                "stack_launch_us": round(out["roofline"]["avg_launch_us"], 1) if "avg_launch_us" in out.get("roofline", {}) else None,
+                "roofline_frac_useful": round(out["roofline"]["frac_useful"], 4) if "frac_useful" in out.get("roofline", {}) else None,
+                "hbm_stream_frac_K3": round(next(iter(out["hbm_stream_roofline"]["kernels"].values()))["frac"], 3) if "hbm_stream_roofline" in out else None,
+                "parity_spot_check_rel_l2": out.get("parity_spot_check", {}).get("rel_l2"),
+            }
+            summary = {k: v for k, v in summary.items() if v is not None}
+            out["config"]["summary"] = summary
+            out["summary"] = summary
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -52,6 +52,10 @@
 #define W16_PRIO 0          // (A/B) issue priority of the two waves of a SIMD (w, w + 4): 0 = left to the arbiter (the older wave, 0-3, wins), 1 = waves 4-7
                             // at s_setprio 1 throughout, 2 = the winner alternates half-stage by half-stage, 3 = group by group
 #endif
+#ifndef W16_DMA4
+#define W16_DMA4 0          // (A/B) 1: waves 0-3 - the older wave of every SIMD, which the arbiter serves first and which then waits ~1300 cycles per
+                            // half-stage at the barrier for its partner - issue ALL the LDS-DMA instructions (two per slot), waves 4-7 none
+#endif
 #ifndef W16_ABL
 #define W16_ABL 0     // timing ablations only (results wrong): 1 = no DMA inside the half-stages, 2 = no transform, 4 = no epilogue, 8 = epilogue without its stores
 #endif
@@ -133,6 +137,15 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     const int64_t HW = (int64_t)H * Wq;                        // pixels of a plane
     const int pl = lane & 31, kb = lane >> 5;
     const bool six = wave < RAW_TOTAL - 8 * (RAW_INSTR - 1);   // (uniform) this wave issues a sixth halo-tile instruction
+    const bool mover = !W16_DMA4 || wave < 4;                  // (uniform) this wave issues LDS-DMA instructions at all
+    // "everything but the halo tile issued last has landed": the instructions of one halo tile that may stay in flight (W16_DMA4: waves 0 and
+    // 1 issue 11 of the 42, waves 2 and 3 ten; the others have only stores in flight and keep the old count)
+    auto wait_all_but_a_tile = [&]() __attribute__((always_inline)) {
+        if (W16_DMA4 && wave < 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RAW_INSTR - 1) : "memory");
+        else if (W16_DMA4 && wave < 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RAW_INSTR - 2) : "memory");
+        else if (six) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR - 1) : "memory");
+    };
 
     // ---- halo tile by LDS-DMA: slot s = 64 (8 j + wave) + lane of the chunk tile is plane p = s / 660, row (s % 660) / 66, and inside the
     // row the EVEN columns first (33), then the odd ones: lane-linear in LDS, a per-lane byte offset on the global side.
@@ -149,10 +162,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         ft_py0 = OUT_ROWS * by - 1;
         ft_px0 = OUT_COLS * bx - 1;
     };
-    auto fetch_lane_offset = [&](int j) __attribute__((always_inline)) -> uint32_t {
+    auto fetch_lane_offset = [&](int j) __attribute__((always_inline)) -> uint32_t {       // (W16_DMA4: j = 2 x slot + which of its two instructions)
         int w_ = wave;
         asm volatile("" : "+s"(w_));                           // (recomputed at every use: once per tile and instruction)
-        const int s = 64 * (8 * j + w_) + lane;
+        const int s = W16_DMA4 ? 64 * (8 * (j >> 1) + w_ + 4 * (j & 1)) + lane : 64 * (8 * j + w_) + lane;
         const int p = (s * 6356) >> 22;                        // s / 660 for s < 2816
         const int q = s - p * RAW_PIX;
         const int row = (q * 993) >> 16, rem = q - row * RAW_COLS;           // q / 66 for q < 660
@@ -165,14 +178,35 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     };
     // the lane offsets of the tile whose chunks are being fetched live in LDS (registers the accumulators need): written once per tile,
     // read one DMA instruction ahead
-    uint32_t vo_next = 0;
-    auto voff_set = [&](int j, uint32_t v) __attribute__((always_inline)) { voff_s[j * TBW + (int)threadIdx.x] = v; };
-    auto voff_get = [&](int j) __attribute__((always_inline)) { vo_next = voff_s[j * TBW + (int)threadIdx.x]; };
+    uint32_t vo_next = 0, vo_next1 = 0;
+    auto voff_set = [&](int j, uint32_t v) __attribute__((always_inline)) {
+        if (W16_DMA4) voff_s[j * (TBW / 2) + (int)(threadIdx.x & (TBW / 2 - 1))] = v;
+        else voff_s[j * TBW + (int)threadIdx.x] = v;
+    };
+    auto voff_get = [&](int j) __attribute__((always_inline)) {
+        if (W16_DMA4) {
+            vo_next = voff_s[(2 * j) * (TBW / 2) + (int)(threadIdx.x & (TBW / 2 - 1))];
+            vo_next1 = voff_s[(2 * j + 1) * (TBW / 2) + (int)(threadIdx.x & (TBW / 2 - 1))];
+        } else vo_next = voff_s[j * TBW + (int)threadIdx.x];
+    };
     const uint32_t raw_lds = (uint32_t)(uintptr_t)(lds_char*)Raw, wt_lds = (uint32_t)(uintptr_t)(lds_char*)Wt;
     auto raw_piece = [&](int c, int buf, int j) __attribute__((always_inline)) {
         int w_ = wave;
         asm volatile("" : "+s"(w_));
         const uint32_t soff = uniform((uint32_t)c * (uint32_t)HW * 64u);                               // 4 planes of 16 HW bytes per chunk
+        if (W16_DMA4) {                                        // instructions 8 j + w and 8 j + w + 4, waves 0-3 only
+            const uint32_t vo[2] = {vo_next, vo_next1};
+            if (j + 1 < RAW_INSTR) voff_get(j + 1);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int I = 8 * j + w_ + 4 * p;
+                if (I >= RAW_TOTAL) continue;                  // (uniform)
+                const uint32_t m0p = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + I * 1024));
+                if (STACK) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc1 lds" ::"s"(m0p), "v"(vo[p]), "s"(rsrc), "s"(soff) : "m0");
+                else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0p), "v"(vo[p]), "s"(rsrc), "s"(soff) : "m0");
+            }
+            return;
+        }
         const uint32_t m0v = uniform(raw_lds + (uint32_t)(buf * RAW_BUF + (8 * j + w_) * 1024));
         const uint32_t voj = vo_next;                          // (voff_get(j) ran a gap ago)
         if (j + 1 < RAW_INSTR) voff_get(j + 1);
@@ -184,7 +218,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     auto w_piece = [&](const char* Wl, int hs, int buf, int j) __attribute__((always_inline)) {
         int w_ = wave;
         asm volatile("" : "+s"(w_));
-        const uint32_t off = (uint32_t)((W_INSTR * w_ + j) * 1024);
+        const uint32_t off = (uint32_t)(((W16_DMA4 ? 2 * W_INSTR : W_INSTR) * w_ + j) * 1024);        // (W16_DMA4: j = 0 .. 5, waves 0-3)
         const uint64_t g = (uint64_t)(Wl + (int64_t)hs * W_HALF) + off;
         const uint32_t m0v = uniform(wt_lds + (uint32_t)(buf * W_HALF) + off);
         const uint64_t gs = ((uint64_t)uniform((uint32_t)(g >> 32)) << 32) | uniform((uint32_t)g);
@@ -310,9 +344,13 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         // DMA instruction k of the half-stage (group 2 only): the weights of half-stage hs + 2 (wnext: there is one; the next tile's come from
         // s3_w, its layer's), then - h = 1 - the halo tile (rnext: there is one and the tiles it reads are written)
         auto dma = [&](int k) __attribute__((always_inline)) {
-            if (W16_ABL & 1) return;
-            if (k < W_INSTR) { if (wnext) w_piece((STACK && hs >= 6) ? s3_w : Wp, (hs + 2) & 7, wb, k); }
-            else if (h == 1 && k < W_INSTR + RAW_INSTR) { if (rnext) raw_piece((c + 2) & 3, c & 1, k - W_INSTR); }
+            if ((W16_ABL & 1) || !mover) return;
+            if (k < W_INSTR) {
+                if (wnext) {
+                    if (W16_DMA4) { w_piece((STACK && hs >= 6) ? s3_w : Wp, (hs + 2) & 7, wb, 2 * k); w_piece((STACK && hs >= 6) ? s3_w : Wp, (hs + 2) & 7, wb, 2 * k + 1); }
+                    else w_piece((STACK && hs >= 6) ? s3_w : Wp, (hs + 2) & 7, wb, k);
+                }
+            } else if (h == 1 && k < W_INSTR + RAW_INSTR) { if (rnext) raw_piece((c + 2) & 3, c & 1, k - W_INSTR); }
         };
         const f32x16 zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (W16_PRIO == 2) { if (((wave >> 2) ^ hs) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
@@ -324,10 +362,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
                 W16_MARK(h);
                 // what the successor reads has to be there: its weights (issued a half-stage ago) and - h = 1 - its halo chunk (two ago); a halo
                 // tile issued behind the weights in the half-stage before has another half-stage to land
-                if (h == 0 && raw_prev && !(W16_ABL & 1)) {
-                    if (six) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR - 1) : "memory");
-                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (h == 0 && raw_prev && !(W16_ABL & 1)) wait_all_but_a_tile();
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 W16_MARK(2 + h);
                 before_barrier();
                 lds_barrier();
@@ -347,7 +383,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
                 if (i >= 4 && i < 8) loadA(dy < 2 ? wb : wb ^ 1, dy < 2 ? dy + 1 : 0, 1, ((i - 4) >> 1) & 1, (i - 4) & 1);
                 if (i >= 8) loadA(dy < 2 ? wb : wb ^ 1, dy < 2 ? dy + 1 : 0, 0, ((i - 8) >> 1) & 1, (i - 8) & 1);
                 if (dy == 2) {
-                    if (h == 1 && i == 0 && rnext) voff_get(0);
+                    if (h == 1 && i == 0 && rnext && mover) voff_get(0);
                     if (i >= 1 && i <= 3) dma(i - 1);                  // weights
                     if (i >= 4 && i <= 9) dma(i - 1);                  // halo tile (h = 1)
                 }
@@ -361,14 +397,15 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     // what a tile starts from when nothing was fetched ahead (prologue, slow path): its first two halo chunks (2 x (6 | 5) instructions), the
     // first row's transform, the first group's weight fragments
     auto fetch_two_chunks_and_wait = [&]() __attribute__((always_inline)) {
-        voff_get(0);
+        if (mover) {
+            voff_get(0);
 #pragma unroll
-        for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j);
-        voff_get(0);
+            for (int j = 0; j < RAW_INSTR; ++j) raw_piece(0, 0, j);
+            voff_get(0);
 #pragma unroll
-        for (int j = 0; j < RAW_INSTR; ++j) raw_piece(1, 1, j);
-        if (six) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR - 1) : "memory");
+            for (int j = 0; j < RAW_INSTR; ++j) raw_piece(1, 1, j);
+        }
+        wait_all_but_a_tile();
     };
     auto first_row_and_fragments = [&]() __attribute__((always_inline)) {
         t_row(0, 0, 0, 0);
@@ -399,12 +436,14 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     if (wave == 0) bias_s[lane] = bias ? bias[lane] : 0.0f;
 #endif
     fetch_tile_uniform(t_first, x);
+    if (mover) {
 #pragma unroll
-    for (int j = 0; j < RAW_INSTR; ++j) voff_set(j, fetch_lane_offset(j));
+        for (int j = 0; j < (W16_DMA4 ? 2 : 1) * RAW_INSTR; ++j) voff_set(j, fetch_lane_offset(j));
 #pragma unroll
-    for (int j = 0; j < W_INSTR; ++j) w_piece(Wp, 0, 0, j);
+        for (int j = 0; j < (W16_DMA4 ? 2 : 1) * W_INSTR; ++j) w_piece(Wp, 0, 0, j);
 #pragma unroll
-    for (int j = 0; j < W_INSTR; ++j) w_piece(Wp, 1, 1, j);
+        for (int j = 0; j < (W16_DMA4 ? 2 : 1) * W_INSTR; ++j) w_piece(Wp, 1, 1, j);
+    }
     fetch_two_chunks_and_wait();
     __syncthreads();
     first_row_and_fragments();
@@ -477,7 +516,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
             }
         }, [&](int m) __attribute__((always_inline)) {
             if (m == 1 && next) fetch_tile_uniform(t_next, (STACK && new_layer) ? y : x);
-            if (m >= 2 && m < 2 + 2 * RAW_INSTR && !(m & 1) && next) voff_set((m - 2) >> 1, fetch_lane_offset((m - 2) >> 1));
+            if (W16_DMA4) { if (m >= 2 && m < 2 + 2 * RAW_INSTR && next && mover) voff_set(m - 2, fetch_lane_offset(m - 2)); }
+            else if (m >= 2 && m < 2 + 2 * RAW_INSTR && !(m & 1) && next) voff_set((m - 2) >> 1, fetch_lane_offset((m - 2) >> 1));
         });
         bool ready = true;
         if (STACK) {
@@ -517,10 +557,8 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         }
         // the next tile's second weight half (issued in half-stage 7's last group, in front of a halo tile that may still fly) has to be there
         // before a store goes out behind it: vmcnt counts loads and stores alike
-        if (rn && !(W16_ABL & 1)) {
-            if (six) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_INSTR - 1) : "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rn && !(W16_ABL & 1)) wait_all_but_a_tile();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         W16_MARK(5);
         if (STACK) {
             const unsigned done_v = fbase + (unsigned)(L + 1);

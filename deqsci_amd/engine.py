@@ -74,6 +74,7 @@ class _Denoiser:
         if stack_kernel not in ("w16", "s16"):
             raise ValueError(f"stack_kernel={stack_kernel!r}: expected 'w16' or 's16'")
         self.stack_kernel = stack_kernel
+        self.gate = None                                            # (_StackGate of a grouped reconstruction: one stack launch on the device at a time)
         self._wstacks = {}                                          # first layer of a run -> _hip.Wino16Stack
         # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch per slice of the batch
         # (_hip.conv3x3_c64_split16_stack: tiles synchronised by per-tile progress words instead of kernel boundaries, slices that keep
@@ -237,6 +238,21 @@ class _Denoiser:
         idx = list(range(1, len(self.fast) - 1))
         return idx if all(self.wino[i] is not None for i in idx) else None
 
+    def stack_slice(self, bsz, B, H, W, device):
+        """Images per stack launch when an f-call of this shape goes slice by slice - first layer -> the run of 64->64 layers as ONE stack
+        launch -> last layer (the branch of _run below; a calibrating call aside) - else None.  prepare() must have run."""
+        if self.tag != "ffdnet" or self.fast is None or self.head_w is None or self.tail_w is None or torch.device(device).type != "cuda":
+            return None
+        run = self._middle_run()
+        if (not self.stack or not self.slice_edges or run is None or len(run) < self.STACK_MIN_LAYERS or run[0] not in self._stacks
+                or self._stacks[run[0]].n_layers != len(run) or not all(u is not None for u in self.wino[1:-1])
+                or _hip.conv64_kernel_for(bsz * B, H // 2, W // 2, device, self.conv64) != "s16"):
+            return None
+        w16 = self.stack_kernel == "w16" and run[0] in self._wstacks and self._wstacks[run[0]].n_layers == len(run)
+        st = self._wstacks[run[0]] if w16 else self._stacks[run[0]]
+        return self.stack_per_launch or _hip.split16_stack_per_launch(bsz * B, H // 2, W // 2,
+                                                                      cus=torch.cuda.get_device_properties(device).multi_processor_count, tile=st.TILE)
+
     def stack_timed_out(self):
         """(host sync) whether a wait inside a stack launch gave up since the last call: its results are invalid."""
         return any([st.timed_out() for st in list(self._stacks.values()) + list(self._wstacks.values())])    # (every stack: the words are rearmed)
@@ -361,11 +377,19 @@ class _Denoiser:
                         out_rng = None if self.ranges is None else self._slot(1)[a:a + m]
                         if w16:
                             hs = _hip.ffdnet_head_p32(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
+                            if self.gate is not None:
+                                self.gate.acquire()
                             ys = _hip.conv3x3_c64_wino16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
+                            if self.gate is not None:
+                                self.gate.release()
                             _hip.ffdnet_tail_p32(ys, self.tail_w16, out=out[a:a + m])
                         else:
                             hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
+                            if self.gate is not None:
+                                self.gate.acquire()
                             ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
+                            if self.gate is not None:
+                                self.gate.release()
                             _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
                     self.stack_launches += 1
                     return out.reshape(bsz, B, H, W), True
@@ -433,27 +457,61 @@ class _StackTimeout(Exception):
     """A wait inside a stack launch gave up (seen behind the first stack f-call of an eager reconstruction)."""
 
 
+class _StackGate:
+    """One stack launch on the device at a time, whatever stream it is on.  The workgroups of a stack launch wait for one another, so all of
+    them have to be resident; two such launches dispatched side by side from two streams can each hold part of the CUs and starve the other
+    until the waits give up.  Every stack launch of a grouped reconstruction therefore waits (on the device: a stream-side event wait, the
+    host goes on) for the stack launch issued before it - a chain in issue order, no cycle."""
+
+    def __init__(self):
+        self.ev = None
+
+    def acquire(self):
+        if self.ev is not None:
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    def release(self):
+        self.ev = torch.cuda.Event()
+        self.ev.record()
+
+
 class DEQSCIEngine:
     GRAPH_AUTO_PIXELS = 4 * 256 * 256
     STACK_RETRY_CALLS = 16        # reconstructions on per-layer launches after a stack launch timed out, before the stack launch is tried again
 
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
-                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="float64",
-                 stack=True, stack_kernel="w16"):
+                 fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="reference",
+                 stack=True, stack_kernel="w16", groups="auto"):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
-        if anderson_arith not in ("float64", "reference", "reference-bmm"):
-            raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'float64', 'reference' or 'reference-bmm'")
-        # How alpha is computed.  "float64" (this class's default): the Gram row accumulated in float64 from the fp32 block partials of K4, the
-        # bordered system solved in float64 (K5+K6) - alpha to ~1e-8.  "reference" (what the drop-in DEQFixedPoint / andersonexp and bench.py
-        # pass): the reference's own arithmetic for that step, solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm over
-        # the N = H W B elements, fp32 LU - by the build's own kernels: the new Gram row in the summation ORDER of that GEMM on the CPU behind
-        # tests/golden (16 interleaved FMA chains per entry, csrc/anderson.hip; no GEMM library, capturable), the system formed and factorised
-        # in fp32 by K6 as sgesv does.  It exists because that order is not neutral on BASELINE config 2: a 2^15-step chain absorbs the many
-        # small products of the heavy-tailed residuals, the diagonal of the Gram matrix comes out 3-7e-6 too small, and that bias is what
-        # puts the reference's 180-iteration ensemble means where they are (DESIGN section 5, "Config 2").  Cost: +3 % of a step at eight
-        # measurements per call, +12 % at one.  "reference-bmm": round 4's form, the Gram as one rocBLAS torch.bmm (A/B only: +13 % / +65 %).
+        if not (groups == "auto" or (isinstance(groups, int) and 1 <= groups <= 2)):
+            raise ValueError(f"groups={groups!r}: expected 'auto', 1 or 2")
+        # groups: "auto" / 2 = a batch of at least two stack slices (FFDNet: 2 x 32 images = 8 measurements of 256 x 256 x 8) is reconstructed
+        # as TWO independent half batches, each on its own stream, their f-calls issued alternately (_reconstruct_grouped).  Measurements are
+        # independent problems and every kernel of the path is per measurement, so the result is bit-identical; what changes is what the
+        # device overlaps: a stack launch holds every CU, but the dozen short kernels around it (first / last layer, K4, the Gram kernels,
+        # the 6 x 6 solve, K7+K3 - latency- or HBM-bound, a sixth of an f-call) of one half now run beside the other half's.  1 = off.
+        self.groups = groups
+        self._ctor = dict(iterator=iterator, m=m, beta=beta, lam=lam, max_iter=max_iter, tol=tol, fold_bn=fold_bn, extra_call=extra_call,
+                          channels_last=channels_last, fused_epilogue=fused_epilogue, fused_edges=fused_edges, winograd=winograd, conv64=conv64,
+                          conv64_f22_calls=conv64_f22_calls, act_range=act_range, blk32=blk32, anderson_arith=anderson_arith, stack=stack,
+                          stack_kernel=stack_kernel)
+        self._net = denoiser
+        self._kids, self._gate, self._grouped = None, None, False
+        if anderson_arith not in ("float64", "reference"):
+            raise ValueError(f"anderson_arith={anderson_arith!r}: expected 'reference' or 'float64'")
+        # How alpha is computed.  "reference" (the default of every entry point: this class, the drop-in DEQFixedPoint / andersonexp, the CLI,
+        # bench.py): the reference's own arithmetic for that step, solvers/new_equilibrium_utils_yaping.py:177-180 - G G^T as ONE fp32 torch.bmm
+        # over the N = H W B elements, fp32 LU - by the build's own kernels: the new Gram row in the summation ORDER of that GEMM on the CPU
+        # behind tests/golden (MKL sgemm on the build host's AVX-512 CPU: 16 interleaved FMA chains per entry, csrc/anderson.hip; no GEMM
+        # library, capturable), the system formed and factorised in fp32 by K6 as sgesv does.  It exists because that order is not neutral on
+        # BASELINE config 2: a 2^15-step chain absorbs the many small products of the heavy-tailed residuals, the diagonal of the Gram matrix
+        # comes out 3-7e-6 too small, and that bias is what puts the reference's 180-iteration ensemble means where they are (DESIGN section
+        # 5, "Config 2").  Another BLAS build or CPU orders the sum differently: "the reference's fp32 Gram" is a property of the machine the
+        # reference ran on, and this is the build host's.  "float64": the Gram row accumulated in float64 from the fp32 block partials of K4,
+        # the bordered system solved in float64 (K5+K6) - alpha to ~1e-8, 2-4 % faster at eight measurements per call, ~10 % at one; every
+        # well-conditioned configuration is indifferent.  (Round 4's rocBLAS torch.bmm form lives in tools/config2_anderson_arith.py.)
         self.anderson_arith = anderson_arith
         if conv64 not in ("auto", "fast", "fast32", "f22", "f44", "s16"):
             raise ValueError(f"conv64={conv64!r}: expected 'auto', 'fast', 'fast32', 'f22', 'f44' or 's16'")
@@ -487,6 +545,7 @@ class DEQSCIEngine:
         # measurement-pixels (4 measurements of 256x256), i.e. when launch gaps are a visible share of the run
         self.use_graph = use_graph
         self._eager = True                # (False while a hipGraph capture records the launches: no host sync then)
+        self._early_check = True          # (False in the halves of a grouped reconstruction: the parent looks at the time-out words once, at the end)
         self._stack_wanted, self._stack_off_for, self.stack_timeouts_total = bool(stack), 0, 0
         self._ws = {}
         self._graph = None
@@ -509,7 +568,7 @@ class DEQSCIEngine:
     # ------------------------------------------------------------------ one f-call = GAP -> denoise -> store -> solve
     def _store_solve(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
         out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
-        if call == 1 and self._eager and self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
+        if call == 1 and self._eager and self._early_check and self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
             # the FIRST stack launch of the reconstruction: a wait that gave up (its workgroups were not all resident: somebody else holds CUs)
             # is seen here, one f-call in - not after 180 f-calls on invalid data.  One host sync per reconstruction (~0.1 ms of queue refill).
             raise _StackTimeout()
@@ -519,11 +578,7 @@ class DEQSCIEngine:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
         else:
             _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
-        gram32 = None
-        if self.anderson_arith == "reference-bmm" and n_solve > 0:
-            G = ws.G[:, :n_solve]                                                               # rows in the reference's slot order k % m
-            gram32 = torch.bmm(G, G.transpose(1, 2))                                            # :178, ONE fp32 GEMM over N elements (rocBLAS: ~200 us)
-        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, gram32=gram32, ref=ref)    # (+ lam I and the fp32 LU of :178-180 in K6)
+        _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, ref=ref)    # (+ lam I and the fp32 LU of :178-180 in K6)
 
     def _poll(self, ws, row):
         ws.host_res[row].copy_(ws.res[row], non_blocking=True)
@@ -546,8 +601,8 @@ class DEQSCIEngine:
             timed_out = 0
             try:
                 rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
-                if self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
-                    raise _StackTimeout()          # (a replayed hipGraph, or a wait that gave up later than the first stack f-call)
+                if self.den.stack and self.den.stack_launches and self._stack_timed_out():
+                    raise _StackTimeout()          # (a replayed hipGraph, a grouped call, or a wait that gave up later than the first stack f-call)
             except _StackTimeout:
                 # a stack launch waits for its own workgroups only - all resident when the device is ours.  A wait that gave up means it is
                 # not (another process holds CUs): that result is invalid; redo it with a launch per layer, and stay there for a while
@@ -555,7 +610,7 @@ class DEQSCIEngine:
                 warnings.warn("deqsci_amd: a wait inside a split-fp16 stack launch timed out (the device's CUs are shared with other work); "
                               f"redoing this call with one launch per layer and keeping that for the next {self.STACK_RETRY_CALLS} calls of this engine",
                               RuntimeWarning)
-                self.den.stack_timed_out()         # (rearm every stack's words)
+                self._stack_timed_out()            # (rearm every stack's words)
                 self.den.stack = False
                 self.den.stack_launches = 0
                 self._graph = None
@@ -583,8 +638,21 @@ class DEQSCIEngine:
             self.last_info["conv64_fallback"] = fallback
             # what the first f-call measured: max |activation| in front of every layer of the denoiser's stack, here the maximum over the
             # batch's images (the kernels use one range per image: den.ranges; 0 where no split-fp16 layer ran)
-            self.last_info["act_ranges"] = None if (self.den.ranges is None or fallback) else self.den.ranges.max(dim=1).values.tolist()
+            rng = self._all_ranges()
+            self.last_info["act_ranges"] = None if (rng is None or fallback) else rng.max(dim=1).values.tolist()
             return rec
+
+    def _stack_timed_out(self):
+        """(host sync) whether a wait inside a stack launch of this engine or of the halves of a grouped call gave up; rearms the words."""
+        dens = [self.den] + [k.den for k in (self._kids or [])]
+        return any([d.stack_timed_out() for d in dens])
+
+    def _all_ranges(self):
+        """(layers + 1, images) range slots of the last call (a grouped call: its halves' side by side)."""
+        if self._grouped and self._kids:
+            parts = [k.den.ranges for k in self._kids]
+            return None if any(p is None for p in parts) else torch.cat(parts, dim=1)
+        return self.den.ranges
 
     def _reconstruct(self, y, Phi, Phi_sum, initial_point):
         y = _hip.f32c(y)
@@ -599,9 +667,15 @@ class DEQSCIEngine:
             Phi_sum = None
         if initial_point is not None:
             initial_point = _hip.f32c(initial_point)
+        graph = self.use_graph if self.use_graph != "auto" else bsz * H * W <= self.GRAPH_AUTO_PIXELS
+        self._grouped = False
+        plan = None if graph else self._group_plan(bsz, H, W, B, y.device)
+        if plan is not None:
+            rec = self._reconstruct_grouped(plan, y, Phi4, Phi_sum, initial_point)
+            if rec is not None:
+                return rec
         ws = self._workspace(bsz, H, W, B, y.device)
         self.den.prepare(self.max_iter + 4, y.device, n_img=bsz * B)
-        graph = self.use_graph if self.use_graph != "auto" else bsz * H * W <= self.GRAPH_AUTO_PIXELS
         if graph:
             rec = self._replay(ws, y, Phi4, Phi_sum, initial_point)
             if rec is not None:
@@ -611,6 +685,106 @@ class DEQSCIEngine:
         r = ws.host_res[res_row]
         self.last_info = {"res": float(r[0]), "res_per_sample": r[1:].tolist(), "iterations": last,
                           "f_calls": call, "iterator": self.iterator, "graph": False}
+        self._warn_if_not_finite()
+        return rec
+
+    # ------------------------------------------------------------------ two half batches on two streams
+    def _group_plan(self, bsz, H, W, B, device):
+        """[(lo, hi), (lo, hi)]: the measurements of the two halves of a grouped reconstruction, or None (groups=1; a batch of less than two
+        stack slices; a denoiser whose f-call is not the sliced stack path).  A half is a whole number of stack slices."""
+        if self.groups == 1 or bsz < 2:
+            return None
+        self.den.prepare(self.max_iter + 4, device)
+        per = self.den.stack_slice(bsz, B, H, W, device)
+        if per is None or per % B or bsz * B < 2 * per:
+            return None
+        mps = per // B                                        # measurements per stack slice
+        first = (-(-(-(-bsz // mps)) // 2)) * mps             # ceil(slices / 2) slices
+        return [(0, first), (first, bsz)]
+
+    def _make_kids(self, n, device):
+        if self._kids is None or len(self._kids) != n or self._kids[0].stream.device != torch.device(device):
+            self._gate = _StackGate()
+            self._kids = []
+            for _ in range(n):
+                kid = DEQSCIEngine(self._net, use_graph=False, groups=1, poll_residual=False, **self._ctor)
+                kid.den.gate = self._gate
+                kid._early_check = False
+                kid.stream = torch.cuda.Stream(device=device)
+                self._kids.append(kid)
+        for kid in self._kids:                                # (what callers set on an engine after building it)
+            for name in ("m", "beta", "lam", "max_iter", "tol", "extra_call", "iterator", "anderson_arith", "conv64", "conv64_policy", "conv64_f22_calls"):
+                setattr(kid, name, getattr(self, name))
+            for name in ("stack", "stack_per_launch", "slice_edges", "f22_calls", "conv64", "stack_kernel", "blk32"):
+                setattr(kid.den, name, getattr(self.den, name))
+        return self._kids
+
+    def _reconstruct_grouped(self, plan, y, Phi4, Phi_sum, initial_point):
+        """The batch as independent half batches (plan), each on its own stream with its own workspace and activation buffers, their
+        f-calls issued alternately; the stack launches of the two streams are chained by events (_StackGate).  Bit-identical to the
+        one-stream path (every kernel of the path is per measurement).  The tolerance test of new_equilibrium_utils_yaping.py:184-186 is
+        over the WHOLE batch: the halves run max_iter iterations, and if any half's own residual ever fell below tol (then, and only then,
+        the whole batch's might have: sqrt(sum g) / (eps + sqrt(sum f)) >= tol whenever that holds for every half) the call is redone on
+        the one-stream path, which stops where the reference stops -> None.  Never on the reference's data."""
+        bsz, H, W = y.shape
+        B = Phi4.shape[3]
+        dev = y.device
+        kids = self._make_kids(len(plan), dev)
+        main = torch.cuda.current_stream()
+        gens, wss = [], []
+        try:
+            for kid, (lo, hi) in zip(kids, plan):
+                kid.stream.wait_stream(main)
+                with torch.cuda.stream(kid.stream):
+                    ws = kid._workspace(hi - lo, H, W, B, dev)
+                    kid.den.prepare(self.max_iter + 4, dev, n_img=(hi - lo) * B)
+                    kid.den.stack_launches = 0
+                    wss.append(ws)
+                    gens.append(kid._enqueue_steps(ws, y[lo:hi], Phi4 if Phi4.shape[0] == 1 else Phi4[lo:hi],
+                                                   None if Phi_sum is None else (Phi_sum if Phi_sum.shape[0] == 1 else Phi_sum[lo:hi]),
+                                                   None if initial_point is None else initial_point[lo:hi], False))
+            done = [None] * len(kids)
+            alive = list(range(len(kids)))
+            while alive:
+                for i in list(alive):
+                    with torch.cuda.stream(kids[i].stream):
+                        try:
+                            next(gens[i])
+                        except StopIteration as fin:
+                            done[i] = fin.value
+                            alive.remove(i)
+            rec = torch.empty((bsz, H, W, B), dtype=torch.float32, device=dev)
+            norms = []
+            for kid, ws, (lo, hi), (r, call, last, res_row) in zip(kids, wss, plan, done):
+                with torch.cuda.stream(kid.stream):
+                    ws.host_res.copy_(ws.res, non_blocking=True)
+                    norms.append(ws.gram[:(hi - lo) * 80].view(hi - lo, 80)[:, 64:66].to("cpu", non_blocking=True))     # |F_k|^2, |G_k|^2 of the last solve (fp64)
+                main.wait_stream(kid.stream)
+                rec[lo:hi].copy_(r)
+                r.record_stream(main)
+            main.synchronize()
+        except BaseException:
+            for g in gens:
+                g.close()
+            torch.cuda.synchronize(dev)
+            raise
+        _, call, last, res_row = done[0]
+        first = 2 if self.iterator == "anderson" else 1
+        for ws in wss:
+            if bool((ws.host_res[first:res_row, 0] < self.tol).any()):
+                return None
+        # the whole batch's residual of the last iteration, as K6's last block folds it: the samples' float64 norms added in sample order
+        sf = sg = 0.0
+        for nm in norms:
+            for k in range(nm.shape[0]):
+                sf += float(nm[k, 0])
+                sg += float(nm[k, 1])
+        eps = float(np.float32(1e-5 if self.iterator == "anderson" else 1e-7))     # (K6 takes eps as a float)
+        res = float(np.float32(math.sqrt(sg) / (eps + math.sqrt(sf))))
+        self._grouped = True
+        self.den.stack_launches += max(k.den.stack_launches for k in kids)
+        self.last_info = {"res": res, "res_per_sample": [v for ws in wss for v in ws.host_res[res_row, 1:].tolist()], "iterations": last,
+                          "f_calls": call, "iterator": self.iterator, "graph": False, "groups": [list(p) for p in plan]}
         self._warn_if_not_finite()
         return rec
 
@@ -629,6 +803,16 @@ class DEQSCIEngine:
     def _enqueue(self, ws, y, Phi4, Phi_sum, initial_point, poll):
         """Every launch of one reconstruction on the current stream.  poll: True = lagged residual read-back with early stop,
         False = one read-back at the end, None = no host traffic at all (what a hipGraph capture records)."""
+        steps = self._enqueue_steps(ws, y, Phi4, Phi_sum, initial_point, poll)
+        while True:
+            try:
+                next(steps)
+            except StopIteration as done:
+                return done.value
+
+    def _enqueue_steps(self, ws, y, Phi4, Phi_sum, initial_point, poll):
+        """_enqueue as a generator that yields behind every f-call (a grouped reconstruction issues the f-calls of its halves alternately);
+        returns what _enqueue returns."""
         self._eager = poll is not None
         phi = _hip.transpose(Phi4, LAYOUT_BHW)
         ps = Phi_sum if Phi_sum is not None else _hip.phi_sum(phi, LAYOUT_BHW)
@@ -637,9 +821,9 @@ class DEQSCIEngine:
         else:
             _hip.transpose(initial_point, LAYOUT_BHW, out=ws.xbuf[0])
         if self.iterator == "anderson":
-            x_last, call, last = self._anderson(ws, y, phi, ps, poll)
+            x_last, call, last = yield from self._anderson(ws, y, phi, ps, poll)
         else:
-            x_last, call, last = self._picard(ws, y, phi, ps, poll)
+            x_last, call, last = yield from self._picard(ws, y, phi, ps, poll)
         res_row = last
         # z = f(z*)  (new_equilibrium_utils_yaping.py:268)
         _hip.gap_update(x_last, phi, y, ps, LAYOUT_BHW, out=ws.z1)
@@ -648,6 +832,7 @@ class DEQSCIEngine:
         rec = _hip.residual_out(ws.z1, out, LAYOUT_HWB) if is_noise else _hip.transpose(out, LAYOUT_HWB)
         call += 1
         if self.extra_call:                                   # dead f0 = f(z) of :271-272
+            yield
             zt = _hip.transpose(rec, LAYOUT_BHW)
             _hip.gap_update(zt, phi, y, ps, LAYOUT_BHW, out=ws.z1)
             self.den.run(ws.z1, call)
@@ -706,8 +891,10 @@ class DEQSCIEngine:
         # f-calls 1, 2 fill slots 0, 1 (:162-163)
         _hip.gap_update(xb[0], phi, y, ps, LAYOUT_BHW, out=ws.z1)
         self._store_solve(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-5, 0)
+        yield
         _hip.gap_update(xb[1], phi, y, ps, LAYOUT_BHW, out=ws.z1)
         self._store_solve(ws, xb[1], 1, 1, 2, 2, None, 1e-5, 1)
+        yield
         if max_iter <= 2:
             raise UnboundLocalError("local variable 'res' referenced before assignment")      # :189 with the loop skipped
         last, prev_ev = None, None
@@ -718,6 +905,7 @@ class DEQSCIEngine:
             nf = min(k + 1, m)
             self._store_solve(ws, x, k, k % m, nf, nf, None, 1e-5, k)
             last = k
+            yield
             if poll:
                 ev = self._poll(ws, k)
                 if prev_ev is not None:
@@ -735,6 +923,7 @@ class DEQSCIEngine:
         xb = ws.xbuf
         _hip.gap_update(xb[0], phi, y, ps, LAYOUT_BHW, out=ws.z1)
         self._store_solve(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-7, 0)           # f0 = f(x0)
+        yield
         if self.max_iter <= 0:
             if poll is not None:
                 ws.host_res[0].copy_(ws.res[0], non_blocking=True)
@@ -745,6 +934,7 @@ class DEQSCIEngine:
             _hip.gap_update(x, phi, y, ps, LAYOUT_BHW, out=ws.z1)
             self._store_solve(ws, x, k + 1, 0, 1, 0, nxt, 1e-7, k + 1)
             last = k
+            yield
             if poll:
                 ev = self._poll(ws, k + 1)
                 if prev_ev is not None:

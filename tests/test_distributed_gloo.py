@@ -161,6 +161,36 @@ def test_bench_strong_scaling_mode_two_ranks():
     assert rec["allgather_bytes_per_step"] == 2 * 3 * 16 * 12 * 8 * 4
 
 
+def test_bench_config3_eight_ranks_global_batch_64():
+    """The only N > 1 the target machine has is 8, and BASELINE config 3 is 64 measurements over 8 GPUs: the launcher starting EIGHT ranks,
+    their rendezvous on one port, the shard bounds, the gather bytes and the reaping, end to end (gloo, stub engine, 8 CPU processes -
+    torch is imported eight times: slow, once)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing-selftest", "--global-batch", "64",
+                          "--size", "16x12x8", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "strong" and rec["config"]["global_batch"] == 64 and rec["config"]["batch_per_gpu"] == 8
+    assert rec["allgather_bytes_per_step"] == 64 * 16 * 12 * 8 * 4 and rec["allgather_ms_per_step"] > 0
+    d = rec["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 8 and [r["rank"] for r in d["ranks"]] == list(range(8))
+    assert [r["measurements"] for r in d["ranks"]] == [[8 * r, 8 * r + 8] for r in range(8)]
+    assert [r["local_rank"] for r in d["ranks"]] == list(range(8))
+    # weak scaling, the driver's default form at N = 8: 8 measurements per GPU = the same 64
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing-selftest", "--size", "16x12x8", "--steps", "1",
+                          "--warmup", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 64 and rec["config"]["batch_per_gpu"] == 8
+
+
 def test_bench_under_torch_distributed_run():
     """The driver's launch form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P
     bench.py --gpus 2 ...` - bench.py must then run as ONE rank of the existing job (no second launcher), rank 0 prints the one line."""

@@ -482,11 +482,21 @@ def test_engine_512x512x16_vs_oracle():
                                    gram_dtype=torch.float64, **kw)
     net = build_pipeline("SimpleCNN", checkpoint.shipped("cnn"), 6)[0].nonlinear_op
     for cl in (True, False):
-        eng = DEQSCIEngine(net, max_iter=6, channels_last=cl)
+        eng = DEQSCIEngine(net, max_iter=6, channels_last=cl, anderson_arith="float64")
         got = eng.reconstruct(G(y), G(Phi)).cpu().numpy()
         assert rel_l2(got, want64.numpy()) < 2e-5
         assert rel_l2(got, want32.numpy()) < 1e-3
         assert abs(eng.last_info["res"] - wres) < 2e-3 * wres and eng.last_info["f_calls"] == 7
+    # the default arithmetic - the reference's fp32 Gram in the summation order of the BUILD HOST's torch.bmm (chains of 2^18 steps here: a
+    # diagonal 2.7e-4 too small, tests/test_oracle_golden.py::test_gram_chain16_holds_at_other_shapes) - is as far from the exact Gram as the
+    # oracle's as-it-is run is; the two need not agree with each other more closely than that: `want32` is torch.bmm on the CPU of the machine
+    # this test runs on, which may order the sum differently (the GPU boxes' CPUs do: DESIGN section 5, item 5)
+    eng = DEQSCIEngine(net, max_iter=6)
+    assert eng.anderson_arith == "reference"
+    got_ref = eng.reconstruct(G(y), G(Phi)).cpu().numpy()
+    print("512x512x16 SimpleCNN@6: reference arithmetic vs the oracle as it is %.2e, vs the exact-Gram oracle %.2e (exact-Gram engine vs the oracle as it is: %.2e)"
+          % (rel_l2(got_ref, want32.numpy()), rel_l2(got_ref, want64.numpy()), rel_l2(got, want32.numpy())))
+    assert rel_l2(got_ref, want32.numpy()) < 1e-3 and 2e-5 < rel_l2(got_ref, want64.numpy()) < 1e-3
 
 
 def test_engine_is_deterministic_and_options():
@@ -1273,14 +1283,20 @@ def test_config3_synthetic_batch_vs_oracle():
     import bench
     y, Phi, _ = bench.make_batch(0, 3, 256, 256, 8, 1234, torch.device(DEV))
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 10)[0].nonlinear_op
-    seen = set()
-    _hip.CONV64_EVENT_HOOK = lambda k, n, h, w: seen.add((k, n))
+    seen = {}
+
+    def hook(k, n, h, w, layers=1):                            # (with the `layers` keyword: stack launches are reported too)
+        seen[(k, n, layers)] = seen.get((k, n, layers), 0) + 1
+    _hip.CONV64_EVENT_HOOK = hook
     try:
         eng = DEQSCIEngine(net, max_iter=10, use_graph=False)
         rec = eng.reconstruct(y, Phi)
     finally:
         _hip.CONV64_EVENT_HOOK = None
-    assert seen == {("s16", 24)} and eng.last_info["f_calls"] == 11 and 0 < eng.last_info["res"] < 1
+    # f-call 0 runs the direct kernel layer by layer (13 writing launches; its measuring launches are not reported); f-calls 1 .. 10 are ONE stack launch each
+    assert seen == {("s16", 24, 1): 13, ("w16stack", 24, 13): 10}, seen
+    assert eng.last_info["stack_launches"] == 10 and eng.last_info["stack_timeouts"] == 0
+    assert eng.last_info["f_calls"] == 11 and 0 < eng.last_info["res"] < 1
     yc, Pc = y.cpu(), Phi.cpu()
     for i in range(3):
         Ps = orc.phi_sum(Pc[i:i + 1])
@@ -1296,6 +1312,43 @@ def test_config3_synthetic_batch_vs_oracle():
     for i in range(3):
         one = DEQSCIEngine(net, max_iter=10, use_graph=False).reconstruct((y * sc)[i:i + 1].contiguous(), Phi[i:i + 1])
         assert torch.equal(one, mixed[i:i + 1])
+
+
+@pytest.mark.parametrize("anderson_arith,bsz,iterator", [("reference", 8, "anderson"), ("float64", 12, "anderson"), ("reference", 8, "picard")])
+def test_grouped_reconstruction_is_bit_identical_to_one_stream(anderson_arith, bsz, iterator):
+    """A batch of at least two stack slices (8 measurements of 256 x 256 x 8 = 2 x 32 images) is reconstructed as two half batches on two
+    streams, their f-calls issued alternately and their stack launches chained by events (DEQSCIEngine groups="auto",
+    _reconstruct_grouped): what the device overlaps changes, no result does - every kernel of the path is per measurement.  Held here:
+    the reconstruction, the residual of the whole batch (new_equilibrium_utils_yaping.py:184: folded from the samples' float64 norms in
+    sample order, as K6's last block does) and the per-sample residuals are BIT-identical to groups=1; a ragged split (12 measurements =
+    3 slices: 8 + 4) likewise; extra_call rides along; a second call through the same engine reuses the halves; and a batch of less
+    than two slices is not grouped."""
+    import bench
+    y, Phi, _ = bench.make_batch(0, bsz, 256, 256, 8, 1234, torch.device(DEV))
+    net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 9)[0].nonlinear_op
+    kw = dict(max_iter=9, use_graph=False, anderson_arith=anderson_arith, iterator=iterator, extra_call=(bsz == 12))
+    one = DEQSCIEngine(net, groups=1, **kw)
+    want = one.reconstruct(y, Phi)
+    assert "groups" not in one.last_info
+    two = DEQSCIEngine(net, **kw)
+    assert two.groups == "auto"
+    for rep in range(2):
+        got = two.reconstruct(y, Phi)
+        assert two.last_info["groups"] == ([[0, 4], [4, 8]] if bsz == 8 else [[0, 8], [8, 12]])
+        assert torch.equal(got, want)
+        for k in ("res", "res_per_sample", "iterations", "f_calls", "stack_timeouts"):
+            assert two.last_info[k] == one.last_info[k], (k, two.last_info[k], one.last_info[k])
+        assert two.last_info["stack_launches"] == one.last_info["stack_launches"] > 0
+        assert two.last_info["act_ranges"] == one.last_info["act_ranges"]
+    small = two.reconstruct(y[:5], Phi[:5])                    # 40 images: one slice of 32 + a remainder - not two slices
+    assert "groups" not in two.last_info and torch.equal(small, want[:5])
+    # a shared mask and a caller's Phi_sum / initial point go to both halves
+    if bsz == 8 and iterator == "anderson":
+        Ps = deqsci_amd.phi_sum(Phi[:1])
+        x0 = deqsci_amd.initial_point(y, Phi[:1].expand(bsz, -1, -1, -1).contiguous(), None, None)
+        a = two.reconstruct(y, Phi[:1], Phi_sum=Ps, initial_point=x0)
+        assert two.last_info["groups"] == [[0, 4], [4, 8]]
+        assert torch.equal(a, one.reconstruct(y, Phi[:1], Phi_sum=Ps, initial_point=x0))
 
 
 def test_ranges_are_measured_by_the_first_split16_call():
@@ -1699,7 +1752,7 @@ def test_config2_ffdnet_anderson_180_all_measurements():
       * it DOES move with the precision of the Gram matrix: the reference's Anderson step emulated on the GPU around the same f - fp32
         torch.bmm Gram, fp32 LU - gives 21.430 +- 0.004 and the reference's per-measurement pattern (m2 at 21.53), the same code with a
         float64 Gram 21.408 / 21.412.  The reference's fp32 Gram error (~5e-6 at N = 2^19) is worth +0.02 dB at 180 iterations.
-    DEQSCIEngine's own default keeps the exact Gram (deviation 3): around round 4's direct split-fp16 kernels its pooled mean sat CONFIG2_GRAM_SHIFT
+    `anderson_arith="float64"` (until round 6 DEQSCIEngine's own default) keeps the exact Gram (deviation 3): around round 4's direct split-fp16 kernels its pooled mean sat CONFIG2_GRAM_SHIFT
     below the reference's (21.417), around round 5's Winograd kernels it is 21.434 - the allowance stays, it is no longer used up
     (DESIGN section 5, item 6); the
     engine's `anderson_arith="reference"` (the next test) reproduces the reference's.  Criteria, all computed from the ensembles:
@@ -1713,7 +1766,8 @@ def test_config2_ffdnet_anderson_180_all_measurements():
         band (the residual of a run that has not converged to 1e-5 moves by 1-2 % under a 1e-7 perturbation on either side);
       * the harness average of the unperturbed run inside the hull of the two reference average bands."""
     solver, _ = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)
-    eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5)
+    assert DEQSCIEngine(solver.nonlinear_op).anderson_arith == "reference"       # (one default for every entry point, round 6: the next test's)
+    eng = DEQSCIEngine(solver.nonlinear_op, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5, anderson_arith="float64")
     assert eng.conv64 == "auto" and eng.conv64_f22_calls is None and eng.conv64_policy == "fast" and eng.anderson_arith == "float64"
     assert _hip.conv64_kernel_for(8, 128, 128, policy=eng.conv64_policy) == "s16"      # one measurement per call = 8 images of 128 x 128
     report, base_by_clip, (a, b) = _config2_ensembles(eng)
@@ -2027,7 +2081,7 @@ def test_engine_512x512x16_ffdnet_vs_oracle():
     f64 = orc.ProxGradSCI("ffdnet")
     want64, wres = orc.deq_forward(f64, orc.andersonexp, y, Phi, Ps, orc.initial_point(y, Phi), gram_dtype=torch.float64, **kw)
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 5)[0].nonlinear_op
-    eng = DEQSCIEngine(net, max_iter=5)
+    eng = DEQSCIEngine(net, max_iter=5, anderson_arith="float64")
     got = eng.reconstruct(G(y), G(Phi)).cpu().numpy()
     assert eng.last_info["f_calls"] == 6 and f64.calls == 7
     assert rel_l2(got, want64.numpy()) < 5e-5

@@ -185,6 +185,23 @@ def test_gram_chain16_is_the_summation_order_of_the_references_bmm():
         assert (np.abs(got.astype(np.float64) - live) <= np.spacing(np.abs(live))).all()
 
 
+@pytest.mark.parametrize("n,lg", [(5, 17), (8, 19), (2, 19), (3, 21), (5, 22)])
+def test_gram_chain16_holds_at_other_shapes(n, lg):
+    """the 16-chain order was pinned at n = 5, N = 2^19 only, and a BLAS may pick another kernel / K blocking for another shape.
+    On the CPU behind tests/golden it does not: torch.bmm of n x N by N x n for N = 2^17 ... 2^22 (512 x 512 x 16) and n = 2 ... 8 (m up to
+    DEQSCI_MAX_M) is the same sixteen interleaved chains - every entry within two ulps of the emulation, most bit-equal, with the diagonal bias
+    growing with the chain length as absorption predicts (3e-6 at 2^17, 2e-5 at 2^19, 2.7e-4 at 2^22 on these heavy-tailed rows).  The fixture
+    holds what torch.bmm returned there (tools/make_gram_golden.py); `"reference"` means THAT machine's order."""
+    g = np.load(os.path.join(GOLDEN, "gram_bmm_cpu_shapes.npz"))
+    G_ = orc.heavy_tailed_rows(seed=11 + n + lg, n=n, N=2 ** lg)
+    got, _ = orc.gram_chain16(G_)
+    bmm, exact = g[f"bmm_{n}_{lg}"], g[f"exact_{n}_{lg}"]
+    assert (np.abs(got.astype(np.float64) - bmm) <= 2 * np.spacing(np.abs(bmm))).all()
+    assert (got == bmm).sum() >= (n * n) // 4
+    np.testing.assert_allclose(np.diag((bmm - exact) / exact), np.diag((got.astype(np.float64) - exact) / exact), rtol=0.05, atol=3e-7)
+    assert (np.diag((got.astype(np.float64) - exact) / exact) < 0).all()
+
+
 def test_admm_variant_golden():
     g = np.load(os.path.join(GOLDEN, "admm_toy.npz"))
     Phi, y, Ps, x0, u0 = (T(g[k]) for k in ("Phi", "y", "Phi_sum", "x0", "u0"))

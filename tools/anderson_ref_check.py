@@ -130,7 +130,12 @@ def engine():
     want = gold["traffic_m0"]
     recs = {}
     for aa in ("float64", "reference", "reference-bmm"):
-        recs[aa] = DEQSCIEngine(net, max_iter=180, anderson_arith=aa).reconstruct(y, Phi).cpu().numpy()
+        if aa == "reference-bmm":
+            from reference_bmm import ReferenceBmmEngine       # (tools/reference_bmm.py)
+            eng = ReferenceBmmEngine(net, max_iter=180)
+        else:
+            eng = DEQSCIEngine(net, max_iter=180, anderson_arith=aa)
+        recs[aa] = eng.reconstruct(y, Phi).cpu().numpy()
 
     def rel(a, b):
         return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))

@@ -131,7 +131,8 @@ def main():
         elif v == "refarith":                                  # the reference's Anderson arithmetic (fp32 bmm Gram, fp32 LU) around the shipped denoiser
             eng = DEQSCIEngine(net, anderson_arith="reference", **kw)
         elif v == "refbmm":                                    # round 4's form of it: the Gram as one fp32 torch.bmm (rocBLAS)
-            eng = DEQSCIEngine(net, anderson_arith="reference-bmm", **kw)
+            from reference_bmm import ReferenceBmmEngine       # (tools/reference_bmm.py)
+            eng = ReferenceBmmEngine(net, **kw)
         elif v == "refarith_fp64":                             # ... around the float64 denoiser
             eng = DEQSCIEngine(Float64FFDNet(net), anderson_arith="reference", **kw)
         elif "+" in v:                                         # "fast+3": the first 3 f-calls on F(2x2,3x3), then the policy - a family of

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """WHICH fp32 rounding of the Gram matrix moves Anderson's alpha on the loop's own data (config 2: FFDNet + Anderson, traffic m2)?  The engine runs
-with round 4's form of the reference's arithmetic (anderson_arith="reference-bmm": G G^T as one fp32 torch.bmm, solvers/new_equilibrium_utils_yaping.py:178);
+with round 4's form of the reference's arithmetic (tools/reference_bmm.py, until round 6 the engine's anderson_arith="reference-bmm": G G^T as one fp32 torch.bmm, solvers/new_equilibrium_utils_yaping.py:178);
 every few iterations the residual history G (n x N, N = 2^19) is taken aside and its Gram matrix formed in float64 (exact on this scale), by that
 torch.bmm, and as flat fp32 chains along K over partials of 1 .. 4096 elements (numpy cumsum: sequential) - the candidates for a hand-written kernel -
 and the bordered system of :179-180 solved in fp32 for each.  Printed per sampled iteration: the relative error of the Gram entries and the
@@ -78,7 +78,8 @@ def main():
     clip = [as_clip(c) for c in SCITestDataset(os.path.join(ROOT, "data", "test_gray")) if "traffic" in as_clip(c)["file"]][0]
     Phi, y = clip["mask"][None].to("cuda"), clip["meas"][None, ..., fi].contiguous().to("cuda")
     net = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), 180)[0].nonlinear_op
-    eng = DEQSCIEngine(net, iterator="anderson", m=5, beta=1.0, lam=LAM, max_iter=180, tol=1e-5, anderson_arith="reference-bmm", use_graph=False)
+    from reference_bmm import ReferenceBmmEngine
+    eng = ReferenceBmmEngine(net, iterator="anderson", m=5, beta=1.0, lam=LAM, max_iter=180, tol=1e-5, use_graph=False)
     taken = []
     orig = _hip.anderson_solve
     count = [0]
