@@ -33,6 +33,9 @@ SIGNATURES = {
     "deqsci_anderson_solve_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
     "deqsci_anderson_solve_gram_f32": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr, _ptr],
     "deqsci_anderson_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_residual_store_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _ptr],
+    "deqsci_anderson_apply_solve_ref_f32": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _f32, _f32, _ptr],
+    "deqsci_gram_ref_fusable": [_i64, _i64],
     "deqsci_gram_row_chain16_f32": [_ptr, _ptr, _ptr, _i64, _i64, _int, _int, _int, _int, _ptr],
     "deqsci_anderson_mix_f32": [_ptr, _ptr, _ptr, _ptr, _f32, _int, _i64, _i64, _int, _ptr],
     "deqsci_anderson_mix_gap_f32": [_ptr, _ptr, _ptr, _f32, _int, _int, _ptr, _ptr, _ptr, _ptr, _ptr,
@@ -269,6 +272,8 @@ class AndersonWorkspace:
         self.alpha = torch.zeros((bsz, MAX_M), device=device, dtype=torch.float32)
         self.res = torch.zeros((res_rows, 1 + bsz), device=device, dtype=torch.float32)
         self.gram32 = None                # (anderson_arith = "reference": the persistent fp32 Gram of deqsci_anderson_solve_ref_f32, see gram32_state)
+        self.ref_fusable = bool(lib.deqsci_gram_ref_fusable(bsz, N))      # K4 can leave the records of the reference Gram's first pass itself
+        self._rounded = None              # (slot, n_filled) of a residual_store(ref=True) whose records await anderson_solve(ref=True)
 
     def ref_state(self):
         """The caller-owned state of deqsci_anderson_solve_ref_f32 (allocated and zeroed on first use): per sample the persistent fp32 Gram
@@ -293,7 +298,18 @@ class AndersonWorkspace:
         return st[:, MAX_M * MAX_M + 16 * MAX_M:MAX_M * MAX_M + 32 * MAX_M].view(torch.int32).view(self.bsz, MAX_M, 16)
 
 
-def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None):
+def residual_store(ws, z1, noise, x_cur, slot, n_filled, x_next=None, ref=False):
+    """ref: the caller will form alpha with anderson_solve(ref=True) next - where the shape allows (ws.ref_fusable) K4's blocks then also leave
+    the records of the reference Gram's first pass (deqsci_residual_store_ref_f32: the history rows are in their registers anyway), and
+    that anderson_solve skips the pass.  Same F / G / x_next / partials either way."""
+    ws._rounded = None
+    if ref and ws.ref_fusable:
+        with _dev(z1):
+            _check(load().deqsci_residual_store_ref_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
+                                                        _p(x_next, "x_next", True), _p(ws.partials), _p(ws.ref_state()), ws.bsz, ws.N, ws.m, slot,
+                                                        n_filled, _stream()), "residual_store_ref")
+        ws._rounded = (slot, n_filled)
+        return
     with _dev(z1):
         _check(load().deqsci_residual_store_f32(_p(z1, "z1"), _p(noise, "noise", True), _p(x_cur, "x_cur"), _p(ws.F), _p(ws.G),
                                                 _p(x_next, "x_next", True), _p(ws.partials), ws.bsz, ws.N, ws.m, slot,
@@ -304,6 +320,14 @@ def anderson_solve(ws, slot, n_filled, n, lam, eps, res_row=0, gram32=None, ref=
     """gram32: (bsz, n, n) fp32 - alpha from THAT Gram block with an fp32 LU (the reference's arithmetic, :177-180) instead of the float64 sums.
     ref: the same arithmetic without a GEMM library - the new Gram row summed by the build's own kernel in the order of the reference's torch.bmm
     (sixteen interleaved FMA chains per entry, csrc/anderson.hip gram_row_chain16_kernel) from the history residual_store just wrote."""
+    if ref and ws._rounded == (slot, n_filled):
+        ws._rounded = None
+        with _dev(ws.F):
+            _check(load().deqsci_anderson_apply_solve_ref_f32(_p(ws.G), _p(ws.partials), _p(ws.ref_state()), ws.gram.data_ptr(), _p(ws.alpha),
+                                                              _p(ws.res[res_row]), ws.bsz, ws.N, ws.m, slot, n_filled, n, float(lam), float(eps), _stream()),
+                   "anderson_apply_solve_ref")
+        return
+    ws._rounded = None
     if ref:
         with _dev(ws.F):
             _check(load().deqsci_anderson_solve_ref_f32(_p(ws.G), _p(ws.partials), _p(ws.ref_state()), ws.gram.data_ptr(), _p(ws.alpha),

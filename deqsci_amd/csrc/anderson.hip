@@ -216,7 +216,9 @@ constexpr int C16_TB = WAVE * (1 + C16_LOADERS);
 constexpr int REF_CSUM = MAXM * MAXM;
 constexpr int REF_WALKED = REF_CSUM + MAXM * C16;            // (diagnostic) blocks each chain was walked through in the last call
 constexpr int REF_TAKEN = REF_WALKED + MAXM * C16;           // per entry: term slots handed out in this call (zeroed again by gram_chain_apply_kernel)
-constexpr int REF_EP = REF_TAKEN + MAXM;
+constexpr int REF_CALL = REF_TAKEN + MAXM;                  // the number of reference-Gram calls finished on this state (gram_chain_apply_kernel counts): the tag of the
+                                                            // granules the blocks of residual_store_round_kernel publish to one another
+constexpr int REF_EP = REF_CALL + 2;
 constexpr int REF_NONE = -100000;                           // no prediction for this block (first block, zero or non-finite sums)
 __host__ __device__ constexpr int ref_lo(int code) { return (code >> 1) - 1 + (code & 1); }     // the lower of the two candidate binades
 constexpr int REF_CAND = 2;                                 // binades a block is rounded for: the predicted one and its nearer neighbour
@@ -224,7 +226,10 @@ constexpr int PF_TERMS = 128;                               // terms per chain o
 constexpr int TSLOTS = 96;                                  // blocks per entry whose terms gram_round_kernel also stores chain by chain (see there)
 __host__ __device__ constexpr int64_t ref_rec(int64_t nchunks) { return REF_EP + nchunks * MAXM; }
 __host__ __device__ constexpr int64_t ref_slot(int64_t nchunks) { return ref_rec(nchunks) + nchunks * MAXM * C16 * REF_CAND * 2; }
-__host__ __device__ constexpr int64_t ref_terms(int64_t nchunks) { return (ref_slot(nchunks) + nchunks * MAXM + 3) / 4 * 4; }
+// (round 6) per K4 block and entry one 8-byte granule {block sum of K4, call number}: how the blocks of the fused K4 + rounding launch tell
+// one another where the chains stand (residual_store_round_kernel)
+__host__ __device__ constexpr int64_t ref_pub(int64_t nchunks) { return (ref_slot(nchunks) + nchunks * MAXM + 3) / 4 * 4; }
+__host__ __device__ constexpr int64_t ref_terms(int64_t nchunks) { return (ref_pub(nchunks) + nchunks * MAXM * 2 + 3) / 4 * 4; }
 __host__ __device__ constexpr int64_t ref_words(int64_t nchunks) { return ref_terms(nchunks) + (int64_t)MAXM * TSLOTS * C16 * PF_TERMS * 2; }
 
 __global__ __launch_bounds__(C16_TB) void gram_row_chain16_kernel(const float* __restrict__ G_hist, float* __restrict__ ref_state, int64_t ref_stride,
@@ -450,6 +455,220 @@ __global__ __launch_bounds__(TB) void gram_round_kernel(const float* __restrict_
                 int* r2 = rec + ((((int64_t)b * MAXM + j) * C16 + c) * REF_CAND + q) * 2;
                 r2[0] = (int)nn;
                 r2[1] = (oo >> 22) ? -1 : (int)aa;              // (a term of 2^22 ulps or more, a tie: not for the fast path)
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 AND the rounding pass in one launch (round 6)
+// ------------------------------------------------------------------------------------------------
+// gram_round_kernel re-reads the NF history rows K4 has just had in its registers, because the binade a block rounds for comes from K4's sums of
+// the blocks BEFORE it.  Here K4's blocks tell one another: a block publishes its NF dot products as 8-byte granules {sum, call number} (one
+// agent-scope store each: value and tag arrive together; the call number is a word of the state that gram_chain_apply_kernel advances when it is
+// done with the call - nothing to reset, a replayed hipGraph counts on), then reads its predecessors' granules (agent-scope 16-byte loads, two
+// granules each, every granule checked by its own tag and re-asked until the tag is this call's).  The wait is BOUNDED and nothing depends on
+// it but speed: the prediction only decides how many blocks gram_chain_apply_kernel walks (a record for the wrong binade is never used), so a
+// block whose predecessors have not reported in time - they run beside it or have finished whenever workgroups are dispatched in index order,
+// which HIP does not promise - rounds for what it has.  (A ticket drawn from an atomic counter would order the blocks by arrival whatever the
+// dispatch order; it cost 15 us of a 66 us launch - the block's loads wait for it - and was dropped: profiles/r06_gram_fused_ablations.txt.)
+// Then the block rounds its own 2048 elements from registers through the LDS tile exactly as gram_round_kernel does.  Same partials, same
+// F / G / x_next, records of the same meaning: the launch replaces residual_store_kernel + gram_round_kernel for chunks of 2048 elements (every
+// shape up to N bsz = 2^25) when N % 2048 == 0.
+constexpr unsigned LOOKBACK_SPINS = 1u << 11;                // re-asks per granule (~0.1 us each) before a block stops waiting: ~0.2 ms
+#ifndef RSR_ABL
+#define RSR_ABL 0     // timing ablations only (tools/gram_fused_time.py; results wrong): 1 = no term stores, 2 = no waiting in the look-back, 4 = no rounding
+                      // arithmetic, 16 = no look-back at all
+#endif
+
+template <int NF, int POL>
+__global__ __launch_bounds__(TB, 4) void residual_store_round_kernel(const float* __restrict__ z1, const float* __restrict__ noise, const float* x_cur,
+                                                                  float* __restrict__ F_hist, float* __restrict__ G_hist, float* x_next,
+                                                                  float* __restrict__ partials, float* __restrict__ ref_state, int64_t ref_stride,
+                                                                  int64_t N, int m, int slot) {
+    constexpr int64_t chunk = 2 * RND_TILE;
+    const int64_t s = blockIdx.y;
+    const int nchunks = gridDim.x;
+    const int t = threadIdx.x, wave = t / WAVE, lane = t % WAVE;
+    float* st = ref_state + s * ref_stride;
+    int* sti = reinterpret_cast<int*>(st);
+    __shared__ float red[TB / WAVE][PART_STRIDE];
+    __shared__ float redx[TB / WAVE][MAXM];
+    __shared__ int ep_s[MAXM], slot_s[MAXM];
+    __shared__ __attribute__((aligned(16))) float tile[NF][RND_PITCH];
+    const int b = blockIdx.x;
+    // (asked for first, needed last: behind the block's own pass)
+    const unsigned epoch = __hip_atomic_load(reinterpret_cast<const unsigned*>(sti + REF_CALL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // (a zeroed state carries tag 0: nothing published)
+    const int64_t beg = (int64_t)b * chunk;
+    const float* zs = z1 + s * N;
+    const float* ns = noise ? noise + s * N : nullptr;
+    const float* xs = x_cur + s * N;
+    float* Fs = F_hist + (s * m + slot) * N;
+    float* Gs = G_hist + (s * m + slot) * N;
+    const float* Gall = G_hist + (s * m) * N;
+    float* xn = x_next ? x_next + s * N : nullptr;
+    // ---- K4 (residual_store_kernel's arithmetic, operation for operation: the block sums are bit-identical to its)
+    const int64_t i = beg + 4 * t, i2 = i + 4 * TB;
+    float4 f = ldp<POL>(zs + i), f2 = ldp<POL>(zs + i2);
+    if (ns) { f = f - ldp<POL>(ns + i); f2 = f2 - ldp<POL>(ns + i2); }
+    const float4 g = f - ldp<POL>(xs + i), g2 = f2 - ldp<POL>(xs + i2);
+    float4 o[NF], o2[NF];
+#pragma unroll
+    // (the residual history with the DEFAULT cache policy whatever POL says: gram_chain_apply_kernel gathers from these rows next - the terms of the
+    //  blocks it walks without a term slot - and finds them in the Infinity Cache: 110.6 -> 105.9 us for K4 + apply + solve at eight measurements)
+    for (int j = 0; j < NF; ++j) if (j != slot) { o[j] = ld4(Gall + j * N + i); o2[j] = ld4(Gall + j * N + i2); }
+    stp<POL>(Fs + i, f); stp<POL>(Fs + i2, f2);
+    st4(Gs + i, g); st4(Gs + i2, g2);
+    if (xn) { stp<POL>(xn + i, f); stp<POL>(xn + i2, f2); }
+    float acc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        if (j == slot) { o[j] = g; o2[j] = g2; }
+        acc[j] = dot4_fma(g, o[j], 0.0f);
+        acc[j] = dot4_fma(g2, o2[j], acc[j]);
+    }
+    const float accf = dot4_fma(f2, f2, dot4_fma(f, f, 0.0f));
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const float v = wave_sum(acc[j]);
+        if (lane == 0) red[wave][j] = v;
+    }
+    {
+        const float v = wave_sum(accf);
+        if (lane == 0) red[wave][MAXM] = v;
+    }
+    __syncthreads();
+    unsigned long long* pub = reinterpret_cast<unsigned long long*>(st + ref_pub(nchunks));
+    float mine = 0.0f;                                          // (t < NF: K4's sum of this block for entry t)
+    if (t < PART_STRIDE) {
+        const int j = t;
+        float v = 0.0f;
+        if (j < NF || j == MAXM) v = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+        partials[(s * nchunks + b) * PART_STRIDE + j] = v;
+        mine = v;
+        if (j < NF)
+            __hip_atomic_store(pub + (int64_t)b * MAXM + j, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- where each chain of each entry is when it gets here: the sums of the blocks before this one (their granules) / 16
+    {
+        float x[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) x[j] = 0.0f;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NP = (NF + 1) / 2;                        // 16-byte pieces of a block's granules: {sum, tag, sum, tag}
+        for (int bb = t; bb < ((RSR_ABL & 16) ? 0 : b); bb += TB) {
+            const u32x4* src = reinterpret_cast<const u32x4*>(pub + (int64_t)bb * MAXM);
+            u32x4 gk[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(gk[p]) : "v"(src + p) : "memory");
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                asm volatile("s_waitcnt vmcnt(%1)" : "+v"(gk[p]) : "n"(NP - 1 - p) : "memory");
+                unsigned spins = 0;
+                while (!(RSR_ABL & 2) && (gk[p].y != epoch || (2 * p + 1 < NF && gk[p].w != epoch)) && ++spins < LOOKBACK_SPINS) {
+                    __builtin_amdgcn_s_sleep(2);
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(gk[p]) : "v"(src + p) : "memory");
+                }
+                x[2 * p] += __uint_as_float(gk[p].x);
+                if (2 * p + 1 < NF) x[2 * p + 1] += __uint_as_float(gk[p].z);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float v = wave_sum(x[j]);
+            if (lane == 0) redx[wave][j] = v;
+        }
+        __syncthreads();
+        if (t < NF) {
+            float v = 0.0f;
+            for (int w = 0; w < TB / WAVE; ++w) v += redx[w][t];
+            v = fabsf(v) * (1.0f / C16);
+            int code = REF_NONE;
+            if (v > 0.0f && v < 3.0e38f) {
+                const int e = ilogbf(v);
+                if (e >= -90 && e <= 90) code = 2 * e + (ldexpf(v, -e) >= 1.41421356f ? 1 : 0);
+            }
+            ep_s[t] = code;
+            sti[REF_EP + (int64_t)b * MAXM + t] = code;
+            int sl = -1;                                        // (the blocks likely to be WALKED also leave their terms chain by chain: gram_round_kernel)
+            {
+                const float here = fabsf(mine) * (1.0f / C16);
+                const float lo = v < v + here ? v : v + here, hi = v + here;
+                bool mark = code == REF_NONE || b < 24 || !(here < 0.2f * v);
+                if (!mark) mark = ilogbf(0.88f * lo) != ilogbf(1.12f * hi);
+                if (mark) {
+                    sl = atomicAdd(&sti[REF_TAKEN + t], 1);
+                    if (sl >= TSLOTS) sl = -1;
+                }
+            }
+            slot_s[t] = sl;
+            sti[ref_slot(nchunks) + (int64_t)b * MAXM + t] = sl;
+        }
+        __syncthreads();
+    }
+    // ---- the rounding pass of gram_round_kernel on the block's own two tiles, from registers
+    float cM[NF][REF_CAND], cH[NF][REF_CAND];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) {
+            const int e = ep_s[j] == REF_NONE ? 0 : ref_lo(ep_s[j]) + q;
+            cM[j][q] = ldexpf(1.5f, e);
+            cH[j][q] = ldexpf(1.0f, e - 24);
+        }
+    unsigned Ns[NF][REF_CAND], As[NF][REF_CAND], Os[NF][REF_CAND];
+    bool tie[NF][REF_CAND];
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) { Ns[j][q] = 0; As[j][q] = 0; Os[j][q] = 0; tie[j][q] = ep_s[j] == REF_NONE; }
+    const int c = t >> 4, gq = t & 15;                         // my chain, and which of its terms: i = gq, gq + 16, ...
+    float* terms = st + ref_terms(nchunks);
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl) {
+        const int w0 = 4 * t + (t >> 2);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const float4 v = tl ? o2[j] : o[j];
+            tile[j][w0] = v.x; tile[j][w0 + 1] = v.y; tile[j][w0 + 2] = v.z; tile[j][w0 + 3] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ii = 0; ii < RND_TILE / C16 / 16; ++ii) {
+            const int ix = gq + 16 * ii, w = 17 * ix + c;
+            const float a = tile[slot][w];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const float bb = tile[j][w];
+                if (slot_s[j] >= 0 && !(RSR_ABL & 1))           // (uniform)
+                    *reinterpret_cast<float2*>(terms + ((((int64_t)j * TSLOTS + slot_s[j]) * C16 + c) * PF_TERMS + (tl * (RND_TILE / C16) + ix)) * 2) = make_float2(a, bb);
+#pragma unroll
+                for (int q = 0; q < ((RSR_ABL & 4) ? 0 : REF_CAND); ++q) {
+                    const float tt = fmaf(a, bb, cM[j][q]);
+                    const unsigned ti = __float_as_uint(tt), mi = __float_as_uint(cM[j][q]);
+                    const unsigned dl = ti > mi ? ti - mi : mi - ti;
+                    Ns[j][q] += ti - mi;
+                    As[j][q] += dl;
+                    Os[j][q] |= dl;
+                    const float d = fmaf(a, bb, -(tt - cM[j][q]));
+                    tie[j][q] |= fabsf(d) == cH[j][q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    int* rec = sti + ref_rec(nchunks);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int q = 0; q < REF_CAND; ++q) {
+            unsigned nn = Ns[j][q], aa = As[j][q], oo = Os[j][q] | (tie[j][q] ? 0x80000000u : 0u);
+#pragma unroll
+            for (int of = 8; of > 0; of >>= 1) { nn += __shfl_xor(nn, of, WAVE); aa += __shfl_xor(aa, of, WAVE); oo |= __shfl_xor(oo, of, WAVE); }
+            if (gq == 0) {
+                int* r2 = rec + ((((int64_t)b * MAXM + j) * C16 + c) * REF_CAND + q) * 2;
+                r2[0] = (int)nn;
+                r2[1] = (oo >> 22) ? -1 : (int)aa;
             }
         }
 }
@@ -735,6 +954,7 @@ __global__ __launch_bounds__(WAVE) void gram_chain_apply_kernel(const float* __r
         st[REF_CSUM + j * C16 + c] = S;
         reinterpret_cast<int*>(st)[REF_WALKED + j * C16 + c] = walked;
         if (c == 0) reinterpret_cast<int*>(st)[REF_TAKEN + j] = 0;              // (gram_round_kernel's term slots: free again for the next call)
+        if (c == 0 && j == 0) reinterpret_cast<unsigned*>(st)[REF_CALL] += 1u;   // (the call is over: residual_store_round_kernel tags its granules with the next number)
     }
 }
 
@@ -1103,6 +1323,46 @@ int deqsci_gram_row_chain16_f32(const float* G_hist, const float* partials, floa
     hipLaunchKernelGGL(gram_chain_apply_kernel, dim3((unsigned)(n_filled * C16), (unsigned)bsz), dim3(WAVE), 0, st, G_hist, partials, ref_state, ref_stride, N, m, slot, chunk,
                        nchunks);
     return launch_status();
+}
+
+int deqsci_gram_ref_fusable(int64_t bsz, int64_t N) {
+    return (bsz > 0 && N > 0 && N % (2 * RND_TILE) == 0 && chunk_elems(bsz, N) == 2 * RND_TILE) ? 1 : 0;
+}
+
+int deqsci_residual_store_ref_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist, float* x_next, float* partials,
+                                  float* ref_state, int64_t bsz, int64_t N, int m, int slot, int n_filled, deqsci_stream_t stream) {
+    if (!z1 || !x_cur || !F_hist || !G_hist || !partials || !ref_state) return DEQSCI_ERR_NULL;
+    if (bsz <= 0 || N <= 0 || m <= 0 || slot < 0 || slot >= m || n_filled < 1 || n_filled > m || slot >= n_filled) return DEQSCI_ERR_SHAPE;
+    if (m > MAXM || bsz > 65535 || !deqsci_gram_ref_fusable(bsz, N)) return DEQSCI_ERR_UNSUPPORTED;
+    if (!aligned16(z1) || (noise && !aligned16(noise)) || !aligned16(x_cur) || !aligned16(F_hist) || !aligned16(G_hist) ||
+        (x_next && !aligned16(x_next)) || !aligned16(ref_state))
+        return DEQSCI_ERR_ALIGN;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+    const int64_t ref_stride = ref_words(nchunks);
+    const dim3 grid((unsigned)nchunks, (unsigned)bsz);
+    const int pol = pick_policy(bsz * N * 4 * (n_filled + 4), POL_NTLS);
+#define RSR_CASE(NF) case NF: POL2_DISPATCH(pol, hipLaunchKernelGGL((residual_store_round_kernel<NF, POL>), grid, dim3(TB), 0, st, z1, noise, x_cur, F_hist, G_hist, x_next, partials, ref_state, ref_stride, N, m, slot)); break;
+    switch (n_filled) {
+        RSR_CASE(1) RSR_CASE(2) RSR_CASE(3) RSR_CASE(4) RSR_CASE(5) RSR_CASE(6) RSR_CASE(7) RSR_CASE(8)
+        default: return DEQSCI_ERR_UNSUPPORTED;
+    }
+#undef RSR_CASE
+    return launch_status();
+}
+
+int deqsci_anderson_apply_solve_ref_f32(const float* G_hist, const float* partials, float* ref_state, void* gram, float* alpha, float* res, int64_t bsz,
+                                        int64_t N, int m, int slot, int n_filled, int n, float lam, float eps, deqsci_stream_t stream) {
+    if (!gram || !res || (n > 0 && !alpha)) return DEQSCI_ERR_NULL;
+    if (n < 0 || n > n_filled) return DEQSCI_ERR_SHAPE;
+    if (int rc = ref_check(G_hist, partials, ref_state, bsz, N, m, slot, n_filled)) return rc;
+    if (!deqsci_gram_ref_fusable(bsz, N)) return DEQSCI_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nchunks = (int)deqsci_anderson_chunks(bsz, N);
+    hipLaunchKernelGGL(gram_chain_apply_kernel, dim3((unsigned)(n_filled * C16), (unsigned)bsz), dim3(WAVE), 0, st, G_hist, partials, ref_state, ref_words(nchunks), N, m, slot,
+                       chunk_elems(bsz, N), nchunks);
+    if (int rc = launch_status()) return rc;
+    return solve_launch(partials, gram, alpha, res, bsz, N, slot, n_filled, n, lam, eps, nullptr, ref_state, st);
 }
 
 int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, float* ref_state, void* gram, float* alpha, float* res, int64_t bsz,

@@ -88,6 +88,13 @@ namespace s16 {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// hi + lo of an fp32 pair in three instructions (csrc/conv_w16.hip: split_pair): hi = v_cvt_pk_f16_f32 (round to nearest even), lo = fp16(a - hi) by
+// v_fma_mixlo / mixhi (a - hi is exact in fp32: one rounding - the bits of converting, converting back, subtracting and converting again)
+__device__ __forceinline__ void split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a0), "v"(a1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(a0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(a1));
+}
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -861,6 +868,8 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
                     v1 = *reinterpret_cast<const f32x4*>(px + (int64_t)(4 * c + 1) * HW * 16);
                 }
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                // (the three-instruction split of csrc/conv_w16.hip - v_cvt_pk_f16_f32 + v_fma_mixlo / mixhi by inline asm - was measured here in
+                //  round 6: 33.5 -> 39.4 us in the loop; the compiler cannot schedule the asm statements between the loads it is waiting for)
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const _Float16 hh = (_Float16)v[k];
@@ -943,35 +952,57 @@ __global__ __launch_bounds__(256) void tail_s16_kernel(const char* __restrict__ 
 // steps); the B operand (k x 32 positions) is GATHERED: lane (position, k block) reads its eight taps from the full-resolution patch /
 // the sigma plane in LDS, multiplies by 2^8 and splits them into hi + lo fp16 on the fly; the weight operands (12 fragments) stay in
 // registers.  18 f16 MFMAs per 32 positions instead of 96 fp32 ones: the layer is left with its 256 B/position store.
-constexpr int HS_H = 8, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
+#ifndef S16_HEAD_NT
+#define S16_HEAD_NT 1        // (A/B) the p32 head's stores: 1 = nt (streaming), 0 = default policy (the lines stay in the XCD's L2 / the Infinity Cache)
+#endif
+#ifndef S16_HEAD_ROWS
+#define S16_HEAD_ROWS 8      // (A/B) rows of half-resolution positions per workgroup tile of head_s16_kernel
+#endif
+constexpr int HS_H = S16_HEAD_ROWS, HS_W = 32, HS_P = 2 * HS_H + 4, HS_Q = 2 * HS_W + 4, HS_QS = HS_Q + 2, HS_SW = HS_W + 2, HS_SS = HS_SW + 1;   // 20 x 68 patch, 10 x 34 sigma plane
 template <int TRACK, int P32>   // TRACK = 1: additionally folds max |output| into *track (the measuring launch of the first f-call; the per-value maximum
                                 // costs the gather-bound kernel a quarter of its time, so the other 180 calls run without it); P32 = 1: the output is
                                 // "p32" (csrc/conv_w16.hip): 2^e y as fp32, the lane's four consecutive couts = its pixel's 16 bytes of plane 2 b8 + kb
 __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__ x, const char* __restrict__ Wp, const float* __restrict__ sigma,
                                                        int sigma_stride, char* __restrict__ y, int H, int W, int w_exp, const float* __restrict__ in_amax,
                                                        int in_exp, const float* __restrict__ out_amax, int out_exp, float* __restrict__ track) {
-    __shared__ __attribute__((aligned(16))) float patch[HS_P * HS_QS + (HS_H + 2) * HS_SS];
+    // (round 6) the patch holds every element ALREADY scaled by 2^e_in and split: one word = its hi piece (low half) and its lo piece (high half).
+    // An element is gathered ~4.5 times (nine taps of the positions around it); multiplying and splitting it at every gather was 96 of the
+    // kernel's ~160 vector instructions per row of 32 positions - and the kernel is issue-bound (it runs right behind the power-capped stack
+    // launch, at its clock: 28 us alone, 39 us in the loop).  Same operations on the same values: the same bits.
+    __shared__ __attribute__((aligned(16))) unsigned patch[HS_P * HS_QS + (HS_H + 2) * HS_SS];
     __shared__ uint32_t trk_s[4];
     constexpr int SGM = HS_P * HS_QS;
     const int n = blockIdx.z, r0 = blockIdx.y * HS_H, c0 = blockIdx.x * HS_W;
     const int H2 = 2 * H, W2 = 2 * W;
     const float* xn = x + (int64_t)n * H2 * W2;
-    // full-resolution pixels (2 r0 - 2 + pr, 2 c0 - 2 + pc): half-res position (r, c), sub-pixel (i, j), tap (dy, dx) reads
-    // (2 (r + dy - 1) + i, 2 (c + dx - 1) + j); zero outside the image = the conv's zero padding of the unshuffled channels
-    for (int e = threadIdx.x; e < HS_P * HS_Q; e += 256) {
-        const int pr = e / HS_Q, pc = e - pr * HS_Q;
-        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
-        patch[pr * HS_QS + pc] = (gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] : 0.0f;
-    }
     const float sig = sigma[(int64_t)n * sigma_stride];
     // the operand gathered below holds 2^e_in (image | sigma): *in_amax is max |image| (the sigma plane is this kernel's own business)
     const int e_in = in_amax ? sp16_act_exp(fmaxf(in_amax[n], __builtin_fabsf(sig))) : in_exp, e_out = out_amax ? sp16_act_exp(out_amax[n]) : out_exp;
     const float in_scale = sp16_pow2(e_in), oscale = sp16_pow2(e_out - e_in - w_exp);
     float tmax = 0.0f;
-    for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
-        const int pr = e / HS_SW, pc = e - pr * HS_SW;
-        const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
-        patch[SGM + pr * HS_SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sig : 0.0f;
+    // full-resolution pixels (2 r0 - 2 + pr, 2 c0 - 2 + pc): half-res position (r, c), sub-pixel (i, j), tap (dy, dx) reads
+    // (2 (r + dy - 1) + i, 2 (c + dx - 1) + j); zero outside the image = the conv's zero padding of the unshuffled channels
+    auto patch_px = [&](int e) __attribute__((always_inline)) -> float {
+        const int pr = e / HS_Q, pc = e - pr * HS_Q;
+        const int gr = 2 * r0 - 2 + pr, gc = 2 * c0 - 2 + pc;
+        return (e < HS_P * HS_Q && gr >= 0 && gr < H2 && gc >= 0 && gc < W2) ? xn[(int64_t)gr * W2 + gc] * in_scale : 0.0f;
+    };
+    for (int e = threadIdx.x; e < HS_P * HS_Q; e += 512) {      // two elements per trip: one split_pair
+        const int e1 = e + 256;
+        unsigned hh, ll;
+        split_pair(patch_px(e), patch_px(e1), hh, ll);
+        patch[(e / HS_Q) * HS_QS + e % HS_Q] = (hh & 0xffffu) | (ll << 16);
+        if (e1 < HS_P * HS_Q) patch[(e1 / HS_Q) * HS_QS + e1 % HS_Q] = (hh >> 16) | (ll & 0xffff0000u);
+    }
+    {
+        unsigned hh, ll;
+        split_pair(sig * in_scale, 0.0f, hh, ll);
+        const unsigned sgw = (hh & 0xffffu) | (ll << 16);
+        for (int e = threadIdx.x; e < (HS_H + 2) * HS_SW; e += 256) {
+            const int pr = e / HS_SW, pc = e - pr * HS_SW;
+            const int rr = r0 - 1 + pr, cc = c0 - 1 + pc;
+            patch[SGM + pr * HS_SS + pc] = (rr >= 0 && rr < H && cc >= 0 && cc < W) ? sgw : 0u;
+        }
     }
     const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6), pl = lane & 31, kb = lane >> 5;
     // this lane's 24 taps: k = 16 ks + 8 kb + j = 9 ch + tap (k >= 45: zero weight, any address): LDS float offset relative to the
@@ -1009,20 +1040,21 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
         h8 Bh[3], Bl[3];
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-            f32x2 v[4];
+            unsigned wd[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 16 * ks + 8 * kb + j;
                 const bool is_sigma = (k < 45 ? k : 0) < 9;      // (sigma taps live in their own plane; per lane: k depends on its k block)
-                v[j >> 1][j & 1] = patch[off[ks][j] + (is_sigma ? sbase : pbase)] * in_scale;
+                wd[j] = patch[off[ks][j] + (is_sigma ? sbase : pbase)];
             }
+            u32x4 bh, bl;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const h2 hh = __builtin_convertvector(v[e], h2);
-                const h2 ll = __builtin_convertvector(v[e] - __builtin_convertvector(hh, f32x2), h2);
-                Bh[ks][2 * e] = hh.x; Bh[ks][2 * e + 1] = hh.y;
-                Bl[ks][2 * e] = ll.x; Bl[ks][2 * e + 1] = ll.y;
+            for (int e = 0; e < 4; ++e) {                       // hi pieces = the words' low halves, lo pieces = their high halves: one v_perm_b32 per pair
+                bh[e] = __builtin_amdgcn_perm(wd[2 * e + 1], wd[2 * e], 0x05040100u);
+                bl[e] = __builtin_amdgcn_perm(wd[2 * e + 1], wd[2 * e], 0x07060302u);
             }
+            Bh[ks] = __builtin_bit_cast(h8, bh);
+            Bl[ks] = __builtin_bit_cast(h8, bl);
         }
         f32x16 acc[2];                                          // (K = 48: nine MFMAs per accumulator - one chain, cross terms first)
 #pragma unroll
@@ -1057,7 +1089,11 @@ __global__ __launch_bounds__(256) void head_s16_kernel(const float* __restrict__
                         if (TRACK && pix != RAW_OOB) tmax = fmaxf(tmax, t[k]);
                     }
                     const uint32_t so = uniform((uint32_t)(2 * (4 * g + gq)) * (uint32_t)HW * 16u);
+#if S16_HEAD_NT
                     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(t), "v"(pix), "s"(orsrc), "s"(so) : "memory");
+#else
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(t), "v"(pix), "s"(orsrc), "s"(so) : "memory");
+#endif
                 }
             continue;
         }

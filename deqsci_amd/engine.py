@@ -575,9 +575,9 @@ class DEQSCIEngine:
         out = _hip.f32c(out)
         ref = self.anderson_arith == "reference"               # the reference's fp32 Gram formed by K4 + K5 themselves (no GEMM library)
         if is_noise:
-            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
+            _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next, ref=ref)
         else:
-            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next)
+            _hip.residual_store(ws, out, None, x_in, slot, n_filled, x_next, ref=ref)
         _hip.anderson_solve(ws, slot, n_filled, n_solve, self.lam, eps, res_row, ref=ref)    # (+ lam I and the fp32 LU of :178-180 in K6)
 
     def _poll(self, ws, row):

@@ -126,9 +126,9 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, *, anders
     ws = _hip.AndersonWorkspace(bsz, N, m, x0.device)
     xb = torch.empty_like(xa)
     flat = lambda t: _hip.f32c(t).reshape(bsz, N)
-    _hip.residual_store(ws, flat(f(xa.view(shape))), None, xa, 0, 1, xb)       # X1 = F0
+    _hip.residual_store(ws, flat(f(xa.view(shape))), None, xa, 0, 1, xb, ref=ref)       # X1 = F0
     _hip.anderson_solve(ws, 0, 1, 0, lam, 1e-5, ref=ref)
-    _hip.residual_store(ws, flat(f(xb.view(shape))), None, xb, 1, 2, None)
+    _hip.residual_store(ws, flat(f(xb.view(shape))), None, xb, 1, 2, None, ref=ref)
     _hip.anderson_solve(ws, 1, 2, 2, lam, 1e-5, ref=ref)
     bufs = [xa.clone(), xb]
     cur = bufs[0]                                                              # X[:, 0] = x0 if the loop is skipped
@@ -138,7 +138,7 @@ def andersonexp(f, x0, m=5, lam=1e-4, max_iter=50, tol=1e-5, beta=1.0, *, anders
         cur = bufs[k % 2]
         _hip.anderson_mix(ws, cur, beta, n)
         nf = min(k + 1, m)
-        _hip.residual_store(ws, flat(f(cur.view(shape))), None, cur, k % m, nf, None)
+        _hip.residual_store(ws, flat(f(cur.view(shape))), None, cur, k % m, nf, None, ref=ref)
         _hip.anderson_solve(ws, k % m, nf, nf, lam, 1e-5, ref=ref)
         res = ws.res[0, 0].item()
         if res < tol:

@@ -140,6 +140,21 @@ int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, fl
                                   int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
                                   float lam, float eps, deqsci_stream_t stream);
 
+/* (round 6) K4 and the first of those two passes in ONE launch: deqsci_residual_store_ref_f32 = deqsci_residual_store_f32 (same F / G / x_next, the
+ *     same block sums in `partials`, bit for bit) whose blocks also leave the records of deqsci_gram_row_chain16_f32's first pass in ref_state - the
+ *     history rows are in the block's registers anyway; the binade a block rounds for comes from its predecessors' block sums, which the blocks
+ *     publish to one another inside the launch (csrc/anderson.hip: residual_store_round_kernel).  Only where deqsci_gram_ref_fusable(bsz, N) = 1
+ *     (N % 2048 == 0 and blocks of 2048 elements: every shape up to N bsz = 2^25), DEQSCI_ERR_UNSUPPORTED otherwise - then the caller uses the two
+ *     entry points above.  deqsci_anderson_apply_solve_ref_f32 = deqsci_anderson_solve_ref_f32 without that first pass: it must follow a
+ *     deqsci_residual_store_ref_f32 of the same call (same ref_state, slot, n_filled) on the same stream.  replaces :163,:177-184 like the pair above. */
+int deqsci_gram_ref_fusable(int64_t bsz, int64_t N);
+int deqsci_residual_store_ref_f32(const float* z1, const float* noise, const float* x_cur,
+                                  float* F_hist, float* G_hist, float* x_next, float* partials, float* ref_state,
+                                  int64_t bsz, int64_t N, int m, int slot, int n_filled, deqsci_stream_t stream);
+int deqsci_anderson_apply_solve_ref_f32(const float* G_hist, const float* partials, float* ref_state, void* gram, float* alpha, float* res,
+                                        int64_t bsz, int64_t N, int m, int slot, int n_filled, int n,
+                                        float lam, float eps, deqsci_stream_t stream);
+
 /* K7  x_out = beta * sum_i alpha_i F_i + (1-beta) * sum_i alpha_i X_i,  X_i = F_i - G_i   (:182) */
 int deqsci_anderson_mix_f32(const float* F_hist, const float* G_hist, const float* alpha,
                             float* x_out, float beta, int n, int64_t bsz, int64_t N, int m,
