@@ -75,6 +75,11 @@ class _Denoiser:
             raise ValueError(f"stack_kernel={stack_kernel!r}: expected 'w16' or 's16'")
         self.stack_kernel = stack_kernel
         self.gate = None                                            # (_StackGate of a grouped reconstruction: one stack launch on the device at a time)
+        # set by the engine while it keeps off the stack launches after a time-out: FFDNet's run as ONE LAUNCH PER LAYER of the same Winograd
+        # kernel - bit-identical to the stack launch (test_wino16_stack_is_bit_identical_to_single_launches), so that the calls behind a
+        # time-out return the bits of ordinary calls.  (A caller's own stack=False keeps its documented meaning: the direct kernel per layer.)
+        self.per_layer_w16 = False
+        self.last_path = None                                       # what the last f-call's run of 64->64 layers went out as (last_info["denoiser_path"])
         self._wstacks = {}                                          # first layer of a run -> _hip.Wino16Stack
         # stack: a run of split-fp16 64->64 layers (FFDNet's 13, SimpleCNN's 2) as ONE launch per slice of the batch
         # (_hip.conv3x3_c64_split16_stack: tiles synchronised by per-tile progress words instead of kernel boundaries, slices that keep
@@ -178,7 +183,8 @@ class _Denoiser:
                 if tuple(layers[-1][0].shape) == (1, 64, 3, 3) and layers[-1][1] is None and not layers[-1][2]:
                     self.plain_tail_w = _hip.pack_c64_to_1_weights(layers[-1][0])
                     self.plain_tail_w16 = _hip.TailSplit16Weights(layers[-1][0])
-                if s16 and self.stack_kernel == "w16" and self.plain_head_w is not None and self.plain_tail_w16 is not None:
+                if (s16 and self.stack_kernel == "w16" and self.conv64 != "s16" and len(layers) - 2 < self.STACK_MIN_LAYERS
+                        and self.plain_head_w is not None and self.plain_tail_w16 is not None):
                     for u in self.wino[1:-1]:                    # (the Winograd pack of the middle layers: here, never inside a capture)
                         if u is not None:
                             u.w16
@@ -392,7 +398,18 @@ class _Denoiser:
                                 self.gate.release()
                             _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
                     self.stack_launches += 1
+                    self.last_path = ("w16" if w16 else "s16") + " stack launch"
                     return out.reshape(bsz, B, H, W), True
+                if (sp and not cal and not self.stack and self.per_layer_w16 and self.stack_kernel == "w16" and self.ranges is not None
+                        and run is not None and self.head_w16 is not None and self.tail_w16 is not None and run[0] in self._wstacks):
+                    # behind a stack time-out: the same kernel, the same ranges, one launch per layer - the stack launch's bits
+                    sg = self.sigma_table[call:call + 1]
+                    h = _hip.ffdnet_head_p32(x, self.head_w16, sg, in_rng=self._slot(0), out_rng=self._slot(1))
+                    for i in run:
+                        h = _hip.conv3x3_c64_wino16(h, self.wino[i].w16, self.fast[i][1], self.fast[i][2], out_rng=self._slot(i + 1))
+                    self.last_path = "w16 per layer (behind a stack time-out)"
+                    return _hip.ffdnet_tail_p32(h, self.tail_w16).reshape(bsz, B, H, W), True
+                self.last_path = "per layer"
                 if self.head_w is not None and x.is_cuda:
                     sg = self.sigma_table[call:call + 1]
                     if sp:
@@ -428,11 +445,14 @@ class _Denoiser:
                     if first and sp and cal:
                         self._measured = True
                         _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=True, out_exp=0, track=self._slot(1))
-                    if (first and sp and not cal and self.stack_kernel == "w16" and self.plain_tail_w16 is not None
+                    if (first and sp and not cal and self.stack_kernel == "w16" and self.plain_tail_w16 is not None and self.conv64 != "s16"
+                            and len(self.fast) - 2 < self.STACK_MIN_LAYERS
                             and all(u is not None for u in self.wino[1:-1]) and self.ranges is not None):
                         # the 64->64 layers on the split-fp16 Winograd kernel (csrc/conv_w16.hip: a third fewer matrix-core products), one
                         # launch per layer (two layers: no run worth a stack launch), p32 activations from the first layer to the last; the
-                        # ranges are the ones the first f-call measured on the direct kernels below
+                        # ranges are the ones the first f-call measured on the direct kernels below.  Only for runs shorter than a stack
+                        # launch is worth (SimpleCNN): a long DnCNN-style run keeps its ONE cache-resident stack launch of the direct kernel
+                        # (_run_stack below), and conv64="s16" means the direct kernel
                         h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], p32=True, out_rng=self._slot(1))
                         for i in range(1, len(self.fast) - 1):
                             h = _hip.conv3x3_c64_wino16(h, self.wino[i].w16, self.fast[i][1], self.fast[i][2], out_rng=self._slot(i + 1))
@@ -597,7 +617,7 @@ class DEQSCIEngine:
             if self._stack_off_for > 0:            # (a stack launch timed out a while ago: per-layer launches for STACK_RETRY_CALLS calls, then try again)
                 self._stack_off_for -= 1
                 if self._stack_off_for == 0 and self._stack_wanted:
-                    self.den.stack, self._graph = True, None
+                    self.den.stack, self.den.per_layer_w16, self._graph = True, False, None
             timed_out = 0
             try:
                 rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
@@ -612,6 +632,7 @@ class DEQSCIEngine:
                               RuntimeWarning)
                 self._stack_timed_out()            # (rearm every stack's words)
                 self.den.stack = False
+                self.den.per_layer_w16 = True      # (FFDNet under the Winograd kernel: per-layer launches of THAT kernel, the stack launch's bits)
                 self.den.stack_launches = 0
                 self._graph = None
                 self._stack_off_for = self.STACK_RETRY_CALLS
@@ -620,6 +641,8 @@ class DEQSCIEngine:
                 rec = self._reconstruct(y, Phi, Phi_sum, initial_point)
             self.last_info["stack_launches"], self.den.stack_launches = self.den.stack_launches, 0
             self.last_info["stack_timeouts"] = timed_out     # 1: a stack launch of THIS call timed out (the result below is the per-layer redo)
+            # what the run of 64->64 layers of the LAST f-call went out as (the kernel actually used, for every call)
+            self.last_info["denoiser_path"] = (self._kids[0].den.last_path if (self._grouped and self._kids) else self.den.last_path)
             fallback = None
             if self.conv64 == "auto" and not math.isfinite(self.last_info["res"]) and bool(torch.isfinite(y).all()):
                 # conv64="auto" promises the reference's fp32 range: a non-finite residual under the split-fp16 layers (already warned
@@ -737,6 +760,10 @@ class DEQSCIEngine:
                 kid.stream.wait_stream(main)
                 with torch.cuda.stream(kid.stream):
                     ws = kid._workspace(hi - lo, H, W, B, dev)
+                    # K4 and the reference Gram's first pass stay TWO launches here: the blocks of the fused launch wait for one another inside
+                    # it (a bounded look-back), and a stack launch of the other half that takes the CUs in the middle of its dispatch leaves
+                    # them spinning on blocks that cannot start - measured: stack launches 1017 -> 1053 us, the grouped step slower than one stream
+                    ws.ref_fusable = False
                     kid.den.prepare(self.max_iter + 4, dev, n_img=(hi - lo) * B)
                     kid.den.stack_launches = 0
                     wss.append(ws)
