@@ -53,6 +53,15 @@ def sigma_schedule(n):
     return out
 
 
+def _exhaust(gen):
+    """Run a generator to its end and return its return value (the plain-call form of the *_steps generators below)."""
+    while True:
+        try:
+            next(gen)
+        except StopIteration as done:
+            return done.value
+
+
 def _fold_bn(conv_w, bn):
     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     return (conv_w * scale.view(-1, 1, 1, 1)).contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
@@ -183,7 +192,7 @@ class _Denoiser:
                 if tuple(layers[-1][0].shape) == (1, 64, 3, 3) and layers[-1][1] is None and not layers[-1][2]:
                     self.plain_tail_w = _hip.pack_c64_to_1_weights(layers[-1][0])
                     self.plain_tail_w16 = _hip.TailSplit16Weights(layers[-1][0])
-                if (s16 and self.stack_kernel == "w16" and self.conv64 != "s16" and len(layers) - 2 < self.STACK_MIN_LAYERS
+                if (s16 and self.stack_kernel == "w16" and self.conv64 != "s16"
                         and self.plain_head_w is not None and self.plain_tail_w16 is not None):
                     for u in self.wino[1:-1]:                    # (the Winograd pack of the middle layers: here, never inside a capture)
                         if u is not None:
@@ -332,6 +341,9 @@ class _Denoiser:
                 self.sigma_table = torch.from_numpy(sigma_schedule(n_calls)).to(device)
 
     def run(self, z1, call, calibrate=False):
+        return _exhaust(self.run_steps(z1, call, calibrate))
+
+    def run_steps(self, z1, call, calibrate=False):
         """calibrate: a new input (the engine: the first f-call of a reconstruction) - the ranges of the split-fp16 activations measured
         last are stale.  They are measured by the next call that takes the split-fp16 path (this one, unless the policy runs its first
         f-calls on another kernel) and kept from then on."""
@@ -347,14 +359,16 @@ class _Denoiser:
         if cal:
             self.ranges.zero_()
         try:
-            out = self._run(z1, x, call, cal)
+            out = yield from self._run_gen(z1, x, call, cal)
             if self._measured:                                      # (only a call that ran to its end has measured every layer)
                 self._stale = False
             return out
         finally:
             self._calibrating = False
 
-    def _run(self, z1, x, call, cal):
+    def _run_gen(self, z1, x, call, cal):
+        """(generator) the f-call's denoiser; yields "stack" behind every stack launch - where a grouped reconstruction switches to its other
+        half (DEQSCIEngine._reconstruct_grouped) - and returns (output, is_noise)."""
         bsz, B, H, W = z1.shape
         if self.tag == "ffdnet":
             sig = self.sigma_table[call:call + 1].expand(bsz * B)
@@ -388,6 +402,7 @@ class _Denoiser:
                             ys = _hip.conv3x3_c64_wino16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
                             if self.gate is not None:
                                 self.gate.release()
+                                yield "stack"
                             _hip.ffdnet_tail_p32(ys, self.tail_w16, out=out[a:a + m])
                         else:
                             hs = _hip.ffdnet_head_split16(x[a:a + m], self.head_w16, sg, out=hin, in_rng=in_rng, out_rng=out_rng)
@@ -396,6 +411,7 @@ class _Denoiser:
                             ys = _hip.conv3x3_c64_split16_stack(hs, st, rows, per_launch=m, rng_offset=a, out_bufs=bufs, check=False)
                             if self.gate is not None:
                                 self.gate.release()
+                                yield "stack"
                             _hip.tail_split16(ys, self.tail_w16, out=out[a:a + m])
                     self.stack_launches += 1
                     self.last_path = ("w16" if w16 else "s16") + " stack launch"
@@ -446,13 +462,12 @@ class _Denoiser:
                         self._measured = True
                         _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], sp16=True, out_exp=0, track=self._slot(1))
                     if (first and sp and not cal and self.stack_kernel == "w16" and self.plain_tail_w16 is not None and self.conv64 != "s16"
-                            and len(self.fast) - 2 < self.STACK_MIN_LAYERS
                             and all(u is not None for u in self.wino[1:-1]) and self.ranges is not None):
                         # the 64->64 layers on the split-fp16 Winograd kernel (csrc/conv_w16.hip: a third fewer matrix-core products), one
                         # launch per layer (two layers: no run worth a stack launch), p32 activations from the first layer to the last; the
-                        # ranges are the ones the first f-call measured on the direct kernels below.  Only for runs shorter than a stack
-                        # launch is worth (SimpleCNN): a long DnCNN-style run keeps its ONE cache-resident stack launch of the direct kernel
-                        # (_run_stack below), and conv64="s16" means the direct kernel
+                        # ranges are the ones the first f-call measured on the direct kernels below.  conv64="s16" means the direct kernel
+                        # (ADVICE r5).  (A long DnCNN-style run - a user plugin; test_plugin_stack_dncnn17_follows_the_data_scale - takes this
+                        # branch too: per-layer Winograd launches, a third fewer matrix-core products than its one direct stack launch.)
                         h = _hip.conv3x3_c1_to_64(x, self.plain_head_w, relu=self.fast[0][2], p32=True, out_rng=self._slot(1))
                         for i in range(1, len(self.fast) - 1):
                             h = _hip.conv3x3_c64_wino16(h, self.wino[i].w16, self.fast[i][1], self.fast[i][2], out_rng=self._slot(i + 1))
@@ -502,16 +517,20 @@ class DEQSCIEngine:
     def __init__(self, denoiser, iterator="anderson", m=5, beta=1.0, lam=1e-2, max_iter=180, tol=1e-5,
                  fold_bn=True, extra_call=False, poll_residual=True, channels_last=None, fused_epilogue=True,
                  fused_edges=True, winograd=True, use_graph="auto", conv64="auto", conv64_f22_calls=None, act_range="data", blk32=True, anderson_arith="reference",
-                 stack=True, stack_kernel="w16", groups="auto"):
+                 stack=True, stack_kernel="w16", groups=1):
         if iterator not in ("anderson", "picard"):
             raise ValueError(iterator)
         if not (groups == "auto" or (isinstance(groups, int) and 1 <= groups <= 2)):
             raise ValueError(f"groups={groups!r}: expected 'auto', 1 or 2")
-        # groups: "auto" / 2 = a batch of at least two stack slices (FFDNet: 2 x 32 images = 8 measurements of 256 x 256 x 8) is reconstructed
-        # as TWO independent half batches, each on its own stream, their f-calls issued alternately (_reconstruct_grouped).  Measurements are
-        # independent problems and every kernel of the path is per measurement, so the result is bit-identical; what changes is what the
-        # device overlaps: a stack launch holds every CU, but the dozen short kernels around it (first / last layer, K4, the Gram kernels,
-        # the 6 x 6 solve, K7+K3 - latency- or HBM-bound, a sixth of an f-call) of one half now run beside the other half's.  1 = off.
+        # groups: 2 (or "auto") = a batch of at least two stack slices (FFDNet: 2 x 32 images = 8 measurements of 256 x 256 x 8) is reconstructed
+        # as TWO independent half batches, each on its own stream, issued alternately up to every stack launch (_reconstruct_grouped).
+        # Measurements are independent problems and every kernel of the path is per measurement, so the result is bit-identical; what
+        # changes is what the device overlaps: a stack launch holds every CU, but the dozen short kernels around it (first / last layer, K4,
+        # the Gram kernels, the 6 x 6 solve, K7+K3 - a seventh of an f-call) of one half run beside the other half's.  MEASURED, and NOT the
+        # default (1 = one stream): the short kernels are HBM- or latency-bound and run at the clock the power-capped stack launch leaves
+        # behind; side by side they gain 50 us per f-call, the stack launches lose 13-36 us each waiting for CUs the other half's short
+        # kernels still hold, and the outcome is between -4 % and +1.3 % from box to box and configuration to configuration
+        # (profiles/r06_groups_*.txt).
         self.groups = groups
         self._ctor = dict(iterator=iterator, m=m, beta=beta, lam=lam, max_iter=max_iter, tol=tol, fold_bn=fold_bn, extra_call=extra_call,
                           channels_last=channels_last, fused_epilogue=fused_epilogue, fused_edges=fused_edges, winograd=winograd, conv64=conv64,
@@ -587,7 +606,10 @@ class DEQSCIEngine:
 
     # ------------------------------------------------------------------ one f-call = GAP -> denoise -> store -> solve
     def _store_solve(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
-        out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
+        return _exhaust(self._store_solve_steps(ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row))
+
+    def _store_solve_steps(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
+        out, is_noise = yield from self.den.run_steps(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
         if call == 1 and self._eager and self._early_check and self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
             # the FIRST stack launch of the reconstruction: a wait that gave up (its workgroups were not all resident: somebody else holds CUs)
             # is seen here, one f-call in - not after 180 f-calls on invalid data.  One host sync per reconstruction (~0.1 ms of queue refill).
@@ -770,16 +792,28 @@ class DEQSCIEngine:
                     gens.append(kid._enqueue_steps(ws, y[lo:hi], Phi4 if Phi4.shape[0] == 1 else Phi4[lo:hi],
                                                    None if Phi_sum is None else (Phi_sum if Phi_sum.shape[0] == 1 else Phi_sum[lo:hi]),
                                                    None if initial_point is None else initial_point[lo:hi], False))
+            # One ROUND = every half issued up to (and including) its next stack launch; then every half that launched one makes its stream
+            # wait for the LAST stack launch of the round before it goes on.  Without that wait the order on the device is a race at every
+            # stack's end - the finished half's own short kernels (next in ITS stream) against the other half's stack launch (released by an
+            # event) - and it locks into the pattern stack A | A's short kernels | stack B | B's short kernels: nothing overlaps, and the
+            # halved launches make it SLOWER than one stream (443 against 426 ms per step).  With it: stack A | stack B | the short
+            # kernels of both halves side by side | stack A | ...
             done = [None] * len(kids)
             alive = list(range(len(kids)))
             while alive:
+                stacked = []
                 for i in list(alive):
                     with torch.cuda.stream(kids[i].stream):
                         try:
-                            next(gens[i])
+                            while next(gens[i]) != "stack":
+                                pass
+                            stacked.append(i)
                         except StopIteration as fin:
                             done[i] = fin.value
                             alive.remove(i)
+                if stacked and self._gate.ev is not None:
+                    for i in stacked:
+                        kids[i].stream.wait_event(self._gate.ev)
             rec = torch.empty((bsz, H, W, B), dtype=torch.float32, device=dev)
             norms = []
             for kid, ws, (lo, hi), (r, call, last, res_row) in zip(kids, wss, plan, done):
@@ -854,15 +888,15 @@ class DEQSCIEngine:
         res_row = last
         # z = f(z*)  (new_equilibrium_utils_yaping.py:268)
         _hip.gap_update(x_last, phi, y, ps, LAYOUT_BHW, out=ws.z1)
-        out, is_noise = self.den.run(ws.z1, call)
+        out, is_noise = yield from self.den.run_steps(ws.z1, call)
         out = _hip.f32c(out)
         rec = _hip.residual_out(ws.z1, out, LAYOUT_HWB) if is_noise else _hip.transpose(out, LAYOUT_HWB)
         call += 1
         if self.extra_call:                                   # dead f0 = f(z) of :271-272
-            yield
+            yield "fcall"
             zt = _hip.transpose(rec, LAYOUT_BHW)
             _hip.gap_update(zt, phi, y, ps, LAYOUT_BHW, out=ws.z1)
-            self.den.run(ws.z1, call)
+            yield from self.den.run_steps(ws.z1, call)
             call += 1
         return rec, call, last, res_row
 
@@ -917,11 +951,11 @@ class DEQSCIEngine:
         xb = ws.xbuf
         # f-calls 1, 2 fill slots 0, 1 (:162-163)
         _hip.gap_update(xb[0], phi, y, ps, LAYOUT_BHW, out=ws.z1)
-        self._store_solve(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-5, 0)
-        yield
+        yield from self._store_solve_steps(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-5, 0)
+        yield "fcall"
         _hip.gap_update(xb[1], phi, y, ps, LAYOUT_BHW, out=ws.z1)
-        self._store_solve(ws, xb[1], 1, 1, 2, 2, None, 1e-5, 1)
-        yield
+        yield from self._store_solve_steps(ws, xb[1], 1, 1, 2, 2, None, 1e-5, 1)
+        yield "fcall"
         if max_iter <= 2:
             raise UnboundLocalError("local variable 'res' referenced before assignment")      # :189 with the loop skipped
         last, prev_ev = None, None
@@ -930,9 +964,9 @@ class DEQSCIEngine:
             x = xb[k % 2]
             _hip.anderson_mix_gap(ws, self.beta, n, phi, y, ps, x, ws.z1, LAYOUT_BHW)
             nf = min(k + 1, m)
-            self._store_solve(ws, x, k, k % m, nf, nf, None, 1e-5, k)
+            yield from self._store_solve_steps(ws, x, k, k % m, nf, nf, None, 1e-5, k)
             last = k
-            yield
+            yield "fcall"
             if poll:
                 ev = self._poll(ws, k)
                 if prev_ev is not None:
@@ -949,8 +983,8 @@ class DEQSCIEngine:
     def _picard(self, ws, y, phi, ps, poll):
         xb = ws.xbuf
         _hip.gap_update(xb[0], phi, y, ps, LAYOUT_BHW, out=ws.z1)
-        self._store_solve(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-7, 0)           # f0 = f(x0)
-        yield
+        yield from self._store_solve_steps(ws, xb[0], 0, 0, 1, 0, xb[1], 1e-7, 0)           # f0 = f(x0)
+        yield "fcall"
         if self.max_iter <= 0:
             if poll is not None:
                 ws.host_res[0].copy_(ws.res[0], non_blocking=True)
@@ -959,9 +993,9 @@ class DEQSCIEngine:
         for k in range(self.max_iter):
             x, nxt = xb[(k + 1) % 2], xb[k % 2]
             _hip.gap_update(x, phi, y, ps, LAYOUT_BHW, out=ws.z1)
-            self._store_solve(ws, x, k + 1, 0, 1, 0, nxt, 1e-7, k + 1)
+            yield from self._store_solve_steps(ws, x, k + 1, 0, 1, 0, nxt, 1e-7, k + 1)
             last = k
-            yield
+            yield "fcall"
             if poll:
                 ev = self._poll(ws, k + 1)
                 if prev_ev is not None:

@@ -1345,9 +1345,10 @@ def test_config3_synthetic_batch_vs_oracle():
 
 @pytest.mark.parametrize("anderson_arith,bsz,iterator", [("reference", 8, "anderson"), ("float64", 12, "anderson"), ("reference", 8, "picard")])
 def test_grouped_reconstruction_is_bit_identical_to_one_stream(anderson_arith, bsz, iterator):
-    """A batch of at least two stack slices (8 measurements of 256 x 256 x 8 = 2 x 32 images) is reconstructed as two half batches on two
-    streams, their f-calls issued alternately and their stack launches chained by events (DEQSCIEngine groups="auto",
-    _reconstruct_grouped): what the device overlaps changes, no result does - every kernel of the path is per measurement.  Held here:
+    """DEQSCIEngine(groups=2) - an option, not the default: it measured between -4 % and +1.3 % - reconstructs a batch of at least two stack
+    slices (8 measurements of 256 x 256 x 8 = 2 x 32 images) as two half batches on two streams, issued alternately up to every stack
+    launch, their stack launches chained by events (_reconstruct_grouped): what the device overlaps changes, no result does - every
+    kernel of the path is per measurement.  Held here:
     the reconstruction, the residual of the whole batch (new_equilibrium_utils_yaping.py:184: folded from the samples' float64 norms in
     sample order, as K6's last block does) and the per-sample residuals are BIT-identical to groups=1; a ragged split (12 measurements =
     3 slices: 8 + 4) likewise; extra_call rides along; a second call through the same engine reuses the halves; and a batch of less
@@ -1359,8 +1360,8 @@ def test_grouped_reconstruction_is_bit_identical_to_one_stream(anderson_arith, b
     one = DEQSCIEngine(net, groups=1, **kw)
     want = one.reconstruct(y, Phi)
     assert "groups" not in one.last_info
-    two = DEQSCIEngine(net, **kw)
-    assert two.groups == "auto"
+    assert DEQSCIEngine(net, **kw).groups == 1
+    two = DEQSCIEngine(net, groups=2, **kw)
     for rep in range(2):
         got = two.reconstruct(y, Phi)
         assert two.last_info["groups"] == ([[0, 4], [4, 8]] if bsz == 8 else [[0, 8], [8, 12]])

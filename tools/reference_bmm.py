@@ -20,8 +20,8 @@ class ReferenceBmmEngine(DEQSCIEngine):
         kw.setdefault("groups", 1)
         super().__init__(denoiser, **kw)
 
-    def _store_solve(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
-        out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))
+    def _store_solve_steps(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
+        out, is_noise = yield from self.den.run_steps(ws.z1, call, calibrate=(call == 0))
         out = _hip.f32c(out)
         if is_noise:
             _hip.residual_store(ws, ws.z1, out, x_in, slot, n_filled, x_next)
