@@ -56,6 +56,9 @@
 #define W16_DMA4 0          // (A/B) 1: waves 0-3 - the older wave of every SIMD, which the arbiter serves first and which then waits ~1300 cycles per
                             // half-stage at the barrier for its partner - issue ALL the LDS-DMA instructions (two per slot), waves 4-7 none
 #endif
+#ifndef W16_STORE_NOW
+#define W16_STORE_NOW 1     // (A/B) 0: round 5 - a tile's outputs always wait for the end of its epilogue
+#endif
 #ifndef W16_ABL
 #define W16_ABL 0     // timing ablations only (results wrong): 1 = no DMA inside the half-stages, 2 = no transform, 4 = no epilogue, 8 = epilogue without its stores
 #endif
@@ -535,6 +538,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         // ---- epilogue: y[2t] = M0 + M1 + M2, y[2t + 1] = M1 - M2 - M3, x 2^(e_out - e_in - w_exp), + bias, ReLU (the NaN-propagating maximum).
         // acc[.][g][i] is cout 32 g + 8 (i >> 2) + 4 kb + (i & 3) of tile pl of row wave: the lane's four consecutive couts of an 8-cout block
         // b8 = 4 g + gq are the 16 bytes of its pixel in plane 2 b8 + kb (the lane's kb rides in pix).
+        // (round 6) a tile whose outputs cannot wait for the next tile's first half-stage - the slow path below, the launch's last tile - stores each
+        // pair of pixels as soon as it exists: the 16 stores take ~150 cycles each to issue, and behind the epilogue's arithmetic they were 2400
+        // cycles of the hand-over between two layers at one tile per workgroup (one measurement per call)
+        const bool store_now = W16_STORE_NOW && (STACK ? (!next || !ready) : !next);
         if (!(W16_ABL & 4) || relu == 77) {
             const float floor_ = relu ? 0.0f : -__builtin_inff();
             const __attribute__((address_space(3))) float* bsl = (const __attribute__((address_space(3))) float*)bias_s + (STACK ? 64 * (L & 1) : 0);
@@ -551,9 +558,10 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
                         o[g][gq][0][k] = __builtin_elementwise_maximum(__builtin_fmaf(y0, dp.oscale, bz[k]), floor_);
                         o[g][gq][1][k] = __builtin_elementwise_maximum(__builtin_fmaf(y1, dp.oscale, bz[k]), floor_);
                     }
+                    if (store_now) { store_step(2 * (4 * g + gq)); store_step(2 * (4 * g + gq) + 1); }
                 }
             }
-            have_o = true;
+            have_o = !store_now;
         }
         // the next tile's second weight half (issued in half-stage 7's last group, in front of a halo tile that may still fly) has to be there
         // before a store goes out behind it: vmcnt counts loads and stores alike
