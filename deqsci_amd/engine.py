@@ -609,7 +609,11 @@ class DEQSCIEngine:
         return _exhaust(self._store_solve_steps(ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row))
 
     def _store_solve_steps(self, ws, x_in, call, slot, n_filled, n_solve, x_next, eps, res_row):
-        out, is_noise = yield from self.den.run_steps(ws.z1, call, calibrate=(call == 0))     # (the first f-call measures the activations' ranges)
+        # (the first f-call measures the activations' ranges; only a half of a grouped reconstruction - a gate is set - needs the generator form)
+        if self.den.gate is not None:
+            out, is_noise = yield from self.den.run_steps(ws.z1, call, calibrate=(call == 0))
+        else:
+            out, is_noise = self.den.run(ws.z1, call, calibrate=(call == 0))
         if call == 1 and self._eager and self._early_check and self.den.stack and self.den.stack_launches and self.den.stack_timed_out():
             # the FIRST stack launch of the reconstruction: a wait that gave up (its workgroups were not all resident: somebody else holds CUs)
             # is seen here, one f-call in - not after 180 f-calls on invalid data.  One host sync per reconstruction (~0.1 ms of queue refill).
@@ -888,7 +892,10 @@ class DEQSCIEngine:
         res_row = last
         # z = f(z*)  (new_equilibrium_utils_yaping.py:268)
         _hip.gap_update(x_last, phi, y, ps, LAYOUT_BHW, out=ws.z1)
-        out, is_noise = yield from self.den.run_steps(ws.z1, call)
+        if self.den.gate is not None:
+            out, is_noise = yield from self.den.run_steps(ws.z1, call)
+        else:
+            out, is_noise = self.den.run(ws.z1, call)
         out = _hip.f32c(out)
         rec = _hip.residual_out(ws.z1, out, LAYOUT_HWB) if is_noise else _hip.transpose(out, LAYOUT_HWB)
         call += 1
@@ -896,7 +903,10 @@ class DEQSCIEngine:
             yield "fcall"
             zt = _hip.transpose(rec, LAYOUT_BHW)
             _hip.gap_update(zt, phi, y, ps, LAYOUT_BHW, out=ws.z1)
-            yield from self.den.run_steps(ws.z1, call)
+            if self.den.gate is not None:
+                yield from self.den.run_steps(ws.z1, call)
+            else:
+                self.den.run(ws.z1, call)
             call += 1
         return rec, call, last, res_row
 
