@@ -896,8 +896,9 @@ def test_engine_split16_on_ragged_sizes(kind, weights):
     _hip.CONV64_EVENT_HOOK = lambda k, n, h, w: seen.append((k, n, h, w))
     try:
         a = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="s16").reconstruct(G(y), G(Phi))
-        # (SimpleCNN's two middle layers: the measuring f-call on the direct kernel, the others on the Winograd form - stack_kernel="w16", the default)
-        assert {k for k, *_ in seen} == ({"s16"} if kind == "ffdnet" else {"s16", "w16"}) and seen[0][1:] == ((16, 50, 38) if kind == "ffdnet" else (16, 100, 76))
+        # (conv64="s16" means the DIRECT kernel - ADVICE r5: until round 6 SimpleCNN's two middle layers took the Winograd form behind the measuring
+        #  f-call even then; FFDNet's run at this size is below a stack launch's worth and goes out per layer)
+        assert {k for k, *_ in seen} == {"s16"} and seen[0][1:] == ((16, 50, 38) if kind == "ffdnet" else (16, 100, 76))
         del seen[:]
         a16 = DEQSCIEngine(net, max_iter=6, use_graph=False, conv64="s16", stack_kernel="s16").reconstruct(G(y), G(Phi))
         assert {k for k, *_ in seen} == {"s16"} and rel_l2(a.cpu().numpy(), a16.cpu().numpy()) < 2e-6
