@@ -2070,6 +2070,32 @@ def test_harness_graph_replay_equals_eager_measurement_by_measurement():
     print(f"\nharness FFDNet@180 measurement-by-measurement (hipGraph): 64 frames in {dt:.3f} s = {64 / dt:.1f} frames/s")
 
 
+def test_rccl_single_rank_collectives():
+    """RCCL itself on this box, as far as ONE GPU lets it run: a fresh process creates the "nccl" process group (world size 1, device_id as
+    distributed.init_from_env passes it) and issues exactly the collectives bench.py's N > 1 path uses - barrier, all_gather_into_tensor of a
+    reconstruction-shaped tensor, all_reduce(MAX) of the step time, all_gather_object of the per-rank record.  The N > 1 run over xGMI is the
+    driver's; this pins that the library loads, initialises and completes a collective on the device (HSA_ENABLE_IPC_MODE_LEGACY=0 as exported)."""
+    import subprocess
+    import sys
+    from deqsci_amd.distributed import free_port
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "torch.cuda.set_device(0); dev = torch.device('cuda', 0)\n"
+        "dist.init_process_group(backend='nccl', rank=0, world_size=1, device_id=dev)\n"
+        "assert dist.get_backend() == 'nccl'\n"
+        "dist.barrier()\n"
+        "x = torch.rand(2, 256, 256, 8, device=dev); full = torch.empty_like(x)\n"
+        "dist.all_gather_into_tensor(full, x); torch.cuda.synchronize(); assert torch.equal(full, x)\n"
+        "t = torch.tensor([1.5], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 1.5\n"
+        "got = [None]; dist.all_gather_object(got, {'rank': 0}); assert got == [{'rank': 0}]\n"
+        "dist.barrier(); dist.destroy_process_group(); print('rccl ok')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "rccl ok" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
 def test_bench_two_ranks_on_one_gpu_real_engine():
     """World size 2 with the REAL engine: `bench.py --gpus 2 --ranks-share-gpu0` starts two rank processes that share cuda:0
     and gather through gloo (RCCL refuses two ranks on one device; the build pool has one GPU per box).  Checks the launcher,
