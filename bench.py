@@ -183,7 +183,8 @@ def hbm_stream_roofline(H, W, B, m, dev, bsz=64, sets=3, budget_s=1.5):
 def config2_shipped_clips(args, dev):
     """BASELINE configs[1] on the data it names: the 3 shipped clips = 8 measurements through the build's evaluation harness
     (deqsci_amd.harness.evaluate: upload, reconstruction, PSNR; file reading excluded) - one measurement per call (the reference's
-    schedule, training/sci_equilibrium_training.py:171-181) and a clip's measurements as one batch - with the average PSNR next to the
+    schedule, training/sci_equilibrium_training.py:171-181), a clip's measurements as one batch, and all eight as ONE batch (each with its
+    own clip's mask: harness.reconstruct_clips_together) - with the average PSNR next to the
     reference's own run and its perturbation band (tests/golden/e2e_ffdnet_anderson_180*.json; FFDNet + Anderson at 180 iterations is
     chaotic on the traffic clip: the band, not the digit, is the comparison - DESIGN section 5)."""
     from deqsci_amd import checkpoint
@@ -193,7 +194,7 @@ def config2_shipped_clips(args, dev):
     _, deq = build_pipeline("ffdnet", checkpoint.shipped("ffdnet_gray"), args.iters)
     out = {"what": "the 8 shipped measurements (drop8 1, runner8 1, traffic 6) through harness.evaluate, FFDNet (net_gray.pth), Anderson, "
                    f"and_maxiters={args.iters}; wall time of upload + reconstruction + PSNR"}
-    for name, batch in (("one_by_one", False), ("clip_batched", True)):
+    for name, batch in (("one_by_one", False), ("clip_batched", True), ("all_clips_one_batch", "all")):
         for _ in range(2):                                     # eager warm-up of every shape, then its hipGraph capture
             evaluate(deq, clips, batch=batch)
         torch.cuda.synchronize()
@@ -645,6 +646,7 @@ def run_rank(args):
                 "one_measurement_per_call": round(oc["one_measurement_per_call"]["value"], 2) if "one_measurement_per_call" in oc else None,
                 "config2_shipped_clips_one_by_one": round(c2["one_by_one"]["value"], 2) if c2 else None,
                 "config2_shipped_clips_clip_batched": round(c2["clip_batched"]["value"], 2) if c2 else None,
+                "config2_shipped_clips_all_in_one_batch": round(c2["all_clips_one_batch"]["value"], 2) if c2 else None,
                 "config2_avg_psnr_db": round(c2["one_by_one"]["avg_psnr_db"], 4) if c2 else None,
                 "config2_reference_avg_psnr_db": round(c2["reference_avg_psnr_db"], 4) if c2.get("reference_avg_psnr_db") else None,
                 "config2_reference_avg_psnr_band_db": [round(v, 4) for v in c2["reference_avg_psnr_band_db"]] if c2.get("reference_avg_psnr_band_db") else None,

@@ -65,9 +65,10 @@ def parser():
                         "new_equilibrium_utils_yaping.py:177-178 in the summation order of its torch.bmm, fp32 LU - which reproduces the reference's "
                         "ensemble statistics on the chaotic FFDNet + Anderson @180 configuration (DESIGN.md section 5); float64 = Gram and solve in "
                         "float64 (exact; 4 % faster at eight measurements per call, 14 % at one)")
-    p.add_argument('--batch_measurements', action='store_true',
-                   help="(this build) a clip's measurements as ONE engine batch instead of the reference's one-by-one schedule; "
-                        "implied by more than one --gpu_ids entry, which shards them")
+    p.add_argument('--batch_measurements', nargs='?', const='clip', default=None, choices=['clip', 'all'],
+                   help="(this build) clip: a clip's measurements as ONE engine batch instead of the reference's one-by-one schedule (implied by "
+                        "more than one --gpu_ids entry, which shards them); all: the measurements of all clips of one frame size as one batch "
+                        "(the three shipped clips: one call of eight measurements - what the device is fastest at)")
     ignored = p.add_argument_group("accepted for command-line compatibility, unused by inference")
     ignored.add_argument('--n_epochs', default=80)
     ignored.add_argument('--batch_size', type=int, default=1)
@@ -105,7 +106,7 @@ def run(args):
             print([r.name], '  PSNR: %.2f dB' % r.mean_psnr)
     t0 = time.time()
     avg, results = evaluate(deq, SCITestDataset(args.testpath), device=dev, on_clip=on_clip,
-                            batch=bool(args.batch_measurements or world > 1))
+                            batch="all" if args.batch_measurements == "all" else bool(args.batch_measurements or world > 1))
     dt = time.time() - t0
     if rank == 0:
         print('---------------------------------', 'Total Average PSNR: %.2f dB' % avg)

@@ -181,9 +181,65 @@ def reconstruct_clip(deep_eq_module, clip, device="cuda", batch=True, group=None
                       info={"measurements": ids, "batched": bool(batch)})
 
 
+def reconstruct_clips_together(deep_eq_module, clips, device="cuda", group=None):
+    """The scored measurements of SEVERAL clips of one frame size as ONE engine batch, every measurement with its own clip's mask
+    ((M,H,W,B) masks: nothing couples the measurements of a batch - alpha, residual, the ranges of the split-fp16 activations are all per
+    measurement - so a measurement's reconstruction is the one it gets in any other batch, bit for bit).  What the reference's loop over
+    clips and measurements (training/sci_equilibrium_training.py:157,171) becomes when the device wants eight measurements per call: the
+    three shipped clips (1 + 1 + 6 measurements) are one call.  -> [ClipResult] in the clips' order; a clip's `seconds` is its share of
+    the call by frames."""
+    import time
+    clips = [as_clip(c) for c in clips]
+    ids = [scored_measurements(c['file'], c['meas'].shape[-1]) for c in clips]
+    Phi = torch.cat([c['mask'].to(device)[None].expand(len(i), -1, -1, -1) for c, i in zip(clips, ids)]).contiguous()      # (M,H,W,B)
+    y = torch.cat([c['meas'].to(device).permute(2, 0, 1)[i] for c, i in zip(clips, ids)]).contiguous()                        # (M,H,W)
+    B = Phi.shape[-1]
+    res = []
+
+    def run(y_part, Phi_part):
+        Ps = operators.phi_sum(Phi_part)
+        with torch.no_grad():
+            x0 = operators.initial_point(y_part, Phi_part, Ps, None)
+        rec = deep_eq_module.forward(y_part, Phi_part, Ps, initial_point=x0, train_flag=False)
+        res.extend(_residuals(deep_eq_module, y_part.shape[0])[0])
+        return rec.detach()
+    t0 = time.perf_counter()
+    rec = distributed.sharded_reconstruct(run, y, Phi, group=group)
+    res = distributed.gather_scalars(res, group=group)
+    if rec.is_cuda:
+        torch.cuda.synchronize(rec.device)
+    dt = time.perf_counter() - t0
+    out, a = [], 0
+    for c, i in zip(clips, ids):
+        r = rec[a:a + len(i)]
+        out.append(ClipResult(name=c['file'], rec=r, psnr=clip_psnr(r, c['gt'], i), res=list(res[a:a + len(i)]), frames=B * len(i),
+                              seconds=dt * len(i) / y.shape[0], info={"measurements": i, "batched": "all"}))
+        a += len(i)
+    return out
+
+
 def evaluate(deep_eq_module, clips, device="cuda", batch=True, group=None, on_clip=None):
-    """-> (mean over clips of the clip's mean PSNR, [ClipResult])."""
+    """-> (mean over clips of the clip's mean PSNR, [ClipResult]).  batch: False = one measurement per call (the reference's schedule),
+    True = a clip's measurements per call, "all" = the measurements of consecutive clips of one frame size per call
+    (reconstruct_clips_together: the three shipped clips are ONE call of eight measurements)."""
     results = []
+    if batch == "all":
+        pending = []
+
+        def flush():
+            if pending:
+                for r in reconstruct_clips_together(deep_eq_module, pending, device=device, group=group):
+                    results.append(r)
+                    if on_clip is not None:
+                        on_clip(r)
+                del pending[:]
+        for sample in clips:
+            c = as_clip(sample)
+            if pending and tuple(as_clip(pending[0])['mask'].shape) != tuple(c['mask'].shape):
+                flush()
+            pending.append(c)
+        flush()
+        return sum(r.mean_psnr for r in results) / len(results), results
     for sample in clips:
         r = reconstruct_clip(deep_eq_module, sample, device=device, batch=batch, group=group)
         results.append(r)
@@ -207,7 +263,8 @@ def test_solver_sci(deep_eq_module, test_dataloader=None, save_img_path=None, ve
                     device="cuda", records=None, batch_measurements=False):
     """Adapter with the reference's signature (training/sci_equilibrium_training.py:152): returns
     (average PSNR, {png path: float image}); prints one line per clip and the total; writes the PNGs.
-    Default = the reference's schedule, one measurement per call (:171-181); batch_measurements=True hands a clip's
+    Default = the reference's schedule, one measurement per call (:171-181); batch_measurements="all" hands the measurements of all clips of
+    one frame size to the engine as ONE batch (the three shipped clips: one call of eight); batch_measurements=True hands a clip's
     measurements to the engine as one batch (faster; on the chaotic FFDNet + Anderson @180 clip a different - equally valid -
     realisation, because the FFDNet head kernel is chosen by launch size)."""
     images = {}

@@ -397,6 +397,22 @@ def test_harness_clip_batched_equals_sequential():
     assert len(im) == 64 and abs(a1 - a2) < 1e-3
     for x, y_ in zip(r1, r2):
         assert x["id"] == y_["id"] and rel_l2(y_["rec"].numpy(), x["rec"].numpy()) < 2e-5
+    # round 6: the measurements of ALL clips of one frame size as one engine batch, each with its own clip's mask (the three shipped clips:
+    # one call of eight) - same order, same PSNRs, same PNG payloads
+    r3 = []
+    a3, im3 = test_solver_sci(deq, test_dataloader=loader, save_img_path="", verbose=False, save_image=False, records=r3, batch_measurements="all")
+    assert len(im3) == 64 and sorted(im3) == sorted(im) and abs(a1 - a3) < 1e-3 and [x["id"] for x in r3] == [x["id"] for x in r1]
+    for x, y_ in zip(r1, r3):
+        assert rel_l2(y_["rec"].numpy(), x["rec"].numpy()) < 2e-5 and abs(x["psnr"] - y_["psnr"]) < 1e-3
+    # ... and for FFDNet's stack path, where a measurement's result does not depend on its batch at all: bit-identical to the clip batches
+    _, dq = _pipeline("ffdnet", 6)
+    from deqsci_amd.harness import evaluate
+    clips = list(SCITestDataset(orc.DATA_DIR))
+    _, by_clip = evaluate(dq, clips, batch=True)
+    _, together = evaluate(dq, clips, batch="all")
+    assert [r.name for r in together] == [r.name for r in by_clip]
+    for p_, q_ in zip(by_clip, together):
+        assert torch.equal(p_.rec, q_.rec) and p_.psnr == q_.psnr and q_.info["batched"] == "all" and p_.frames == q_.frames
 
 
 def test_engine_batch_equals_single_and_shared_mask():
