@@ -472,8 +472,8 @@ __global__ __launch_bounds__(TB) void gram_round_kernel(const float* __restrict_
 // which HIP does not promise - rounds for what it has.  (A ticket drawn from an atomic counter would order the blocks by arrival whatever the
 // dispatch order; it cost 15 us of a 66 us launch - the block's loads wait for it - and was dropped: profiles/r06_gram_fused_ablations.txt.)
 // Then the block rounds its own 2048 elements from registers through the LDS tile exactly as gram_round_kernel does.  Same partials, same
-// F / G / x_next, records of the same meaning: the launch replaces residual_store_kernel + gram_round_kernel for chunks of 2048 elements (every
-// shape up to N bsz = 2^25) when N % 2048 == 0.
+// F / G / x_next, records of the same meaning: the launch replaces residual_store_kernel + gram_round_kernel for chunks of 2048 elements (N bsz <= 2^25)
+// when N is a whole number of at most 256 of them (deqsci_gram_ref_fusable).
 constexpr unsigned LOOKBACK_SPINS = 1u << 11;                // re-asks per granule (~0.1 us each) before a block stops waiting: ~0.2 ms
 #ifndef RSR_ABL
 #define RSR_ABL 0     // timing ablations only (tools/gram_fused_time.py; results wrong): 1 = no term stores, 2 = no waiting in the look-back, 4 = no rounding
@@ -1325,8 +1325,11 @@ int deqsci_gram_row_chain16_f32(const float* G_hist, const float* partials, floa
     return launch_status();
 }
 
+// (N / 2048 <= 256 blocks per sample: every block reads ALL its predecessors' granules - at N = 2^22, 2048 blocks per sample in several residency
+//  rounds, the fused launch is SLOWER than the two launches (bsz 2: 241 against 202 us for K4 + Gram + solve; bsz 8: 770 against 557:
+//  tools/gram_fused_time.py with GRAM_BIG=1); a two-level look-back would lift that, the two launches serve until then)
 int deqsci_gram_ref_fusable(int64_t bsz, int64_t N) {
-    return (bsz > 0 && N > 0 && N % (2 * RND_TILE) == 0 && chunk_elems(bsz, N) == 2 * RND_TILE) ? 1 : 0;
+    return (bsz > 0 && N > 0 && N % (2 * RND_TILE) == 0 && N / (2 * RND_TILE) <= 256 && chunk_elems(bsz, N) == 2 * RND_TILE) ? 1 : 0;
 }
 
 int deqsci_residual_store_ref_f32(const float* z1, const float* noise, const float* x_cur, float* F_hist, float* G_hist, float* x_next, float* partials,

@@ -144,7 +144,7 @@ int deqsci_anderson_solve_ref_f32(const float* G_hist, const float* partials, fl
  *     same block sums in `partials`, bit for bit) whose blocks also leave the records of deqsci_gram_row_chain16_f32's first pass in ref_state - the
  *     history rows are in the block's registers anyway; the binade a block rounds for comes from its predecessors' block sums, which the blocks
  *     publish to one another inside the launch (csrc/anderson.hip: residual_store_round_kernel).  Only where deqsci_gram_ref_fusable(bsz, N) = 1
- *     (N % 2048 == 0 and blocks of 2048 elements: every shape up to N bsz = 2^25), DEQSCI_ERR_UNSUPPORTED otherwise - then the caller uses the two
+ *     (blocks of 2048 elements - N bsz <= 2^25 -, N a whole number of at most 256 of them: 256 x 256 x 8 is exactly that), DEQSCI_ERR_UNSUPPORTED otherwise - then the caller uses the two
  *     entry points above.  deqsci_anderson_apply_solve_ref_f32 = deqsci_anderson_solve_ref_f32 without that first pass: it must follow a
  *     deqsci_residual_store_ref_f32 of the same call (same ref_state, slot, n_filled) on the same stream.  replaces :163,:177-184 like the pair above. */
 int deqsci_gram_ref_fusable(int64_t bsz, int64_t N);

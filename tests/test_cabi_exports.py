@@ -44,7 +44,7 @@ def test_scratch_size_queries_and_error_strings():
     assert lib.deqsci_anderson_solve_ref_f32(None, None, None, None, None, None, 1, 64, 5, 0, 1, 0, 1e-2, 1e-5, None) == -1
     assert lib.deqsci_gram_row_chain16_f32(None, None, None, 1, 64, 5, 0, 1, 0, None) == -1
     # round 6: K4 fused with the reference Gram's first pass - where the blocks are 2048 elements and N is a whole number of them
-    assert lib.deqsci_gram_ref_fusable(8, 256 * 256 * 8) == 1 and lib.deqsci_gram_ref_fusable(2, 512 * 512 * 16) == 1
+    assert lib.deqsci_gram_ref_fusable(8, 256 * 256 * 8) == 1 and lib.deqsci_gram_ref_fusable(2, 512 * 512 * 16) == 0      # (2048 blocks per sample: the two launches)
     assert lib.deqsci_gram_ref_fusable(1, 2048) == 1 and lib.deqsci_gram_ref_fusable(1, 2048 + 4) == 0 and lib.deqsci_gram_ref_fusable(64, 1 << 22) == 0
     assert lib.deqsci_gram_ref_fusable(0, 2048) == 0
     assert lib.deqsci_residual_store_ref_f32(None, None, None, None, None, None, None, None, 1, 2048, 5, 0, 1, None) == -1

@@ -25,8 +25,8 @@ def timed(fn, reps=40):
     return 1e3 * e0.elapsed_time(e1) / reps
 
 
-for bsz in (8, 4, 1):
-    N, m = 1 << 19, 5
+for bsz, N in ((8, 1 << 19), (4, 1 << 19), (1, 1 << 19)) + (((2, 1 << 22), (8, 1 << 22)) if os.environ.get("GRAM_BIG") else ()):
+    m = 5
     g = torch.Generator(device="cuda").manual_seed(5)
     base = torch.randn(bsz, 1, N, device="cuda", generator=g) ** 3
     rows = ((base * (1 + 0.05 * torch.arange(m, device="cuda").view(1, m, 1)) + 0.3 * torch.randn(bsz, m, N, device="cuda", generator=g) ** 3) * 1e-3).contiguous()
@@ -37,7 +37,7 @@ for bsz in (8, 4, 1):
         _hip.anderson_solve(ws, k, k + 1, k + 1 if k else 0, 1e-2, 1e-5, ref=True)
     z = rows[:, 2].contiguous()
     noise = torch.zeros_like(z)
-    out = {"bsz": bsz}
+    out = {"bsz": bsz, "N": N}
     out["K4"] = timed(lambda: _hip.residual_store(ws, z, noise, zero, 2, m, None))
     out["K4 + first pass fused"] = timed(lambda: _hip.residual_store(ws, z, noise, zero, 2, m, None, ref=True))
 
