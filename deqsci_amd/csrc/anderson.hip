@@ -1327,7 +1327,9 @@ int deqsci_gram_row_chain16_f32(const float* G_hist, const float* partials, floa
 
 // (N / 2048 <= 256 blocks per sample: every block reads ALL its predecessors' granules - at N = 2^22, 2048 blocks per sample in several residency
 //  rounds, the fused launch is SLOWER than the two launches (bsz 2: 241 against 202 us for K4 + Gram + solve; bsz 8: 770 against 557:
-//  tools/gram_fused_time.py with GRAM_BIG=1); a two-level look-back would lift that, the two launches serve until then)
+//  tools/gram_fused_time.py with GRAM_BIG=1).  A two-level look-back - the group's 255 predecessors + one inclusive prefix per group of 256 - was
+//  built and measured: 176 / 563 us for the fused launch against 186 / 642, still behind K4 + the separate pass (48 + 80 / 202 + 140): at four and
+//  more residency rounds of blocks that wait for one another the launch is slower than the sum of its parts, not its look-back; not kept)
 int deqsci_gram_ref_fusable(int64_t bsz, int64_t N) {
     return (bsz > 0 && N > 0 && N % (2 * RND_TILE) == 0 && N / (2 * RND_TILE) <= 256 && chunk_elems(bsz, N) == 2 * RND_TILE) ? 1 : 0;
 }
