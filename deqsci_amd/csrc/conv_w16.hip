@@ -56,6 +56,9 @@
 #define W16_DMA4 0          // (A/B) 1: waves 0-3 - the older wave of every SIMD, which the arbiter serves first and which then waits ~1300 cycles per
                             // half-stage at the barrier for its partner - issue ALL the LDS-DMA instructions (two per slot), waves 4-7 none
 #endif
+#ifndef W16_EPI_PK
+#define W16_EPI_PK 1        // (A/B) 0: round 5 - the epilogue's additions and multiply-adds one cout at a time
+#endif
 #ifndef W16_STORE_NOW
 #define W16_STORE_NOW 1     // (A/B) 0: round 5 - a tile's outputs always wait for the end of its epilogue
 #endif
@@ -69,6 +72,7 @@ namespace w16 {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
@@ -101,6 +105,12 @@ __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& hi, uns
 // (single v_sub / v_add by inline asm: left to itself hipcc pairs them into v_pk_add_f32, 19 cycles beside an MFMA against 2 x 5)
 __device__ __forceinline__ float sub1(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float add1(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// packed fp32 (two values per instruction, each lane-wise IEEE operation the scalar one): spelled out, because hipcc packs the additions of a
+// float2 expression but scalarises its subtractions
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
 struct StackLayer { const char* w; const float* bias; int w_exp; int relu; };
 constexpr unsigned STACK_SPIN_LIMIT = 1u << 21;                // polls, one every ~0.1 us: a wait gives up after a quarter of a second
@@ -550,6 +560,23 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const f32x4 bz = *reinterpret_cast<const lds_f32x4*>(bsl + 32 * g + 8 * gq + 4 * kb) * dp.bscale;
+#if W16_EPI_PK
+                    // (round 6) two couts per instruction: v_pk_add_f32 / v_pk_fma_f32 - the same IEEE operations lane by lane (the same bits), half the
+                    // issue slots; nothing competes for them here: both waves of the SIMD are in their epilogues, no MFMA runs beside them
+#pragma unroll
+                    for (int k = 0; k < 4; k += 2) {
+                        const int i = 4 * gq + k;
+                        const f32x2 m0 = {acc[0][g][i], acc[0][g][i + 1]}, m1 = {acc[1][g][i], acc[1][g][i + 1]};
+                        const f32x2 m2 = {acc[2][g][i], acc[2][g][i + 1]}, m3 = {acc[3][g][i], acc[3][g][i + 1]};
+                        const f32x2 y0 = pk_add(pk_add(m0, m1), m2), y1 = pk_sub(pk_sub(m1, m2), m3);
+                        const f32x2 sc = {dp.oscale, dp.oscale}, b2 = {bz[k], bz[k + 1]};
+                        const f32x2 z0 = pk_fma(y0, sc, b2), z1 = pk_fma(y1, sc, b2);
+                        o[g][gq][0][k] = __builtin_elementwise_maximum(z0.x, floor_);
+                        o[g][gq][0][k + 1] = __builtin_elementwise_maximum(z0.y, floor_);
+                        o[g][gq][1][k] = __builtin_elementwise_maximum(z1.x, floor_);
+                        o[g][gq][1][k + 1] = __builtin_elementwise_maximum(z1.y, floor_);
+                    }
+#else
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int i = 4 * gq + k;
@@ -558,6 +585,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
                         o[g][gq][0][k] = __builtin_elementwise_maximum(__builtin_fmaf(y0, dp.oscale, bz[k]), floor_);
                         o[g][gq][1][k] = __builtin_elementwise_maximum(__builtin_fmaf(y1, dp.oscale, bz[k]), floor_);
                     }
+#endif
                     if (store_now) { store_step(2 * (4 * g + gq)); store_step(2 * (4 * g + gq) + 1); }
                 }
             }
