@@ -197,12 +197,14 @@ def config2_shipped_clips(args, dev):
     for name, batch in (("one_by_one", False), ("clip_batched", True), ("all_clips_one_batch", "all")):
         for _ in range(2):                                     # eager warm-up of every shape, then its hipGraph capture
             evaluate(deq, clips, batch=batch)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        avg, _ = evaluate(deq, clips, batch=batch)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": 64 / dt, "unit": "frames/s", "avg_psnr_db": avg}
+        dts = []
+        for _ in range(2):                                     # two timed passes, the faster one (a pass is 0.45-0.6 s: one allocator hiccup is 15 % of it)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            avg, _ = evaluate(deq, clips, batch=batch)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        out[name] = {"value": 64 / min(dts), "unit": "frames/s", "avg_psnr_db": avg, "passes_s": [round(v, 4) for v in dts]}
     if args.iters == 180:
         g = os.path.join(ROOT, "tests", "golden")
         with open(os.path.join(g, "e2e_ffdnet_anderson_180.json")) as fh:
