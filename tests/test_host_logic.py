@@ -262,6 +262,13 @@ def test_cli_accepts_every_reference_flag():
                              "--savepath", "s/", "--trainpath", "t/", "--testpath", "d/", "--loadpath", "m.ckpt", "--denoiser", "SimpleCNN",
                              "--inference", "True", "--print_every_n_steps", "1", "--save_every_n_steps", "5", "--sigma", "10"])
     assert a.and_maxiters == 180 and a.and_m == 4 and a.etainit == 0.9 and a.sigma == 10 and a.gpu_ids == "0,1"
+    # this build's own flags: the batching of the harness (none = the reference's one-by-one schedule; bare = a clip per call; all = every clip
+    # of one frame size in one call) and the arithmetic of alpha (the reference's by default)
+    assert a.batch_measurements is None and a.anderson_arith == "reference"
+    assert parser().parse_args(["--batch_measurements"]).batch_measurements == "clip"
+    assert parser().parse_args(["--batch_measurements", "all", "--anderson_arith", "float64"]).batch_measurements == "all"
+    with pytest.raises(SystemExit):
+        parser().parse_args(["--anderson_arith", "reference-bmm"])
     with pytest.raises(NotImplementedError):
         cli_main(["--denoiser", "unet"])
 
