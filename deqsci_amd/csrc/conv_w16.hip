@@ -64,7 +64,7 @@
 #endif
 #ifndef W16_ABL
 #define W16_ABL 0     // timing ablations only (results wrong): 1 = no DMA inside the half-stages, 2 = no transform, 4 = no epilogue, 8 = epilogue without its stores,
-                      // 16 = what-if: the transform shared through LDS (see xf_step)
+                      // 16 = what-if: the transform shared through LDS, 32 = what-if: the instruction mix of 4 x 64 tiles with one cout group per wave (see xf_step)
 #endif
 
 namespace deqsci {
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     __shared__ uint32_t poll_s[64];                            // (STACK) the words wave 0 polled in the shadow of half-stage 4 (by LDS-DMA: no register
                                                                // waits for a load that lands a half-stage later)
     __shared__ uint32_t voff_s[RAW_INSTR * TBW];               // per-lane global offsets of the halo-tile DMA instructions (see voff_set)
-    __shared__ __attribute__((aligned(16))) char abl_v[(W16_ABL & 16) ? 4096 : 16];      // (W16_ABL & 16: the what-if's dummy V tile)
+    __shared__ __attribute__((aligned(16))) char abl_v[(W16_ABL & 48) ? 4096 : 16];      // (W16_ABL & 16: the what-if's dummy V tile)
     const int lane = (int)(threadIdx.x & 63);
     const int wave = (int)uniform((uint32_t)(threadIdx.x >> 6));
     int t_first, t_step, t_end;
@@ -289,6 +289,23 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
     // the micro-step of gap i (0 .. 11) of a group:  [load f0][-][-][-][xf][xf][split + load f1][split][xf][xf][split][split]
     auto xf_step = [&](int i, int rb, int rho, int hh, int ns) __attribute__((always_inline)) {
         if (W16_ABL & 2) return;
+        if (W16_ABL & 32) {
+            // WHAT-IF (results wrong): the instruction mix of block tiles of 4 x 64 pixels with a wave = one row x ONE cout group (the geometry whose
+            // shared V fits the LDS), per 36 MFMAs: two row transforms instead of three (78 vector instructions, 12 raw
+            // reads), 6 V writes and 24 V reads from the dummy tile beside the 24 weight-fragment reads
+            __attribute__((address_space(3))) u32x4* dv = (__attribute__((address_space(3))) u32x4*)abl_v + lane;
+            if (rho == 2) {
+                if (i < 8) { u32x4 t_ = dv[64 * (i & 3)]; asm volatile("" :: "v"(t_)); }
+                if (i == 0) { Vh[ns][0] = dv[0]; Vl[ns][0] = dv[64]; Vh[ns][1] = dv[128]; Vl[ns][1] = dv[192]; }
+                return;
+            }
+            if (i < 8) { u32x4 t_ = dv[64 * (i & 3)]; asm volatile("" :: "v"(t_)); }      // (16 more V reads over the two transformed rows)
+            if (i == 11) {
+                t_split(1, ns, 1);
+                dv[0] = Vh[ns][0]; dv[64] = Vl[ns][0]; dv[128] = Vh[ns][1];
+                return;
+            }
+        }
         if (W16_ABL & 16) {
             // WHAT-IF (results wrong): every halo row transformed ONCE per workgroup and shared through LDS - a wave transforms 1.25 rows per
             // half-stage instead of 3 (its middle row; the first row of its successor only in waves 0 and 1) and WRITES their V (4 x 16 bytes per
