@@ -83,6 +83,46 @@ def wino16_layer(x, w, bias, relu):
     return out
 
 
+def wino16_fixed_layer(x, w, bias, relu, grid_bits=10):
+    """(round 6) the same layer with a CHEAPER input transform: the activation split on a FIXED grid per image - hi = the
+    multiple of q = 2^(12 - grid_bits) nearest to 2^e x (at most grid_bits bits below the image's maximum, so that a difference of two hi pieces is
+    exact in fp16), lo = fp16(2^e x - hi) - and B^T d formed on the pieces separately in fp16 (v_pk_add_f16: V_hi exact, V_lo rounded to fp16):
+    16 packed additions per halo row and half-stage instead of 16 fp32 subtractions + 24 split instructions."""
+    n, C, H, W = x.shape
+    U = torch.einsum('xk,ocyk->yxoc', G, w.double()).float()
+    sw = 13 - int(np.floor(np.log2(float(U.abs().max()))))
+    Uh, Ul = split(U * pow2(sw))
+    q = pow2(12 - grid_bits)
+    out = torch.empty_like(x)
+    for i in range(n):
+        e = act_exp(x[i].abs().max())
+        xs = x[i] * pow2(e)
+        dh = torch.round(xs / q) * q                                                 # exact in fp16: |dh / q| <= 2^grid_bits
+        dl = (xs - dh).half().float()
+        tiles_h = F.pad(dh, (1, 1, 1, 1)).unfold(2, 4, 2)
+        tiles_l = F.pad(dl, (1, 1, 1, 1)).unfold(2, 4, 2)
+        Vh = torch.einsum('xj,crtj->xrct', BT, tiles_h)
+        assert bool((Vh.half().float() == Vh).all())                                 # (the hi differences are fp16 numbers)
+        Vl = torch.einsum('xj,crtj->xrct', BT.double(), tiles_l.double()).half().float()     # one fp16 rounding per packed addition
+        M = []
+        for xi in range(4):
+            rows = []
+            for r in range(H):
+                terms = []
+                for dy in range(3):
+                    terms += [(Ul[dy, xi], Vh[xi, r + dy]), (Uh[dy, xi], Vl[xi, r + dy]), (Uh[dy, xi], Vh[xi, r + dy])]
+                rows.append(chain_k16(terms))
+            M.append(torch.stack(rows, 1))
+        M = torch.stack(M, 0)
+        y0 = (M[0] + M[1]) + M[2]
+        y1 = (M[1] - M[2]) - M[3]
+        y = torch.stack((y0, y1), -1).reshape(C, H, W) * pow2(-e - sw)
+        if bias is not None:
+            y = y + bias.view(-1, 1, 1)
+        out[i] = torch.relu(y) if relu else y
+    return out
+
+
 def direct16_layer(x, w, bias, relu):
     """The split-fp16 direct convolution of csrc/conv_s16.hip, emulated the same way: two chains (hi.hi | cross), 144 / 288 steps."""
     n, C, H, W = x.shape
@@ -136,6 +176,8 @@ def main():
             ref = torch.relu(F.conv2d(h.double(), w.double(), b.double(), padding=1))
             row = {"layer": (li - 2) // 3 + 1,
                    "wino16 F(2,3)x nested (emulated)": rel(wino16_layer(h, w, b, True), ref),
+                   "wino16, hi on a fixed 10-bit grid, packed fp16 transform (emulated)": rel(wino16_fixed_layer(h, w, b, True, 10), ref),
+                   "... 9-bit grid": rel(wino16_fixed_layer(h, w, b, True, 9), ref),
                    "s16 direct two chains (emulated)": rel(direct16_layer(h, w, b, True), ref),
                    "fp32 conv2d (oneDNN)": rel(torch.relu(F.conv2d(h, w, b, padding=1)), ref)}
             rows.append(row)
