@@ -62,6 +62,9 @@
 #ifndef W16_STORE_NOW
 #define W16_STORE_NOW 1     // (A/B) 0: round 5 - a tile's outputs always wait for the end of its epilogue
 #endif
+#ifndef W16_XF_PK
+#define W16_XF_PK 0         // (A/B) 1: the input transform's subtractions as packed fp32 (two channels per instruction, the same bits)
+#endif
 #ifndef W16_ABL
 #define W16_ABL 0     // timing ablations only (results wrong): 1 = no DMA inside the half-stages, 2 = no transform, 4 = no epilogue, 8 = epilogue without its stores,
                       // 16 = what-if: the transform shared through LDS, 32 = what-if: the instruction mix of 4 x 64 tiles with one cout group per wave (see xf_step)
@@ -273,6 +276,14 @@ __global__ __launch_bounds__(TBW, 2) void conv_w16_kernel(const char* __restrict
         return __builtin_bit_cast(float, u);
     };
     auto t_xf = [&](int s, int hh) __attribute__((always_inline)) {  // s = 0, 1: channels 2 s, 2 s + 1 of the half
+#if W16_XF_PK
+        {
+            const f32x2 d0 = {px(0, 2 * s), px(0, 2 * s + 1)}, d1 = {px(1, 2 * s), px(1, 2 * s + 1)}, d2 = {px(2, 2 * s), px(2, 2 * s + 1)};
+            const f32x2 a = hh == 0 ? pk_sub(d0, d2) : pk_sub(d1, d0), b = hh == 0 ? pk_add(d1, d2) : pk_sub(d0, d2);
+            va[2 * s] = a[0]; va[2 * s + 1] = a[1]; vb[2 * s] = b[0]; vb[2 * s + 1] = b[1];
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 2 * s; k < 2 * s + 2; ++k) {
             if (hh == 0) { va[k] = sub1(px(0, k), px(2, k)); vb[k] = add1(px(1, k), px(2, k)); }
